@@ -1,0 +1,19 @@
+"""f3dgaus_amd -- MI355X-native GOF rasterization + cycle-aggregative projection for F3D-Gaus.
+
+The directory is named ``f3d-gaus_amd`` (not an identifier); import it as ``f3dgaus_amd`` through the shim module
+at the repo root, or with ``importlib.import_module("f3d-gaus_amd")``. Importing the package also registers the
+drop-in ``diff_gof_rasterization`` module name so the reference's own import line resolves to this build.
+"""
+import sys as _sys
+
+from . import _lib, build, cameras  # noqa: F401
+from . import diff_gof_rasterization  # noqa: F401
+
+# `from diff_gof_rasterization import GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF`
+# (reference src/gaussian_renderer/__init__.py:10) resolves to this build unless another one is already loaded.
+_sys.modules.setdefault("diff_gof_rasterization", diff_gof_rasterization)
+
+from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF,  # noqa: E402,F401
+                                     rasterize_views)
+
+__version__ = "0.1.0"

@@ -1,0 +1,60 @@
+"""Builds libf3dg_hip.so (the C-ABI library of include/f3dg.h) for gfx950 with hipcc, in-tree.
+
+Flags that matter for parity (DESIGN.md "numerics"):
+  -ffp-contract=off       hipcc defaults to 'fast' (FMA contraction); the GOF exponent cancels 1e5..1e6 x, so the
+                          reference's separate multiply/add roundings are kept
+  no -ffast-math, IEEE fp32 divide/sqrt (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), denormals kept.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libf3dg_hip.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    srcs = sources()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "f3dg.h"))
+    objs = [s[:-4] + ".o" for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if force or _stale(obj, [src] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return True
+        return False
+
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        rebuilt = list(ex.map(compile_one, zip(srcs, objs)))
+    if force or any(rebuilt) or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,218 @@
+// f3dg_api.hip -- the C ABI (include/f3dg.h): workspace carving and launch orchestration.
+//
+// Host-side counterpart of CudaRasterizer::Rasterizer::forward (reference
+// RAST/cuda_rasterizer/rasterizer_impl.cu:247-405) and of the chunk carving in :188-243 / rasterizer_impl.h:23-89,
+// re-designed so that a call never blocks: the instance count stays on the device, the workspace is sized once
+// for a capacity, and all views of a batch go through one launch sequence.
+#include "f3dg_common.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+__global__ void init_header_kernel(F3dgHeader* hdr, unsigned capacity)
+{
+    if (threadIdx.x < 64) {
+        unsigned* w = reinterpret_cast<unsigned*>(hdr);
+        w[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) hdr->capacity = capacity;
+}
+
+__global__ void fill_background_kernel(int V, size_t HW, const float* __restrict__ bg, int bg_per_view,
+                                       float* __restrict__ out)
+{
+    // P == 0: the reference skips the rasterizer and returns the zero-initialised tensor (rasterize_points.cu:72,85)
+    const size_t n = (size_t)V * F3DG_OUT_CHANNELS * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = 0.0f;
+    (void)bg; (void)bg_per_view;
+}
+
+} // namespace
+
+int f3dg_set_hip_error(hipError_t e, const char* where)
+{
+    snprintf(g_last_error, sizeof g_last_error, "%s: %s", where, hipGetErrorString(e));
+    return F3DG_ERR_HIP;
+}
+
+extern "C" const char* f3dg_version(void) { return "f3dg-hip gfx950 0.1.0"; }
+extern "C" const char* f3dg_last_error(void) { return g_last_error; }
+
+int f3dg_sort_passes(int V, int T);
+
+F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
+{
+    F3dgLayout L;
+    memset(&L, 0, sizeof L);
+    const size_t VP = (size_t)V * (size_t)(P > 0 ? P : 1);
+    const size_t HW = (size_t)W * H;
+    const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
+    const size_t C = (size_t)(cap > 0 ? cap : 1);
+    L.sort_blocks = (unsigned)((C + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK);
+    const size_t scan_a = (VP + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
+    const size_t scan_b = ((size_t)256 * L.sort_blocks + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
+    L.scan_tmp_elems = (unsigned)((scan_a > scan_b ? scan_a : scan_b) + 1);
+
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.header = take(sizeof(F3dgHeader));
+    L.rec = take(VP * sizeof(F3dgRec));
+    L.means2D = take(VP * sizeof(float2));
+    L.conic = take(VP * sizeof(float4));
+    L.radii = take(VP * sizeof(int));
+    L.tiles = take(VP * sizeof(unsigned));
+    L.offsets = take(VP * sizeof(unsigned));
+    L.clamped = take(VP);
+    L.scan_tmp = take((size_t)L.scan_tmp_elems * sizeof(unsigned));
+    L.keys[0] = take(C * 8);
+    L.keys[1] = take(C * 8);
+    L.vals[0] = take(C * 4);
+    L.vals[1] = take(C * 4);
+    L.hist = take((size_t)256 * L.sort_blocks * sizeof(unsigned));
+    L.ranges = take((size_t)V * T * sizeof(uint2));
+    L.final_T = take((size_t)V * 4 * HW * sizeof(float));
+    L.n_contrib = take((size_t)V * 2 * HW * sizeof(unsigned));
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t f3dg_workspace_bytes(int P, int W, int H, int n_views, long long max_rendered)
+{
+    if (P < 0 || W <= 0 || H <= 0 || n_views <= 0 || max_rendered < 0) return 0;
+    return f3dg_layout(P, W, H, n_views, max_rendered).total;
+}
+
+extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                    int n_views, int P, int D, int M,
+                                    const float* background, int W, int H,
+                                    const float* means3D, const float* shs, const float* colors_precomp,
+                                    const float* opacities, const float* scales, float scale_modifier,
+                                    const float* rotations, const float* cov3D_precomp,
+                                    const float* view2gaussian_precomp,
+                                    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                    float tan_fovx, float tan_fovy, float kernel_size,
+                                    float* out_color, int* radii, unsigned flags)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n_views <= 0 || P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !background || !workspace)
+        return F3DG_ERR_BAD_ARG;
+    if (max_rendered > 0xFFFFFFF0ll || (long long)n_views * P > 0xFFFFFFF0ll)
+        return F3DG_ERR_BAD_ARG;                       // instance and (view,Gaussian) indices are 32-bit
+    const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
+    if (workspace_bytes < L.total) return F3DG_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
+    const size_t HW = (size_t)W * H;
+
+    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
+
+    if (P == 0) {
+        hipLaunchKernelGGL(fill_background_kernel, dim3(1024), dim3(256), 0, s, n_views, HW, background,
+                           (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color);
+        F3DG_HIP_CHECK(hipGetLastError());
+        return F3DG_OK;
+    }
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos) return F3DG_ERR_BAD_ARG;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return F3DG_ERR_BAD_ARG;       // exactly one (rast_py:205)
+    const bool have_sr = scales != nullptr && rotations != nullptr;
+    if (have_sr == (cov3D_precomp != nullptr)) return F3DG_ERR_BAD_ARG;                 // exactly one (rast_py:208)
+    if (!have_sr && view2gaussian_precomp == nullptr) return F3DG_ERR_BAD_ARG;          // view2gaussian needs scale/rot
+    if (shs && (M <= 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)) return F3DG_ERR_BAD_ARG;
+
+    const float focal_y = H / (2.0f * tan_fovy);       // float32, rasterizer_impl.cu:274-275
+    const float focal_x = W / (2.0f * tan_fovx);
+    const int save_aux = (flags & F3DG_FLAG_SAVE_AUX) ? 1 : 0;
+    int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
+
+    int rc = f3dg_launch_preprocess(s, n_views, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+                                    cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
+                                    cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
+                                    reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
+                                    reinterpret_cast<float4*>(ws + L.conic), radii_used,
+                                    reinterpret_cast<unsigned*>(ws + L.tiles),
+                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
+    if (rc != F3DG_OK) return rc;
+
+    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, radii_used);
+    if (rc != F3DG_OK) return rc;
+
+    return f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
+                              reinterpret_cast<const uint2*>(ws + L.ranges),
+                              reinterpret_cast<const unsigned*>(ws + L.vals[0]),
+                              reinterpret_cast<const F3dgRec*>(ws + L.rec), background,
+                              (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color,
+                              reinterpret_cast<float*>(ws + L.final_T),
+                              reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux);
+}
+
+extern "C" int f3dg_read_status(void* stream, const void* workspace, long long* h_num_rendered)
+{
+    if (!workspace) return F3DG_ERR_BAD_ARG;
+    F3dgHeader h;
+    F3DG_HIP_CHECK(hipMemcpyAsync(&h, workspace, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    F3DG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (h_num_rendered) *h_num_rendered = (long long)h.num_rendered;
+    return h.overflow ? F3DG_ERR_OVERFLOW : F3DG_OK;
+}
+
+extern "C" long long f3dg_forward(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                  int P, int D, int M, const float* background, int W, int H,
+                                  const float* means3D, const float* shs, const float* colors_precomp,
+                                  const float* opacities, const float* scales, float scale_modifier,
+                                  const float* rotations, const float* cov3D_precomp,
+                                  const float* view2gaussian_precomp,
+                                  const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                  float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+                                  float* out_color, int* radii, unsigned flags, long long* h_needed)
+{
+    (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:194-198)
+    int rc = f3dg_forward_batched(stream, workspace, workspace_bytes, max_rendered, 1, P, D, M, background, W, H,
+                                  means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                  cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                                  tan_fovy, kernel_size, out_color, radii, flags & ~F3DG_FLAG_BG_PER_VIEW);
+    if (rc != F3DG_OK) return rc;
+    long long n = 0;
+    rc = f3dg_read_status(stream, workspace, &n);
+    if (h_needed) *h_needed = n;
+    if (rc != F3DG_OK) return rc;
+    return n;
+}
+
+// ---- debug/inspection: copy internal per-Gaussian state to caller buffers (used by the stage-wise parity
+// tests; mirrors the oracle's accessors). Any pointer may be NULL.
+extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int W, int H, int n_views,
+                                 long long max_rendered, float* rec /*[V*P*16]*/, float* means2D /*[V*P*2]*/,
+                                 float* conic /*[V*P*4]*/, unsigned* tiles /*[V*P]*/, unsigned* offsets /*[V*P]*/,
+                                 unsigned char* clamped /*[V*P]*/, unsigned long long* keys_sorted /*[cap]*/,
+                                 unsigned* point_list /*[cap]*/, unsigned* ranges /*[V*T*2]*/,
+                                 float* final_T /*[V*4*HW]*/, unsigned* n_contrib /*[V*2*HW]*/)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
+    const char* ws = static_cast<const char*>(workspace);
+    const size_t VP = (size_t)n_views * P, HW = (size_t)W * H;
+    const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
+    const size_t C = (size_t)max_rendered;
+#define CP(dst, off, bytes) if (dst && (bytes)) F3DG_HIP_CHECK(hipMemcpyAsync(dst, ws + (off), (bytes), hipMemcpyDeviceToDevice, s))
+    CP(rec, L.rec, VP * sizeof(F3dgRec));
+    CP(means2D, L.means2D, VP * 8);
+    CP(conic, L.conic, VP * 16);
+    CP(tiles, L.tiles, VP * 4);
+    CP(offsets, L.offsets, VP * 4);
+    CP(clamped, L.clamped, VP);
+    CP(keys_sorted, L.keys[0], C * 8);
+    CP(point_list, L.vals[0], C * 4);
+    CP(ranges, L.ranges, (size_t)n_views * T * 8);
+    CP(final_T, L.final_T, (size_t)n_views * 4 * HW * 4);
+    CP(n_contrib, L.n_contrib, (size_t)n_views * 2 * HW * 4);
+#undef CP
+    return F3DG_OK;
+}

@@ -1,0 +1,89 @@
+// f3dg_common.h -- internal declarations shared by the HIP translation units of libf3dg_hip.so.
+// gfx950 only. Parity-critical arithmetic is compiled with -ffp-contract=off (see build.py / DESIGN.md):
+// the GOF exponent cancels ~1e5..1e6 x, so the float32/float64 operation order of the reference is kept
+// literally.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/f3dg.h"
+
+#define F3DG_BLOCK 256                 // threads per workgroup = one 16x16 tile = 4 wave64
+#define F3DG_REC_FLOATS 16             // per-(view,Gaussian) compositing record, 64 B
+#define F3DG_NEAR_PLANE 0.2            // auxiliary.h:27 (double)
+#define F3DG_FAR_PLANE 100.0           // auxiliary.h:28 (double)
+#define F3DG_SORT_ITEMS 16             // keys per thread per radix block
+#define F3DG_SORT_CHUNK (F3DG_BLOCK * F3DG_SORT_ITEMS)
+#define F3DG_SCAN_ITEMS 16
+#define F3DG_SCAN_CHUNK (F3DG_BLOCK * F3DG_SCAN_ITEMS)
+
+// Workspace header (device memory, first 256 bytes of the workspace)
+struct F3dgHeader {
+    unsigned int num_rendered;   // total (Gaussian, tile) instances of the call (all views)
+    unsigned int overflow;       // 1 if num_rendered > capacity
+    unsigned int capacity;       // instance capacity the workspace was carved for
+    unsigned int sort_cur;       // which ping-pong half holds the sorted result
+    unsigned int reserved[60];
+};
+
+// Per-(view, Gaussian) record consumed by the compositing kernel: one 64-byte line.
+//   f[0..9]  view2gaussian (Sigma' upper triangle, B, C)      forward.cu:268-277
+//   f[10]    opacity * coef (conic_opacity.w)                  forward.cu:392
+//   f[11..13] rgb                                              forward.cu:379-384
+//   f[14]    view-space depth                                  forward.cu:388
+//   f[15]    unused
+struct __attribute__((aligned(16))) F3dgRec { float f[F3DG_REC_FLOATS]; };
+
+// Host-side description of where each array lives inside the workspace (byte offsets).
+struct F3dgLayout {
+    size_t header;
+    size_t rec;            // [V*P] F3dgRec
+    size_t means2D;        // [V*P] float2
+    size_t conic;          // [V*P] float4 (conic.xyz, opacity*coef) -- backward only
+    size_t radii;          // [V*P] int   (internal copy when the caller passes none)
+    size_t tiles;          // [V*P] u32   tiles_touched
+    size_t offsets;        // [V*P] u32   inclusive scan of tiles_touched
+    size_t clamped;        // [V*P] u8    bit c set when SH colour channel c was clamped
+    size_t scan_tmp;       // u32 block sums for the scans
+    size_t keys[2];        // [cap] u64 ping-pong
+    size_t vals[2];        // [cap] u32 ping-pong
+    size_t hist;           // [256 * sort_blocks] u32
+    size_t ranges;         // [V*T] uint2
+    size_t final_T;        // [V][4][H*W] float
+    size_t n_contrib;      // [V][2][H*W] u32
+    size_t total;
+    unsigned int sort_blocks;
+    unsigned int scan_tmp_elems;
+};
+
+F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap);
+
+int f3dg_set_hip_error(hipError_t e, const char* where);
+#define F3DG_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return f3dg_set_hip_error(_e, #expr); } while (0)
+
+struct F3dgViewConsts {           // passed by pointer: [V] of these are the caller's flat arrays
+    const float* viewmatrix;      // [V,16]
+    const float* projmatrix;      // [V,16]
+    const float* cam_pos;         // [V,3]
+};
+
+// ---- launchers (each returns F3DG_OK or a negative error) -------------------------------------------
+int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const float* means3D, const float* scales,
+                           float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                           const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
+                           float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
+                           F3dgRec* rec, float2* means2D, float4* conic, int* radii, unsigned* tiles,
+                           unsigned char* clamped, int save_aux);
+
+int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out, unsigned long long n,
+                               unsigned* tmp, unsigned tmp_elems, int exclusive,
+                               F3dgHeader* hdr_total /* if not null: write total + overflow */);
+
+int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii);
+
+int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
+                       const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
+                       const float* background, int bg_per_view, float* out_color, float* final_T,
+                       unsigned* n_contrib, int save_aux);

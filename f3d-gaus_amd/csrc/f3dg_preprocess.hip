@@ -1,0 +1,344 @@
+// f3dg_preprocess.hip -- per-(view, Gaussian) projection stage.
+//
+// Replaces preprocessCUDA<3> and its helpers (reference RAST/cuda_rasterizer/forward.cu:283-404 with
+// computeCov3D :129-163, computeCov2D :74-124, computeView2Gaussian :168-279, computeColorFromSH :20-71,
+// and auxiliary.h in_frustum :177-202, getRect :64-74, ndc2Pix :59-62).
+//
+// MI355X shape: one launch covers all views of the call (blockIdx.y = view, so the view matrices are
+// wave-uniform scalar loads), every thread owns one Gaussian, and everything the compositing kernel needs
+// about a Gaussian is packed into ONE 64-byte record so the later gather touches a single half cache line.
+// The arithmetic keeps the reference's float/double operation order (file is built with -ffp-contract=off).
+#include "f3dg_common.h"
+
+namespace {
+
+__device__ __constant__ float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                           -1.0925484305920792f, 0.5462742152960396f };
+__device__ __constant__ float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f };
+
+// 3x3 column-major matrix, m[col][row]; products follow glm 0.9.9.9's evaluation order:
+// R[c][r] = (A[0][r]*B[c][0] + A[1][r]*B[c][1]) + A[2][r]*B[c][2]
+struct M3 { float m[3][3]; };
+
+__device__ __forceinline__ M3 mul(const M3& a, const M3& b)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = a.m[0][q] * b.m[c][0] + a.m[1][q] * b.m[c][1] + a.m[2][q] * b.m[c][2];
+    return r;
+}
+__device__ __forceinline__ M3 transpose(const M3& a)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = a.m[q][c];
+    return r;
+}
+
+// Rotation from the (r,x,y,z) quaternion, NOT normalised (forward.cu:138-149); arguments are columns.
+__device__ __forceinline__ M3 quat_to_R(float4 q)
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    M3 R;
+    R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[0][1] = 2.f * (x * y - r * z);       R.m[0][2] = 2.f * (x * z + r * y);
+    R.m[1][0] = 2.f * (x * y + r * z);       R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[1][2] = 2.f * (y * z - r * x);
+    R.m[2][0] = 2.f * (x * z - r * y);       R.m[2][1] = 2.f * (y * z + r * x);       R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+    return R;
+}
+
+__device__ __forceinline__ float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+preprocess_kernel(int P, int D, int M,
+                  const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
+                  const float* __restrict__ rotations, const float* __restrict__ opacities,
+                  const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                  const float* __restrict__ colors_precomp, const float* __restrict__ v2g_precomp,
+                  const float* __restrict__ viewmatrices, const float* __restrict__ projmatrices,
+                  const float* __restrict__ cam_positions, int W, int H, int grid_x, int grid_y,
+                  float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
+                  F3dgRec* __restrict__ rec, float2* __restrict__ means2D, float4* __restrict__ conic_out,
+                  int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
+                  unsigned char* __restrict__ clamped, int save_aux)
+{
+    const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    const int v = blockIdx.y;
+    if (g >= P)
+        return;
+    const size_t idx = (size_t)v * P + g;
+    const float* view = viewmatrices + 16 * v;      // wave-uniform -> scalar loads
+    const float* proj = projmatrices + 16 * v;
+
+    int my_radii = 0;
+    unsigned my_tiles = 0;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;   // the 64-byte record
+    float2 xy = make_float2(0, 0);
+    float4 con = make_float4(0, 0, 0, 0);
+    unsigned char clamp_bits = 0;
+
+    const float px_ = means3D[3 * (size_t)g], py_ = means3D[3 * (size_t)g + 1], pz_ = means3D[3 * (size_t)g + 2];
+
+    // in_frustum (auxiliary.h:177-202): near cull only, the x/y test is commented out in the reference
+    const float pvx = view[0] * px_ + view[4] * py_ + view[8] * pz_ + view[12];
+    const float pvy = view[1] * px_ + view[5] * py_ + view[9] * pz_ + view[13];
+    const float pvz = view[2] * px_ + view[6] * py_ + view[10] * pz_ + view[14];
+
+    if (!(pvz <= 0.2f)) {
+        const float hx = proj[0] * px_ + proj[4] * py_ + proj[8] * pz_ + proj[12];
+        const float hy = proj[1] * px_ + proj[5] * py_ + proj[9] * pz_ + proj[13];
+        const float hw = proj[3] * px_ + proj[7] * py_ + proj[11] * pz_ + proj[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+
+        float3 scale = make_float3(0, 0, 0);
+        float4 rot = make_float4(1, 0, 0, 0);
+        if (scales) scale = make_float3(scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]);
+        if (rotations) rot = reinterpret_cast<const float4*>(rotations)[g];
+
+        // ---- computeCov3D (forward.cu:129-163) or the precomputed one
+        float c3[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)g + i];
+        } else {
+            M3 S = {};
+            S.m[0][0] = scale_modifier * scale.x;
+            S.m[1][1] = scale_modifier * scale.y;
+            S.m[2][2] = scale_modifier * scale.z;
+            const M3 R = quat_to_R(rot);
+            const M3 Mm = mul(S, R);
+            const M3 Sigma = mul(transpose(Mm), Mm);
+            c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
+            c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+        }
+
+        // ---- computeCov2D (forward.cu:74-124)
+        float tx = pvx, ty = pvy;
+        const float tz = pvz;
+        const float limx = 1.3f * tan_fovx;
+        const float limy = 1.3f * tan_fovy;
+        const float txtz = tx / tz;
+        const float tytz = ty / tz;
+        tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+
+        M3 J;
+        J.m[0][0] = focal_x / tz; J.m[0][1] = 0.0f;         J.m[0][2] = -(focal_x * tx) / (tz * tz);
+        J.m[1][0] = 0.0f;         J.m[1][1] = focal_y / tz; J.m[1][2] = -(focal_y * ty) / (tz * tz);
+        J.m[2][0] = 0.0f;         J.m[2][1] = 0.0f;         J.m[2][2] = 0.0f;
+        M3 Wm;
+        Wm.m[0][0] = view[0]; Wm.m[0][1] = view[4]; Wm.m[0][2] = view[8];
+        Wm.m[1][0] = view[1]; Wm.m[1][1] = view[5]; Wm.m[1][2] = view[9];
+        Wm.m[2][0] = view[2]; Wm.m[2][1] = view[6]; Wm.m[2][2] = view[10];
+        const M3 T = mul(Wm, J);
+        M3 Vrk;
+        Vrk.m[0][0] = c3[0]; Vrk.m[0][1] = c3[1]; Vrk.m[0][2] = c3[2];
+        Vrk.m[1][0] = c3[1]; Vrk.m[1][1] = c3[3]; Vrk.m[1][2] = c3[4];
+        Vrk.m[2][0] = c3[2]; Vrk.m[2][1] = c3[4]; Vrk.m[2][2] = c3[5];
+        const M3 cov = mul(mul(transpose(T), transpose(Vrk)), T);
+
+        const float det_0 = (float)fmax(1e-6, (double)(cov.m[0][0] * cov.m[1][1] - cov.m[0][1] * cov.m[0][1]));
+        const float det_1 = (float)fmax(1e-6, (double)((cov.m[0][0] + kernel_size) * (cov.m[1][1] + kernel_size) - cov.m[0][1] * cov.m[0][1]));
+        float coef = (float)sqrt(det_0 / (det_1 + 1e-6) + 1e-6);
+        if (det_0 <= 1e-6 || det_1 <= 1e-6)
+            coef = 0.0f;
+        const float cx = cov.m[0][0] + kernel_size;
+        const float cy = cov.m[0][1];
+        const float cz = cov.m[1][1] + kernel_size;
+
+        // ---- invert, extent, tile rectangle (forward.cu:350-374)
+        const float det = (cx * cz - cy * cy);
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conic_x = cz * det_inv, conic_y = -cy * det_inv, conic_z = cx * det_inv;
+            const float mid = 0.5f * (cx + cz);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float pix_x = ndc2Pix(projx, W), pix_y = ndc2Pix(projy, H);
+            const int max_radius = (int)my_radius;
+            const int rminx = min(grid_x, max(0, (int)((pix_x - max_radius) / F3DG_TILE)));
+            const int rminy = min(grid_y, max(0, (int)((pix_y - max_radius) / F3DG_TILE)));
+            const int rmaxx = min(grid_x, max(0, (int)((pix_x + max_radius + F3DG_TILE - 1) / F3DG_TILE)));
+            const int rmaxy = min(grid_y, max(0, (int)((pix_y + max_radius + F3DG_TILE - 1) / F3DG_TILE)));
+            const int area = (rmaxx - rminx) * (rmaxy - rminy);
+            if (area != 0) {
+                // ---- colour (forward.cu:20-71) or precomputed
+                float cr, cg, cb;
+                if (colors_precomp) {
+                    cr = colors_precomp[3 * (size_t)g]; cg = colors_precomp[3 * (size_t)g + 1]; cb = colors_precomp[3 * (size_t)g + 2];
+                } else {
+                    const float* campos = cam_positions + 3 * v;
+                    float dx = px_ - campos[0], dy = py_ - campos[1], dz = pz_ - campos[2];
+                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx = dx / len; dy = dy / len; dz = dz / len;
+                    const float* sh = shs + (size_t)g * M * 3;
+                    float res[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) res[ch] = SH_C0 * sh[ch];
+                    if (D > 0) {
+                        const float x = dx, y = dy, z = dz;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            res[ch] = res[ch] - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
+                        if (D > 1) {
+                            const float xx = x * x, yy = y * y, zz = z * z;
+                            const float xy_ = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                                res[ch] = res[ch] +
+                                    SH_C2[0] * xy_ * sh[12 + ch] +
+                                    SH_C2[1] * yz * sh[15 + ch] +
+                                    SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] +
+                                    SH_C2[3] * xz * sh[21 + ch] +
+                                    SH_C2[4] * (xx - yy) * sh[24 + ch];
+                            if (D > 2) {
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++)
+                                    res[ch] = res[ch] +
+                                        SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] +
+                                        SH_C3[1] * xy_ * z * sh[30 + ch] +
+                                        SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                                        SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] +
+                                        SH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                                        SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        res[ch] += 0.5f;
+                        if (res[ch] < 0) clamp_bits |= (unsigned char)(1u << ch);
+                        res[ch] = fmaxf(res[ch], 0.0f);
+                    }
+                    cr = res[0]; cg = res[1]; cb = res[2];
+                }
+
+                // ---- view2gaussian (forward.cu:168-279) or precomputed [V,P,10]
+                float vg[10];
+                if (v2g_precomp) {
+#pragma unroll
+                    for (int i = 0; i < 10; i++) vg[i] = v2g_precomp[idx * 10 + i];
+                } else {
+                    const M3 R = quat_to_R(rot);
+                    // G2V = W2V * G2W (glm mat4 product, 4 terms left to right); G2W columns are the ROWS of R
+                    // with the mean as 4th column; W2V[c][r] = view[4c + r].
+                    float G2V[4][3];   // [col][row], rows 0..2 only (row 3 is never read)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float b0 = R.m[0][c], b1 = R.m[1][c], b2 = R.m[2][c];    // G2W[c] = (R[0][c], R[1][c], R[2][c], 0)
+#pragma unroll
+                        for (int q = 0; q < 3; q++)
+                            G2V[c][q] = view[q] * b0 + view[4 + q] * b1 + view[8 + q] * b2 + view[12 + q] * 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+                        G2V[3][q] = view[q] * px_ + view[4 + q] * py_ + view[8 + q] * pz_ + view[12 + q] * 1.0f;
+
+                    M3 Rt;   // "R_transpose": columns (G2V[0][k], G2V[1][k], G2V[2][k])
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        Rt.m[c][0] = G2V[0][c]; Rt.m[c][1] = G2V[1][c]; Rt.m[c][2] = G2V[2][c];
+                    }
+                    const float t_x = G2V[3][0], t_y = G2V[3][1], t_z = G2V[3][2];
+                    // t2 = (-R_transpose) * t
+                    const float t2x = (-Rt.m[0][0]) * t_x + (-Rt.m[1][0]) * t_y + (-Rt.m[2][0]) * t_z;
+                    const float t2y = (-Rt.m[0][1]) * t_x + (-Rt.m[1][1]) * t_y + (-Rt.m[2][1]) * t_z;
+                    const float t2z = (-Rt.m[0][2]) * t_x + (-Rt.m[1][2]) * t_y + (-Rt.m[2][2]) * t_z;
+
+                    const double Sx = 1.0f / ((double)scale.x * scale.x + 1e-7);
+                    const double Sy = 1.0f / ((double)scale.y * scale.y + 1e-7);
+                    const double Sz = 1.0f / ((double)scale.z * scale.z + 1e-7);
+                    const double Cc = t2x * t2x * Sx + t2y * t2y * Sy + t2z * t2z * Sz;
+
+                    M3 SR;
+                    SR.m[0][0] = (float)(Sx * Rt.m[0][0]); SR.m[0][1] = (float)(Sy * Rt.m[0][1]); SR.m[0][2] = (float)(Sz * Rt.m[0][2]);
+                    SR.m[1][0] = (float)(Sx * Rt.m[1][0]); SR.m[1][1] = (float)(Sy * Rt.m[1][1]); SR.m[1][2] = (float)(Sz * Rt.m[1][2]);
+                    SR.m[2][0] = (float)(Sx * Rt.m[2][0]); SR.m[2][1] = (float)(Sy * Rt.m[2][1]); SR.m[2][2] = (float)(Sz * Rt.m[2][2]);
+
+                    // B = t2 * SR (row vector times matrix): B_c = (SR[c][0]*t2.x + SR[c][1]*t2.y) + SR[c][2]*t2.z
+                    const float Bx = SR.m[0][0] * t2x + SR.m[0][1] * t2y + SR.m[0][2] * t2z;
+                    const float By = SR.m[1][0] * t2x + SR.m[1][1] * t2y + SR.m[1][2] * t2z;
+                    const float Bz = SR.m[2][0] * t2x + SR.m[2][1] * t2y + SR.m[2][2] * t2z;
+                    const M3 Sig = mul(transpose(Rt), SR);
+                    vg[0] = Sig.m[0][0]; vg[1] = Sig.m[0][1]; vg[2] = Sig.m[0][2];
+                    vg[3] = Sig.m[1][1]; vg[4] = Sig.m[1][2]; vg[5] = Sig.m[2][2];
+                    vg[6] = Bx; vg[7] = By; vg[8] = Bz; vg[9] = (float)Cc;
+                }
+
+                const float opac = opacities[g] * coef;
+                my_radii = max_radius;
+                my_tiles = (unsigned)area;
+                xy = make_float2(pix_x, pix_y);
+                con = make_float4(conic_x, conic_y, conic_z, opac);
+                r0 = make_float4(vg[0], vg[1], vg[2], vg[3]);
+                r1 = make_float4(vg[4], vg[5], vg[6], vg[7]);
+                r2 = make_float4(vg[8], vg[9], opac, cr);
+                r3 = make_float4(cg, cb, pvz, 0.0f);
+            }
+        }
+    }
+
+    radii[idx] = my_radii;
+    tiles_touched[idx] = my_tiles;
+    means2D[idx] = xy;
+    float4* dst = reinterpret_cast<float4*>(rec + idx);
+    dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+    if (save_aux) {
+        conic_out[idx] = con;
+        clamped[idx] = clamp_bits;
+    }
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view,
+                                    unsigned char* __restrict__ present)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const float x = means3D[3 * (size_t)g], y = means3D[3 * (size_t)g + 1], z = means3D[3 * (size_t)g + 2];
+    const float pvz = view[2] * x + view[6] * y + view[10] * z + view[14];
+    present[g] = !(pvz <= 0.2f);
+}
+
+} // namespace
+
+int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const float* means3D, const float* scales,
+                           float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                           const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
+                           float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
+                           F3dgRec* rec, float2* means2D, float4* conic, int* radii, unsigned* tiles,
+                           unsigned char* clamped, int save_aux)
+{
+    const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
+    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, means3D, scales, scale_modifier,
+                       rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
+                       cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
+                       conic, radii, tiles, clamped, save_aux);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+extern "C" int f3dg_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                                 const float* projmatrix, uint8_t* present)
+{
+    (void)projmatrix;   // the reference computes p_proj but only tests view-space z (auxiliary.h:192)
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return F3DG_ERR_BAD_ARG;
+    if (P == 0) return F3DG_OK;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D,
+                       viewmatrix, present);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}

@@ -1,0 +1,175 @@
+// f3dg_splat_head.hip -- cycle-aggregative projection ("splat head") and the render epilogue.
+//
+// splat_head_kernel fuses everything GaussianSplatPredictor_gtunet.forward does after the U-Net
+// (reference src/gaussian_predictor.py): get_pos_from_network_output :857-881 (pos = ray_dirs * depth + offset),
+// the [pos,1] @ view_to_world bmm and perspective divide :961-970, sigmoid / exp / F.normalize activations
+// :976-979, transform_rotations = quaternion_raw_multiply(cam_quat, q) :839-855 / :45-64, transform_SHs
+// :821-837 with the constant sh<->v permutation matrices :649-655, flatten_vector :788-791 (NCHW -> N x C), and
+// writes straight into the aggregated per-image Gaussian buffers at `n_offset`, which replaces the torch.cat
+// chain of the cycle loop (visualize.py:336-340) -- ~15 small torch kernels + permutes + 9 reallocations become
+// one bandwidth-bound pass: 96 B read + 96 B written per Gaussian.
+//
+// epilogue_kernel fuses the post-processing of render_predicted_more_v2_gof
+// (src/gaussian_renderer/__init__.py:1043-1053 world normals, :881-909 depth_to_normal).
+#include "f3dg_common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+splat_head_kernel(int HW, const float* __restrict__ net_out, const float* __restrict__ depth,
+                  const float* __restrict__ ray_dirs, const float* __restrict__ view_to_world,
+                  const float* __restrict__ cam_quat, float squre_clip, long long n_total, long long n_offset,
+                  float* __restrict__ xyz, float* __restrict__ opacity, float* __restrict__ scaling,
+                  float* __restrict__ rotation, float* __restrict__ features_dc, float* __restrict__ features_rest,
+                  float* __restrict__ unet_depth)
+{
+    const int n = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= HW) return;
+    const float* net = net_out + (size_t)b * 23 * HW + n;       // channel c at net[c * HW]
+    const float* M = view_to_world + 16 * b;                     // row-major 4x4, row-vector convention (uniform)
+    const float* qc = cam_quat + 4 * b;
+
+    const float d = depth[(size_t)b * HW + n];
+    // pos = ray_dirs * depth + offset  (two roundings, as torch evaluates it)
+    const float p0 = ray_dirs[n] * d + net[0 * HW];
+    const float p1 = ray_dirs[HW + n] * d + net[1 * HW];
+    const float p2 = ray_dirs[2 * HW + n] * d + net[2 * HW];
+    // [p,1] @ M
+    const float w0 = p0 * M[0] + p1 * M[4] + p2 * M[8] + M[12];
+    const float w1 = p0 * M[1] + p1 * M[5] + p2 * M[9] + M[13];
+    const float w2 = p0 * M[2] + p1 * M[6] + p2 * M[10] + M[14];
+    const float w3 = p0 * M[3] + p1 * M[7] + p2 * M[11] + M[15];
+    const float den = w3 + 1e-10f;
+    float X = w0 / den, Y = w1 / den;
+    const float Z = w2 / den;
+    if (squre_clip < 10.0f) {
+        X = fminf(fmaxf(X, -squre_clip), squre_clip);
+        Y = fminf(fmaxf(Y, -squre_clip), squre_clip);
+    }
+
+    const size_t o = (size_t)b * (size_t)n_total + (size_t)n_offset + n;
+    xyz[3 * o + 0] = X; xyz[3 * o + 1] = Y; xyz[3 * o + 2] = Z;
+
+    opacity[o] = 1.0f / (1.0f + expf(-net[3 * HW]));
+    scaling[3 * o + 0] = expf(net[4 * HW]);
+    scaling[3 * o + 1] = expf(net[5 * HW]);
+    scaling[3 * o + 2] = expf(net[6 * HW]);
+
+    // F.normalize(dim=channel, eps=1e-12) then Hamilton product cam_quat (x) q, real part first
+    float bw = net[7 * HW], bx = net[8 * HW], by = net[9 * HW], bz = net[10 * HW];
+    const float nrm = fmaxf(sqrtf(bw * bw + bx * bx + by * by + bz * bz), 1e-12f);
+    bw /= nrm; bx /= nrm; by /= nrm; bz /= nrm;
+    const float aw = qc[0], ax = qc[1], ay = qc[2], az = qc[3];
+    rotation[4 * o + 0] = aw * bw - ax * bx - ay * by - az * bz;
+    rotation[4 * o + 1] = aw * bx + ax * bw + ay * bz - az * by;
+    rotation[4 * o + 2] = aw * by - ax * bz + ay * bw + az * bx;
+    rotation[4 * o + 3] = aw * bz + ax * by - ay * bx + az * bw;
+
+    features_dc[3 * o + 0] = net[11 * HW];
+    features_dc[3 * o + 1] = net[12 * HW];
+    features_dc[3 * o + 2] = net[13 * HW];
+
+    // T = sh_to_v @ R @ v_to_sh with R = M[:3,:3]; the two constant matrices are signed permutations:
+    //   X = sh_to_v @ R : rows (-R[1], R[2], -R[0]);   T[i] = (-X[i][1], X[i][2], -X[i][0])
+    float Tm[3][3];
+    {
+        const float Xr[3][3] = { { -M[4], -M[5], -M[6] }, { M[8], M[9], M[10] }, { -M[0], -M[1], -M[2] } };
+#pragma unroll
+        for (int i = 0; i < 3; i++) { Tm[i][0] = -Xr[i][1]; Tm[i][1] = Xr[i][2]; Tm[i][2] = -Xr[i][0]; }
+    }
+    // rest'[t][c] = sum_s rest[s][c] * T[s][t], rest channel index = 14 + 3*s + c
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float s0 = net[(14 + c) * HW], s1 = net[(17 + c) * HW], s2 = net[(20 + c) * HW];
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            features_rest[9 * o + 3 * t + c] = s0 * Tm[0][t] + s1 * Tm[1][t] + s2 * Tm[2][t];
+    }
+    unet_depth[o] = d;
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+epilogue_kernel(int H, int W, const float* __restrict__ raster, const float* __restrict__ c2w, float fx, float fy,
+                float* __restrict__ normal_world, float* __restrict__ depth_normal)
+{
+    const int HW = H * W;
+    const int n = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    const int v = blockIdx.y;
+    if (n >= HW) return;
+    const int y = n / W, x = n % W;
+    const float* ras = raster + (size_t)v * F3DG_OUT_CHANNELS * HW;
+    const float* Cw = c2w + 16 * v;     // row-major 4x4
+
+    if (normal_world) {
+        const float a = ras[3 * HW + n], b = ras[4 * HW + n], c = ras[5 * HW + n];
+        const float nrm = fmaxf(sqrtf(a * a + b * b + c * c), 1e-12f);
+        const float na = a / nrm, nb = b / nrm, nc = c / nrm;
+        float* o = normal_world + (size_t)v * 3 * HW;
+        o[n] = Cw[0] * na + Cw[1] * nb + Cw[2] * nc;
+        o[HW + n] = Cw[4] * na + Cw[5] * nb + Cw[6] * nc;
+        o[2 * HW + n] = Cw[8] * na + Cw[9] * nb + Cw[10] * nc;
+    }
+    if (depth_normal) {
+        float* o = depth_normal + (size_t)v * 3 * HW;
+        float r0 = 0, r1 = 0, r2 = 0;
+        if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {
+            const float* dep = ras + 6 * HW;
+            const float ax = 1.0f / fx, bx = -(W / 2.0f) / fx, ay = 1.0f / fy, by = -(H / 2.0f) / fy;
+            // point(yy, xx) = depth * ([xx,yy,1] @ Kinv^T @ R^T) + origin
+            auto point = [&](int yy, int xx, float& px, float& py, float& pz) {
+                const float cx = xx * ax + bx, cy = yy * ay + by;
+                const float dx = cx * Cw[0] + cy * Cw[1] + Cw[2];
+                const float dy = cx * Cw[4] + cy * Cw[5] + Cw[6];
+                const float dz = cx * Cw[8] + cy * Cw[9] + Cw[10];
+                const float dd = dep[yy * W + xx];
+                px = dd * dx + Cw[3]; py = dd * dy + Cw[7]; pz = dd * dz + Cw[11];
+            };
+            float ux, uy, uz, lx, ly, lz, rx, ry, rz, dx_, dy_, dz_;
+            point(y + 1, x, ux, uy, uz);
+            point(y - 1, x, lx, ly, lz);
+            point(y, x + 1, rx, ry, rz);
+            point(y, x - 1, dx_, dy_, dz_);
+            const float ex = ux - lx, ey = uy - ly, ez = uz - lz;          // "dx": along rows
+            const float gx = rx - dx_, gy = ry - dy_, gz = rz - dz_;       // "dy": along columns
+            const float cx_ = ey * gz - ez * gy, cy_ = ez * gx - ex * gz, cz_ = ex * gy - ey * gx;
+            const float nrm = fmaxf(sqrtf(cx_ * cx_ + cy_ * cy_ + cz_ * cz_), 1e-12f);
+            r0 = cx_ / nrm; r1 = cy_ / nrm; r2 = cz_ / nrm;
+        }
+        o[n] = r0; o[HW + n] = r1; o[2 * HW + n] = r2;
+    }
+}
+
+} // namespace
+
+extern "C" int f3dg_splat_head(void* stream, int B, int H, int W, const float* net_out, const float* depth,
+                               const float* ray_dirs, const float* view_to_world, const float* cam_quat,
+                               float squre_clip, long long n_total, long long n_offset,
+                               float* xyz, float* opacity, float* scaling, float* rotation,
+                               float* features_dc, float* features_rest, float* unet_depth)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || !net_out || !depth || !ray_dirs || !view_to_world || !cam_quat || !xyz ||
+        !opacity || !scaling || !rotation || !features_dc || !features_rest || !unet_depth)
+        return F3DG_ERR_BAD_ARG;
+    const long long HW = (long long)H * W;
+    if (n_offset < 0 || n_total < n_offset + HW) return F3DG_ERR_BAD_ARG;
+    dim3 grid((unsigned)((HW + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)B);
+    hipLaunchKernelGGL(splat_head_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, (int)HW, net_out, depth,
+                       ray_dirs, view_to_world, cam_quat, squre_clip, n_total, n_offset, xyz, opacity, scaling,
+                       rotation, features_dc, features_rest, unet_depth);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+extern "C" int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* raster,
+                                    const float* c2w, float fx, float fy,
+                                    float* normal_world, float* depth_normal)
+{
+    if (n_views <= 0 || H <= 0 || W <= 0 || !raster || !c2w) return F3DG_ERR_BAD_ARG;
+    if (!normal_world && !depth_normal) return F3DG_OK;
+    dim3 grid((unsigned)(((long long)H * W + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)n_views);
+    hipLaunchKernelGGL(epilogue_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, H, W, raster, c2w, fx, fy,
+                       normal_world, depth_normal);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}

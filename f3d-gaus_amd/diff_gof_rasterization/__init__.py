@@ -1,0 +1,264 @@
+"""Drop-in replacement of the reference's ``diff_gof_rasterization`` package on MI355X.
+
+Same names, argument meaning, return shapes and error behaviour as
+RAST/diff_gof_rasterization/__init__.py (``GaussianRasterizationSettings_GOF`` :168-182,
+``GaussianRasterizer_GOF`` :185-307, ``_RasterizeGaussians`` :46-165), but backed by libf3dg_hip.so through the
+C ABI of include/f3dg.h instead of the pybind ``_C`` module (RAST/ext.cpp:15-20). Put the directory that contains
+this package on ``sys.path`` (or ``import f3dgaus_amd`` first, which registers it) and the reference's
+``from diff_gof_rasterization import GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF``
+(src/gaussian_renderer/__init__.py:10) resolves here unchanged.
+
+Beyond the reference API, ``rasterize_views`` renders many cameras of the same Gaussians in one launch sequence
+with no host synchronisation (the MI355X-first entry the batched loops use).
+"""
+from typing import NamedTuple
+
+import ctypes as C
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+__all__ = ["GaussianRasterizationSettings_GOF", "GaussianRasterizer_GOF", "rasterize_gaussians", "rasterize_views",
+           "Workspace"]
+
+
+class GaussianRasterizationSettings_GOF(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    subpixel_offset: torch.Tensor
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, device):
+    """contiguous float32 on `device`; empty / None -> None (the reference maps empty tensors to nullptr)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device or t.dtype != torch.float32:
+        t = t.to(device=device, dtype=torch.float32)
+    return t.contiguous()
+
+
+class Workspace:
+    """Caller-owned scratch for one forward (and its backward): the counterpart of the three resizable byte
+    tensors of the reference (RAST/rasterize_points.cu:72-82), sized once per capacity instead of grown mid-call."""
+
+    def __init__(self, P, W, H, n_views, max_rendered, device):
+        self.P, self.W, self.H, self.n_views, self.max_rendered = int(P), int(W), int(H), int(n_views), int(max_rendered)
+        nbytes = _lib.lib().f3dg_workspace_bytes(self.P, self.W, self.H, self.n_views, self.max_rendered)
+        if nbytes == 0:
+            raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_workspace_bytes")
+        self.buffer = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+    @property
+    def nbytes(self):
+        return self.buffer.numel()
+
+    def fits(self, P, W, H, n_views, max_rendered):
+        return (self.P, self.W, self.H, self.n_views) == (P, W, H, n_views) and self.max_rendered >= max_rendered
+
+
+_WS_CACHE = {}      # (device index) -> Workspace reused by no-grad single-view calls
+_CAP_HINT = {}      # (P, W, H, n_views) -> instances/capacity that worked last time
+
+
+def _initial_capacity(P, W, H, n_views):
+    hint = _CAP_HINT.get((P, W, H, n_views))
+    if hint:
+        return hint
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    return int(n_views * max(4 * P, 4 * tiles, 1 << 14))
+
+
+def _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+    if means3D.ndim != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")     # AT_ERROR, rasterize_points.cu:61-63
+
+
+def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg, *, image_height, image_width,
+                    tanfovx, tanfovy, sh=None, colors_precomp=None, scales=None, rotations=None, cov3Ds_precomp=None,
+                    view2gaussian_precomp=None, sh_degree=0, scale_modifier=1.0, kernel_size=0.0, workspace=None,
+                    max_rendered=None, save_aux=False, out=None, radii=None, check=True):
+    """Render ``n_views`` cameras of the same Gaussians in ONE launch sequence (f3dg_forward_batched).
+
+    viewmatrices / projmatrices: [V,4,4] (any leading singleton dims), camposs [V,3], bg [3] or [V,3].
+    Returns (color [V,9,H,W], radii [V,P] int32, workspace). With ``check=False`` nothing synchronises; the
+    caller may later call ``read_status(workspace)``. With ``check=True`` an overflow grows the workspace and
+    re-runs the call (the analogue of the reference's resize callback).
+    """
+    L = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("f3dgaus_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
+    _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+    P = means3D.size(0)
+    H, W = int(image_height), int(image_width)
+    vm = _dev_f32(viewmatrices, device).reshape(-1, 16)
+    V = vm.size(0)
+    pm = _dev_f32(projmatrices, device).reshape(-1, 16)
+    cp = _dev_f32(camposs, device).reshape(-1, 3)
+    bgt = _dev_f32(bg, device).reshape(-1, 3)
+    if pm.size(0) != V or cp.size(0) != V or bgt.size(0) not in (1, V):
+        raise RuntimeError("viewmatrices, projmatrices, camposs (and bg if per view) must agree on the number of views")
+    flags = (_lib.FLAG_SAVE_AUX if save_aux else 0) | (_lib.FLAG_BG_PER_VIEW if (bgt.size(0) == V and V > 1) else 0)
+
+    means3D = _dev_f32(means3D, device)
+    sh = _dev_f32(sh, device)
+    colors_precomp = _dev_f32(colors_precomp, device)
+    opacities = _dev_f32(opacities, device)
+    scales = _dev_f32(scales, device)
+    rotations = _dev_f32(rotations, device)
+    cov3Ds_precomp = _dev_f32(cov3Ds_precomp, device)
+    view2gaussian_precomp = _dev_f32(view2gaussian_precomp, device)
+    M = 0 if sh is None else (sh.size(1) if sh.ndim == 3 else sh.numel() // (3 * max(P, 1)))
+
+    if out is None:
+        out = torch.empty((V, 9, H, W), dtype=torch.float32, device=device)
+    if radii is None:
+        radii = torch.empty((V, P), dtype=torch.int32, device=device)
+
+    cap = int(max_rendered) if max_rendered is not None else (workspace.max_rendered if workspace is not None else _initial_capacity(P, W, H, V))
+    while True:
+        if workspace is None or not workspace.fits(P, W, H, V, cap):
+            workspace = Workspace(P, W, H, V, cap, device)
+        rc = L.f3dg_forward_batched(
+            _stream(), C.c_void_p(workspace.buffer.data_ptr()), workspace.nbytes, workspace.max_rendered, V, P,
+            int(sh_degree), int(M), _lib.ptr(bgt), W, H, _lib.ptr(means3D), _lib.ptr(sh), _lib.ptr(colors_precomp),
+            _lib.ptr(opacities), _lib.ptr(scales), float(scale_modifier), _lib.ptr(rotations),
+            _lib.ptr(cov3Ds_precomp), _lib.ptr(view2gaussian_precomp), _lib.ptr(vm), _lib.ptr(pm), _lib.ptr(cp),
+            float(tanfovx), float(tanfovy), float(kernel_size), _lib.ptr(out), _lib.ptr(radii), flags)
+        _lib.check(rc, "f3dg_forward_batched")
+        if not check:
+            workspace.num_rendered = None
+            return out, radii, workspace
+        n = C.c_longlong(0)
+        rc = L.f3dg_read_status(_stream(), C.c_void_p(workspace.buffer.data_ptr()), C.byref(n))
+        if rc == _lib.ERR_OVERFLOW:
+            cap = int(n.value * 1.25) + 1024          # grow and retry
+            workspace = None
+            continue
+        _lib.check(rc, "f3dg_read_status")
+        workspace.num_rendered = int(n.value)
+        _CAP_HINT[(P, W, H, V)] = max(int(n.value * 1.5) + 1024, 1 << 14)
+        return out, radii, workspace
+
+
+def read_status(workspace):
+    """BLOCKING: number of (Gaussian, tile) instances of the last call on this workspace; raises on overflow."""
+    n = C.c_longlong(0)
+    rc = _lib.lib().f3dg_read_status(_stream(), C.c_void_p(workspace.buffer.data_ptr()), C.byref(n))
+    _lib.check(rc, "f3dg_read_status")
+    workspace.num_rendered = int(n.value)
+    return workspace.num_rendered
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        view2gaussian_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, view2gaussian_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Autograd wrapper; argument order and the (color, radii) result follow rast_py:46-104, the gradient order
+    rast_py:152-165."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                view2gaussian_precomp, raster_settings):
+        rs = raster_settings
+        needs_grad = torch.is_grad_enabled() and any(
+            isinstance(t, torch.Tensor) and t.requires_grad
+            for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations))
+        device = means3D.device
+        P = means3D.size(0) if means3D.ndim == 2 else 0
+        key = device.index
+        ws = None if needs_grad else _WS_CACHE.get(key)
+        color, radii, ws = rasterize_views(
+            means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg.reshape(-1)[:3],
+            image_height=rs.image_height, image_width=rs.image_width, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, sh=sh,
+            colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp,
+            view2gaussian_precomp=view2gaussian_precomp, sh_degree=rs.sh_degree, scale_modifier=rs.scale_modifier,
+            kernel_size=rs.kernel_size, workspace=ws, save_aux=needs_grad, check=True)
+        if not needs_grad:
+            _WS_CACHE[key] = ws
+        ctx.raster_settings = rs
+        ctx.num_rendered = ws.num_rendered
+        ctx.workspace = ws if needs_grad else None
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp,
+                              radii, sh)
+        color = color[0]
+        radii = radii[0]
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        from .backward import rasterize_backward
+        return rasterize_backward(ctx, grad_out_color)
+
+
+class GaussianRasterizer_GOF(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: view-space z > 0.2 (rast_py:190-199 -> rasterizer_impl.cu:172-186)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            pos = _dev_f32(positions, positions.device)
+            P = pos.size(0)
+            present = torch.zeros((P,), dtype=torch.uint8, device=pos.device)
+            vm = _dev_f32(rs.viewmatrix, pos.device)
+            pm = _dev_f32(rs.projmatrix, pos.device)
+            rc = _lib.lib().f3dg_mark_visible(_stream(), P, _lib.ptr(pos), _lib.ptr(vm), _lib.ptr(pm), _lib.ptr(present))
+            _lib.check(rc, "f3dg_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, view2gaussian_precomp=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        empty = torch.Tensor([])
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+        if view2gaussian_precomp is None:
+            view2gaussian_precomp = empty
+
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, view2gaussian_precomp, raster_settings)
+
+    def integrate(self, points3D, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                  rotations=None, cov3D_precomp=None, view2gaussian_precomp=None):
+        # SURVEY section 8(f) rank 1 ("next"): mesh-extraction path, not part of the round-1 hot path.
+        raise NotImplementedError("GaussianRasterizer_GOF.integrate (mesh extraction) is outside the accelerated "
+                                  "hot path in this build; see DESIGN.md 'out of scope / next'")

@@ -1,0 +1,176 @@
+/*
+ * f3dg.h -- C ABI of libf3dg_hip.so: the MI355X (gfx950) implementation of F3D-Gaus's GOF rasterization +
+ * cycle-aggregative projection hot path.
+ *
+ * Plain pointers and sizes only (no torch / no C++ types). Every pointer is a DEVICE pointer unless the
+ * parameter name starts with `h_`. Nothing in this library synchronises the host with the device except
+ * the functions documented as blocking. `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference; RAST =
+ * src/gaussian-splatting/submodules/diff-gof-rasterization):
+ *
+ *   f3dg_forward / f3dg_forward_batched
+ *       CudaRasterizer::Rasterizer::forward      RAST/cuda_rasterizer/rasterizer.h:31-55,
+ *                                                RAST/cuda_rasterizer/rasterizer_impl.cu:247-405
+ *       reached from pybind `rasterize_gaussians` RAST/ext.cpp:16, RAST/rasterize_points.cu:36-122
+ *   f3dg_backward
+ *       CudaRasterizer::Rasterizer::backward     RAST/cuda_rasterizer/rasterizer.h:57-90,
+ *                                                RAST/cuda_rasterizer/rasterizer_impl.cu:409-526
+ *       reached from pybind `rasterize_gaussians_backward` RAST/ext.cpp:18, RAST/rasterize_points.cu:124-211
+ *   f3dg_mark_visible
+ *       CudaRasterizer::Rasterizer::markVisible  RAST/cuda_rasterizer/rasterizer.h:23-29,
+ *                                                RAST/cuda_rasterizer/rasterizer_impl.cu:172-186 (pybind `mark_visible`)
+ *   f3dg_workspace_bytes / f3dg_read_status
+ *       the std::function<char*(size_t)> resize callbacks + the blocking 4-byte D2H of num_rendered
+ *       RAST/rasterize_points.cu:28-34, RAST/cuda_rasterizer/rasterizer_impl.cu:277-279,290-292,336-340
+ *   f3dg_splat_head
+ *       the post-network half of GaussianSplatPredictor_gtunet.forward   src/gaussian_predictor.py:857-881, 961-1007
+ *       (python-only in the reference; there is no native FFI for it -- this is the build's fused kernel)
+ *   f3dg_render_epilogue
+ *       the torch post-processing of render_predicted_more_v2_gof  src/gaussian_renderer/__init__.py:881-909, 1043-1053
+ *
+ * Memory ownership mirrors the reference: outputs and the workspace are allocated and owned by the caller
+ * (torch tensors on the Python side). Instead of growing buffers through callbacks in the middle of the call
+ * (which forces the reference's host sync, rasterizer_impl.cu:336), the caller passes ONE workspace sized by
+ * f3dg_workspace_bytes() for a chosen instance capacity `max_rendered`; if the (Gaussian, tile) instance count
+ * of a call exceeds that capacity the device sets an overflow flag, the compositing stage is skipped, and
+ * f3dg_read_status()/f3dg_forward() report F3DG_ERR_OVERFLOW together with the capacity that would have
+ * sufficed, so the caller can grow the workspace and retry -- the same contract as the resize callback, moved
+ * outside the launch sequence. The workspace layout is the forward<->backward contract (as the three byte
+ * buffers are in the reference, rasterizer_impl.cu:444-446) and is private to the library.
+ */
+#ifndef F3DG_H_INCLUDED
+#define F3DG_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F3DG_OK              0
+#define F3DG_ERR_BAD_ARG    -1   /* NULL where data is required, non-positive sizes, both/neither of sh & colours ... */
+#define F3DG_ERR_WORKSPACE  -2   /* workspace_bytes smaller than f3dg_workspace_bytes(...) */
+#define F3DG_ERR_OVERFLOW   -3   /* more (Gaussian, tile) instances than max_rendered; see f3dg_read_status */
+#define F3DG_ERR_HIP        -4   /* a HIP runtime call failed; f3dg_last_error() has the text */
+#define F3DG_ERR_UNSUPPORTED -5  /* NUM_CHANNELS != 3 etc. (rasterizer_impl.cu:294-297) */
+
+/* flags for f3dg_forward_batched */
+#define F3DG_FLAG_SAVE_AUX   1u  /* keep final_T / n_contrib / conic / clamped for f3dg_backward (training mode).
+                                    Without it the compositing kernel writes only the 9 output channels. */
+#define F3DG_FLAG_BG_PER_VIEW 2u /* background is [n_views,3] instead of [3] */
+
+#define F3DG_TILE 16             /* BLOCK_X = BLOCK_Y = 16, RAST/cuda_rasterizer/config.h:16-17 */
+#define F3DG_OUT_CHANNELS 9      /* RGB, normal xyz, median depth, alpha, distortion: auxiliary.h:21-24 */
+
+/* Library / build identification: "f3dg-hip gfx950 <version>" */
+const char* f3dg_version(void);
+/* Text of the last HIP error seen by this thread's calls (empty string if none). */
+const char* f3dg_last_error(void);
+
+/* Bytes of workspace needed for n_views views of P Gaussians at W x H with room for max_rendered
+ * (Gaussian, tile) instances summed over all views of the call. Pure host arithmetic. */
+size_t f3dg_workspace_bytes(int P, int W, int H, int n_views, long long max_rendered);
+
+/* Batched forward: renders n_views views of the SAME P Gaussians in one launch sequence, no host sync.
+ *   viewmatrix, projmatrix : [n_views,16]  (row-vector convention, i.e. already transposed; auxiliary.h:86-115)
+ *   cam_pos                : [n_views,3]
+ *   background             : [3] or [n_views,3] with F3DG_FLAG_BG_PER_VIEW
+ *   shs [P,M,3] xor colors_precomp [P,3]; (scales [P,3] and rotations [P,4]) xor cov3D_precomp [P,6];
+ *   view2gaussian_precomp  : NULL or [n_views,P,10]
+ *   out_color              : [n_views,9,H,W]   radii: [n_views,P] int32 or NULL
+ * Returns F3DG_OK or a negative error for host-detectable problems. Instance overflow is reported by
+ * f3dg_read_status(). P == 0 is legal: outputs are filled with background / zeros (rasterize_points.cu:85). */
+int f3dg_forward_batched(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                         int n_views, int P, int D, int M,
+                         const float* background, int W, int H,
+                         const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, float scale_modifier,
+                         const float* rotations, const float* cov3D_precomp,
+                         const float* view2gaussian_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                         float tan_fovx, float tan_fovy, float kernel_size,
+                         float* out_color, int* radii, unsigned flags);
+
+/* BLOCKING. Waits for `stream`, then reads the workspace header written by the last forward on it.
+ * h_num_rendered: total instances the call needed; returns F3DG_OK, or F3DG_ERR_OVERFLOW if that exceeded
+ * the capacity the workspace was sized for (outputs of that call are then undefined). */
+int f3dg_read_status(void* stream, const void* workspace, long long* h_num_rendered);
+
+/* Reference-shaped single-view forward (Rasterizer::forward): f3dg_forward_batched(n_views = 1) followed by
+ * f3dg_read_status(). BLOCKING, like the reference (rasterizer_impl.cu:336). Returns num_rendered >= 0 or a
+ * negative error; on F3DG_ERR_OVERFLOW *h_needed (if not NULL) receives the required capacity. */
+long long f3dg_forward(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                       int P, int D, int M, const float* background, int W, int H,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* view2gaussian_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                       float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+                       float* out_color, int* radii, unsigned flags, long long* h_needed);
+
+/* Backward of a forward made with F3DG_FLAG_SAVE_AUX on the same workspace (same P, W, H, n_views,
+ * max_rendered). Argument meaning follows Rasterizer::backward (rasterizer.h:57-90). All dL_* outputs must be
+ * zero-filled by the caller (rasterize_points.cu:160-170); sizes per view v:
+ *   dL_dpix [n_views,9,H,W] in;  dL_dmean2D [n_views,P,3], dL_dconic [n_views,P,4] (stays 0), dL_dopacity [P],
+ *   dL_dcolor [n_views,P,3], dL_dmean3D [P,3], dL_dcov3D [P,6] (stays 0), dL_dsh [P,M,3], dL_dscale [P,3],
+ *   dL_drot [P,4], dL_dview2gaussian [n_views,P,10].
+ * Per-Gaussian parameter gradients (opacity, mean3D, sh, scale, rot) are summed over the views of the call. */
+int f3dg_backward(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                  int n_views, int P, int D, int M, const float* background, int W, int H,
+                  const float* means3D, const float* shs, const float* colors_precomp,
+                  const float* scales, float scale_modifier, const float* rotations,
+                  const float* cov3D_precomp, const float* view2gaussian_precomp,
+                  const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                  float tan_fovx, float tan_fovy, float kernel_size,
+                  const int* radii, const float* dL_dpix,
+                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                  float* dL_dview2gaussian);
+
+/* present[i] = (view-space z of means3D[i] > 0.2), auxiliary.h:177-202. present is uint8 [P]. */
+int f3dg_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, uint8_t* present);
+
+/* Cycle-aggregative projection ("splat head", src/gaussian_predictor.py:857-881, 961-1007) for B images:
+ *   net_out [B,23,H,W] planar: offset 0:3, opacity 3, scaling 4:7, rotation 7:11, features_dc 11:14, features_rest 14:23
+ *   depth [B,1,H,W], ray_dirs [3,H,W] (predictor buffer), view_to_world [B,16] (row-vector convention), cam_quat [B,4]
+ * Outputs are written for image b at Gaussian offset `n_offset` of destination tensors whose per-image length is
+ * `n_total` (>= n_offset + H*W): this is what lets the cycle loop aggregate the 9 passes in place instead of the
+ * reference's torch.cat chain (visualize.py:336-340):
+ *   xyz [B,n_total,3], opacity [B,n_total,1], scaling [B,n_total,3], rotation [B,n_total,4],
+ *   features_dc [B,n_total,1,3], features_rest [B,n_total,3,3], unet_depth [B,n_total,1]
+ * squre_clip: clamp |x|,|y| only when < 10 (gaussian_predictor.py:972-974). */
+int f3dg_splat_head(void* stream, int B, int H, int W, const float* net_out, const float* depth,
+                    const float* ray_dirs, const float* view_to_world, const float* cam_quat, float squre_clip,
+                    long long n_total, long long n_offset,
+                    float* xyz, float* opacity, float* scaling, float* rotation,
+                    float* features_dc, float* features_rest, float* unet_depth);
+
+/* Fused epilogue of render_predicted_more_v2_gof (gaussian_renderer/__init__.py:881-909, 1043-1053) for n_views
+ * rendered frames raster [n_views,9,H,W]:
+ *   normal_world [n_views,3,H,W] = c2w[:3,:3] @ normalize(raster[3:6]);  c2w = inverse(world_view^T), given as
+ *       c2w_rot [n_views,9] row-major 3x3 (host-computed, it is a 4x4 inverse)
+ *   depth_normal [n_views,3,H,W]: central-difference normal of the back-projected median depth, border = 0;
+ *       needs c2w [n_views,16] row-major 4x4 and fx, fy.
+ * Either output pointer may be NULL to skip it. */
+int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* raster,
+                         const float* c2w, float fx, float fy,
+                         float* normal_world, float* depth_normal);
+
+/* Test/inspection hook: device-to-device copies of the library's internal per-call state into caller buffers
+ * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the
+ * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
+ *   rec [V*P*16] (view2gaussian[10], opacity*coef, rgb[3], depth, 0), means2D [V*P*2], conic [V*P*4] (SAVE_AUX),
+ *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped; SAVE_AUX), keys_sorted [cap] u64,
+ *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX). */
+int f3dg_debug_export(void* stream, const void* workspace, int P, int W, int H, int n_views,
+                      long long max_rendered, float* rec, float* means2D, float* conic, unsigned* tiles,
+                      unsigned* offsets, unsigned char* clamped, unsigned long long* keys_sorted,
+                      unsigned* point_list, unsigned* ranges, float* final_T, unsigned* n_contrib);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F3DG_H_INCLUDED */
