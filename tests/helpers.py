@@ -123,5 +123,7 @@ def assert_render_parity(hip_out, ora_out, label=""):
     assert frac_within(hip_out[7], ora_out[7], 1e-4) >= 0.999, f"{label} alpha"
     assert frac_within(hip_out[3:6], ora_out[3:6], 1e-4) >= 0.999, f"{label} normal"
     assert frac_within(hip_out[6], ora_out[6], 0.0, 1e-4) >= 0.999, f"{label} depth"
-    # distortion: values ~1e-7..1e-5 from cancelling float32 accumulations -> relative 1e-3 with an absolute floor
-    assert frac_within(hip_out[8], ora_out[8], 1e-7, 1e-3) >= 0.999, f"{label} distortion"
+    # distortion: values ~1e-7..1e-5 built from float32 accumulations (dist1, dist2, distortion) that cancel
+    # strongly; a 1-ulp expf difference is amplified to a few percent of the value (SURVEY appendix A.2 measured
+    # ~3 % relative / 3.5e-7 absolute between faithful implementations) -> 5 % relative with a 1e-6 floor
+    assert frac_within(hip_out[8], ora_out[8], 1e-6, 5e-2) >= 0.999, f"{label} distortion"
