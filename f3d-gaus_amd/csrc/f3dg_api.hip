@@ -8,6 +8,7 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 namespace {
 
@@ -35,7 +36,55 @@ __global__ void fill_background_kernel(int V, size_t HW, const float* __restrict
     (void)bg; (void)bg_per_view;
 }
 
+// ---- optional per-stage timing with HIP events on the caller's stream (bench.py's live roofline figure) ----
+enum { ST_PREPROCESS = 0, ST_BINNING, ST_RENDER, ST_COUNT };
+struct ProfCall { hipEvent_t ev[ST_COUNT + 1]; };
+struct Prof {
+    bool enabled = false;
+    std::vector<ProfCall> calls;     // events recorded since the last collect
+    std::vector<ProfCall> pool;      // recycled events
+};
+thread_local Prof g_prof;
+
+ProfCall* prof_begin(hipStream_t s)
+{
+    if (!g_prof.enabled) return nullptr;
+    ProfCall c;
+    if (!g_prof.pool.empty()) { c = g_prof.pool.back(); g_prof.pool.pop_back(); }
+    else for (int i = 0; i <= ST_COUNT; i++) if (hipEventCreate(&c.ev[i]) != hipSuccess) return nullptr;
+    g_prof.calls.push_back(c);
+    (void)hipEventRecord(c.ev[0], s);
+    return &g_prof.calls.back();
+}
+inline void prof_mark(ProfCall* c, int stage_done, hipStream_t s) { if (c) (void)hipEventRecord(c->ev[stage_done + 1], s); }
+
 } // namespace
+
+extern "C" int f3dg_profile_enable(int on)
+{
+    g_prof.enabled = on != 0;
+    return F3DG_OK;
+}
+
+// BLOCKING: waits for the recorded events, adds up per-stage milliseconds of every forward call recorded since
+// the previous collect: h_stage_ms[0] preprocess, [1] binning (scan + keys + sort + ranges), [2] compositing.
+extern "C" int f3dg_profile_collect(double* h_stage_ms, int* h_calls)
+{
+    double sum[ST_COUNT] = { 0, 0, 0 };
+    for (ProfCall& c : g_prof.calls) {
+        F3DG_HIP_CHECK(hipEventSynchronize(c.ev[ST_COUNT]));
+        for (int i = 0; i < ST_COUNT; i++) {
+            float ms = 0;
+            F3DG_HIP_CHECK(hipEventElapsedTime(&ms, c.ev[i], c.ev[i + 1]));
+            sum[i] += ms;
+        }
+        g_prof.pool.push_back(c);
+    }
+    if (h_calls) *h_calls = (int)g_prof.calls.size();
+    g_prof.calls.clear();
+    if (h_stage_ms) for (int i = 0; i < ST_COUNT; i++) h_stage_ms[i] = sum[i];
+    return F3DG_OK;
+}
 
 int f3dg_set_hip_error(hipError_t e, const char* where)
 {
@@ -132,6 +181,7 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
     const int save_aux = (flags & F3DG_FLAG_SAVE_AUX) ? 1 : 0;
     int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
 
+    ProfCall* prof = prof_begin(s);
     int rc = f3dg_launch_preprocess(s, n_views, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
@@ -140,17 +190,21 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
                                     reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
     if (rc != F3DG_OK) return rc;
+    prof_mark(prof, ST_PREPROCESS, s);
 
     rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, radii_used);
     if (rc != F3DG_OK) return rc;
+    prof_mark(prof, ST_BINNING, s);
 
-    return f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
+    rc = f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
                               reinterpret_cast<const uint2*>(ws + L.ranges),
                               reinterpret_cast<const unsigned*>(ws + L.vals[0]),
                               reinterpret_cast<const F3dgRec*>(ws + L.rec), background,
                               (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color,
                               reinterpret_cast<float*>(ws + L.final_T),
                               reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux);
+    prof_mark(prof, ST_RENDER, s);
+    return rc;
 }
 
 extern "C" int f3dg_read_status(void* stream, const void* workspace, long long* h_num_rendered)

@@ -159,6 +159,14 @@ int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* r
                          const float* c2w, float fx, float fy,
                          float* normal_world, float* depth_normal);
 
+/* Optional per-stage timing of the forward path with HIP events recorded on the caller's stream (this is what
+ * bench.py uses for the live roofline figure). f3dg_profile_enable(1) makes every following
+ * f3dg_forward_batched on this host thread record 4 events; f3dg_profile_collect() is BLOCKING, sums the
+ * milliseconds of all calls recorded since the last collect into h_stage_ms[3] = {projection (preprocess),
+ * binning (scan + key duplication + radix sort + tile ranges), compositing} and returns the call count. */
+int f3dg_profile_enable(int on);
+int f3dg_profile_collect(double* h_stage_ms, int* h_calls);
+
 /* Test/inspection hook: device-to-device copies of the library's internal per-call state into caller buffers
  * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the
  * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
