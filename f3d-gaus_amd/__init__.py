@@ -6,7 +6,7 @@ drop-in ``diff_gof_rasterization`` module name so the reference's own import lin
 """
 import sys as _sys
 
-from . import _lib, build, cameras  # noqa: F401
+from . import _lib, build, cameras, synthetic  # noqa: F401
 from . import diff_gof_rasterization  # noqa: F401
 
 # `from diff_gof_rasterization import GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF`
@@ -15,5 +15,11 @@ _sys.modules.setdefault("diff_gof_rasterization", diff_gof_rasterization)
 
 from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF,  # noqa: E402,F401
                                      rasterize_views)
+
+from . import gaussian_renderer, gaussian_predictor, unet_gs, cycle, dist  # noqa: E402,F401
+from .gaussian_renderer import (render_predicted_more_v2_gof, render_predicted_more_v3_gof,  # noqa: E402,F401
+                                render_views, depth_to_normal, depths_to_points)
+from .gaussian_predictor import GaussianSplatPredictor_gtunet, splat_head  # noqa: E402,F401
+from .unet_gs import Unet_GS_gtunet  # noqa: E402,F401
 
 __version__ = "0.1.0"

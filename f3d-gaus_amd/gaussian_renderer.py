@@ -1,0 +1,176 @@
+"""Renderer operator of the hot path: drop-in ``render_predicted_more_v2_gof`` / ``_v3_gof`` and helpers.
+
+Mirrors reference src/gaussian_renderer/__init__.py: ``focal2fov`` :15-19, ``depths_to_points`` :881-896,
+``depth_to_normal`` :898-909, ``render_predicted_more_v2_gof`` :915-1067, ``render_predicted_more_v3_gof``
+:1232-1380 (same, but ``pc[bs][key]`` list-of-dicts). Same signature, same returned dict keys / shapes / dtypes;
+the rasterizer is ``GaussianRasterizer_GOF`` of this package (HIP), and the post-processing (normal
+normalisation + rotation to world space, finite-difference normal of the median depth) is one fused HIP kernel
+(``f3dg_render_epilogue``) instead of ~10 small torch kernels per call.
+
+``render_views`` is the batched MI355X-first form the loops use: all cameras of one image in one launch sequence.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF, _stream,
+                                     rasterize_views)
+
+
+def focal2fov(focal, pixels):
+    return 2 * math.atan(pixels / (2 * focal))
+
+
+def focal2fov_torch(focal, pixels):
+    return 2 * torch.atan(pixels / (2 * focal))
+
+
+def _epilogue(raster, world_view, W, H, FoVx, FoVy, want_normal=True, want_depth_normal=True):
+    """raster [V,9,H,W], world_view [V,4,4] (row-vector convention). Returns (normal_world, depth_normal) [V,3,H,W]."""
+    V = raster.shape[0]
+    device = raster.device
+    c2w = torch.linalg.inv(world_view.reshape(V, 4, 4).transpose(1, 2)).contiguous().float()
+    fx = W / (2 * math.tan(FoVx / 2.))
+    fy = H / (2 * math.tan(FoVy / 2.))
+    nw = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_normal else None
+    dn = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_depth_normal else None
+    raster = raster.contiguous()
+    rc = _lib.lib().f3dg_render_epilogue(_stream(), V, H, W, _lib.ptr(raster), _lib.ptr(c2w), float(fx), float(fy),
+                                         _lib.ptr(nw), _lib.ptr(dn))
+    _lib.check(rc, "f3dg_render_epilogue")
+    return nw, dn
+
+
+def depths_to_points(world_view_transform, image_width, image_height, FoVx, FoVy, depthmap):
+    """Back-projects a depth map to world-space points [H*W,3] (gaussian_renderer/__init__.py:881-896).
+    Small torch helper kept for API parity; the render path itself uses the fused epilogue kernel."""
+    dev = depthmap.device
+    c2w = (world_view_transform.T).inverse()
+    W, H = image_width, image_height
+    fx = W / (2 * math.tan(FoVx / 2.))
+    fy = H / (2 * math.tan(FoVy / 2.))
+    intrins = torch.tensor([[fx, 0., W / 2.], [0., fy, H / 2.], [0., 0., 1.0]]).float().to(dev)
+    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(), indexing='xy')
+    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
+    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3]
+    return depthmap.reshape(-1, 1) * rays_d + rays_o
+
+
+def depth_to_normal(world_view_transform, image_width, image_height, FoVx, FoVy, depth):
+    """Central-difference normal map [H,W,3] of a depth map [1,H,W], border = 0 (:898-909). Uses the fused kernel."""
+    H, W = depth.shape[-2], depth.shape[-1]
+    raster = torch.zeros((1, 9, H, W), dtype=torch.float32, device=depth.device)
+    raster[0, 6] = depth.reshape(H, W)
+    _, dn = _epilogue(raster, world_view_transform.reshape(1, 4, 4), image_width, image_height, FoVx, FoVy,
+                      want_normal=False)
+    return dn[0].permute(1, 2, 0)
+
+
+def _render_one(get, bs, world_view_transform, full_proj_transform, camera_center, bg_color, cfg, kernel_size,
+                scaling_modifier, override_color):
+    xyz = get("xyz")
+    device = xyz.device
+    # zero tensor whose gradient receives the screen-space mean gradients (reference :932-936)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    tanfovx = math.tan(cfg['model']['fov'] * np.pi / 360)
+    tanfovy = math.tan(cfg['model']['fov'] * np.pi / 360)
+    FovX = cfg['model']['fov'] * np.pi / 180
+    FovY = cfg['model']['fov'] * np.pi / 180
+    image_height = int(cfg['model']['training_resolution'])
+    image_width = int(cfg['model']['training_resolution'])
+    # the reference allocates a zero [H,W,2] subpixel_offset per call that no kernel reads (forward.cu:473 list of
+    # unused arguments); an empty tensor keeps the 14-field settings tuple without the allocation + memset
+    subpixel_offset = torch.empty((0,), dtype=torch.float32, device=device)
+
+    raster_settings = GaussianRasterizationSettings_GOF(
+        image_height=image_height, image_width=image_width, tanfovx=tanfovx, tanfovy=tanfovy,
+        kernel_size=kernel_size, subpixel_offset=subpixel_offset, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=world_view_transform, projmatrix=full_proj_transform, sh_degree=cfg['model']['max_sh_degree'],
+        campos=camera_center, prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer_GOF(raster_settings=raster_settings)
+
+    means3D = xyz
+    means2D = screenspace_points
+    opacity = get("opacity")
+    scales = get("scaling")
+    rotations = get("rotation")
+
+    if override_color is None:
+        shs = torch.cat([get("features_dc"), get("features_rest")], dim=1).contiguous()
+        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None,
+                                           opacities=opacity, scales=scales, rotations=rotations,
+                                           cov3D_precomp=None, view2gaussian_precomp=None)
+    else:
+        colors_precomp = get("rgbs")
+        rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp,
+                                           opacities=opacity, scales=scales, rotations=rotations,
+                                           cov3D_precomp=None, view2gaussian_precomp=None)
+
+    wv = world_view_transform.reshape(1, 4, 4)
+    nw, dn = _epilogue(rendered_image.detach().unsqueeze(0), wv, image_width, image_height, FovX, FovY)
+    return {"render": rendered_image[:3, :, :],
+            "rendered_normal": nw[0],
+            "rendered_depth": rendered_image[6:7, :, :],
+            "depth_normal": dn[0],
+            "rendered_alpha": rendered_image[7:8, :, :],
+            "distortion_map": rendered_image[8:9, :, :],
+            "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0,
+            "radii": radii}
+
+
+def render_predicted_more_v2_gof(pc: dict, bs, world_view_transform, full_proj_transform, camera_center,
+                                 bg_color: torch.Tensor, cfg, kernel_size=0.0, scaling_modifier=1.0,
+                                 override_color=None, subpixel_offset=None):
+    """Render image ``bs`` of the batched Gaussian dict ``pc`` (every value [B,N,...]) from one camera.
+    Matrices may carry leading singleton dims ([1,1,4,4], [1,1,3], [1,3]) exactly as visualize.py passes them."""
+    return _render_one(lambda k: pc[k][bs], bs, world_view_transform, full_proj_transform, camera_center, bg_color,
+                       cfg, kernel_size, scaling_modifier, override_color)
+
+
+def render_predicted_more_v3_gof(pc, bs, world_view_transform, full_proj_transform, camera_center,
+                                 bg_color: torch.Tensor, cfg, kernel_size=0.0, scaling_modifier=1.0,
+                                 override_color=None, subpixel_offset=None):
+    """Same as v2 but ``pc`` is a list of per-image dicts: ``pc[bs][key]`` (:1232-1380)."""
+    return _render_one(lambda k: pc[bs][k], bs, world_view_transform, full_proj_transform, camera_center, bg_color,
+                       cfg, kernel_size, scaling_modifier, override_color)
+
+
+def render_views(pc: dict, bs, world_view_transforms, full_proj_transforms, camera_centers, bg_color, cfg,
+                 kernel_size=0.0, scaling_modifier=1.0, override_color=None, workspace=None, epilogue=True,
+                 check=True):
+    """All V cameras of image ``bs`` in one launch sequence (no per-view Python loop, no per-view host sync).
+    Returns a dict with the same keys as ``render_predicted_more_v2_gof`` but a leading view axis:
+    render [V,3,H,W], rendered_normal [V,3,H,W], rendered_depth [V,1,H,W], depth_normal [V,3,H,W],
+    rendered_alpha [V,1,H,W], distortion_map [V,1,H,W], radii [V,P], visibility_filter [V,P], plus 'workspace'."""
+    fov = cfg['model']['fov']
+    tanfov = math.tan(fov * np.pi / 360)
+    res = int(cfg['model']['training_resolution'])
+    V = world_view_transforms.reshape(-1, 16).shape[0]
+    if override_color is None:
+        shs = torch.cat([pc["features_dc"][bs], pc["features_rest"][bs]], dim=1).contiguous()
+        colors = None
+    else:
+        shs, colors = None, pc["rgbs"][bs]
+    with torch.no_grad():
+        raster, radii, ws = rasterize_views(
+            pc["xyz"][bs], pc["opacity"][bs], world_view_transforms, full_proj_transforms, camera_centers, bg_color,
+            image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, sh=shs, colors_precomp=colors,
+            scales=pc["scaling"][bs], rotations=pc["rotation"][bs], sh_degree=cfg['model']['max_sh_degree'],
+            scale_modifier=scaling_modifier, kernel_size=kernel_size, workspace=workspace, check=check)
+        nw = dn = None
+        if epilogue:
+            nw, dn = _epilogue(raster, world_view_transforms.reshape(V, 4, 4).to(raster.device), res, res,
+                               fov * np.pi / 180, fov * np.pi / 180)
+    return {"render": raster[:, :3], "rendered_normal": nw, "rendered_depth": raster[:, 6:7], "depth_normal": dn,
+            "rendered_alpha": raster[:, 7:8], "distortion_map": raster[:, 8:9], "visibility_filter": radii > 0,
+            "radii": radii, "raster": raster, "workspace": ws}

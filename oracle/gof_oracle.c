@@ -667,3 +667,11 @@ int gof_oracle_forward(gof_ctx* c, int P, int D, int M, const float* background,
     }
     return R;
 }
+
+/* exported for tests/test_oracle_pins.py: SH colour of ONE Gaussian (compared against the reference's python
+ * eval_sh, src/gaussian-splatting/utils/sh_utils.py:57-116) */
+void gof_oracle_color_from_sh(int deg, int max_coeffs, const float* mean, const float* campos, const float* sh,
+                              float* rgb_out, uint8_t* clamped_out)
+{
+    computeColorFromSH(0, deg, max_coeffs, mean, campos, sh, clamped_out, rgb_out);
+}

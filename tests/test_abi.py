@@ -1,0 +1,73 @@
+"""The C-ABI library loads and exports every symbol include/f3dg.h declares (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "f3dg.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(f3dg_\w+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound(f3d):
+    from f3dgaus_amd import _lib
+    names = _declared()
+    assert len(names) >= 12
+    L = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"libf3dg_hip.so does not export {n}"
+    assert set(names) == set(_lib.SIGNATURES), (set(names) ^ set(_lib.SIGNATURES))
+    assert _lib.lib().f3dg_version().startswith(b"f3dg-hip gfx950")
+
+
+def test_library_is_gfx950_code_object():
+    lib = os.path.join(ROOT, "f3d-gaus_amd", "csrc", "libf3dg_hip.so")
+    data = open(lib, "rb").read()
+    assert b"gfx950" in data and b"render_fwd_kernel" in data
+
+
+def test_workspace_arithmetic_and_host_side_errors(f3d):
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    a = L.f3dg_workspace_bytes(65536, 256, 256, 1, 200000)
+    b = L.f3dg_workspace_bytes(65536, 256, 256, 1, 400000)
+    c = L.f3dg_workspace_bytes(65536, 256, 256, 8, 400000)
+    assert 0 < a < b < c
+    assert b - a >= 200000 * 24                       # 2 x (u64 key + u32 value) per instance
+    assert L.f3dg_workspace_bytes(-1, 256, 256, 1, 10) == 0
+    assert L.f3dg_workspace_bytes(10, 0, 256, 1, 10) == 0
+    # argument validation happens before any HIP call, so it is testable without a GPU
+    null = None
+    rc = L.f3dg_forward_batched(null, null, 0, 10, 1, 10, 1, 4, null, 64, 64, null, null, null, null, null, 1.0,
+                                null, null, null, null, null, null, 0.1, 0.1, 0.0, null, null, 0)
+    assert rc == _lib.ERR_BAD_ARG
+    buf = (C.c_char * 1024)()
+    one = C.cast(buf, C.c_void_p)
+    rc = L.f3dg_forward_batched(null, one, 1024, 100000, 1, 1000, 1, 4, one, 64, 64, one, one, null, one, one, 1.0,
+                                one, null, null, one, one, one, 0.1, 0.1, 0.0, one, null, 0)
+    assert rc == _lib.ERR_WORKSPACE
+    assert L.f3dg_splat_head(null, 0, 32, 32, *([null] * 5), 1.0, 1024, 0, *([null] * 7)) == _lib.ERR_BAD_ARG
+    assert L.f3dg_mark_visible(null, 5, null, null, null, null) == _lib.ERR_BAD_ARG
+
+
+def test_python_api_errors_without_gpu(f3d):
+    import torch
+    S = f3d.GaussianRasterizationSettings_GOF
+    assert S._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "kernel_size", "subpixel_offset", "bg",
+                         "scale_modifier", "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    rs = S(64, 64, 0.1, 0.1, 0.0, torch.zeros(0), torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 1, torch.zeros(3),
+           False, False)
+    r = f3d.GaussianRasterizer_GOF(rs)
+    x = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=x, means2D=x, opacities=torch.zeros(4, 1), scales=x, rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=x, means2D=x, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 4, 3))
+    with pytest.raises(RuntimeError, match="HIP device"):       # no silent CPU fallback
+        r(means3D=x, means2D=x, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 4, 3), scales=x,
+          rotations=torch.zeros(4, 4))
