@@ -31,7 +31,7 @@ SIGNATURES = {
     "f3dg_forward": (_ll, [_p, _p, _sz, _ll, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,
                            _f, _f, _f, _i, _p, _p, _u, C.POINTER(_ll)]),
     "f3dg_backward": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,
-                           _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+                           _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u]),
     "f3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
     "f3dg_splat_head": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _ll, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "f3dg_render_epilogue": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),

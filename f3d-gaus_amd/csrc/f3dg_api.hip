@@ -129,6 +129,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.ranges = take((size_t)V * T * sizeof(uint2));
     L.final_T = take((size_t)V * 4 * HW * sizeof(float));
     L.n_contrib = take((size_t)V * 2 * HW * sizeof(unsigned));
+    L.bwd_acc = take(VP * 10 * sizeof(double));
     L.total = off;
     return L;
 }

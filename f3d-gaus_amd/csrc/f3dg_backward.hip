@@ -1,5 +1,545 @@
-// f3dg_backward.hip -- backward of the compositing and projection stages (placeholder until the kernels land).
+// f3dg_backward.hip -- backward of the compositing stage and of the per-Gaussian projection stage.
+//
+// Replaces (reference RAST/cuda_rasterizer/backward.cu):
+//   renderCUDA<3> (bwd)              :634-955   -> render_bwd_kernel
+//   preprocessCUDA<3> (bwd)          :593-631   -> preprocess_bwd_kernel, with
+//   computeView2Gaussian_backward    :381-587
+//   computeColorFromSH (bwd)         :20-139
+// The reference's computeCov2DCUDA / computeCov3D backward are commented out there (:992-1007, :627-630), so
+// dL_dconic and dL_dcov3D are identically zero; they are left untouched here as well.
+//
+// MI355X shape. The reference issues 17 float atomicAdds per contributing (pixel, Gaussian) pair. Here all 64
+// lanes of a wave walk the tile list in lock-step, so the 17 partial derivatives of one Gaussian are first
+// summed across the wave with cross-lane butterflies and only lane 0 touches memory: <= 17 atomics per
+// (wave, Gaussian) instead of per (pixel, Gaussian), and nothing at all for the (wave, Gaussian) pairs no lane of
+// the strip contributes to (a ballot). The 10 dL/dview2gaussian entries are accumulated in float64
+// (global_atomic_add_f64): the per-Gaussian stage below amplifies a 5e-7 ordering perturbation of them into tens
+// of percent on dL/dscale (SURVEY 0.9 -- the reference's own run-to-run spread), so float64 sums make the result
+// reproducible to rounding where the reference is not.
 #include "f3dg_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// float64 butterfly: the 64 per-pixel float terms are summed exactly (to double rounding), so the only float32
+// rounding left in dL/dview2gaussian is the final narrowing -- see the header comment on why that matters
+__device__ __forceinline__ double wave_sum_f64(float v)
+{
+    double d = (double)v;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) d += __shfl_xor(d, m, 64);
+    return d;
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                  const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                  const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                  const float2* __restrict__ means2D, const float4* __restrict__ conic,
+                  const float* __restrict__ background, int bg_per_view,
+                  const float* __restrict__ final_T, const unsigned* __restrict__ n_contrib,
+                  const float* __restrict__ dL_dpixels,
+                  float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
+                  double* __restrict__ dL_dv2g_acc)
+{
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned slot = blockIdx.x >> 3;
+    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
+    const unsigned tile = slot % (unsigned)T;
+    if (view >= (unsigned)V)
+        return;
+
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lx = threadIdx.x & 15u, ly = threadIdx.x >> 4;
+    const unsigned pix_x = tile_x * F3DG_TILE + lx, pix_y = tile_y * F3DG_TILE + ly;
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const int rounds = (int)((range.y - range.x + F3DG_BLOCK - 1) / F3DG_BLOCK);
+    int toDo = (int)(range.y - range.x);
+
+    __shared__ float4 staged[F3DG_BLOCK * 4];
+    __shared__ float4 staged_conic[F3DG_BLOCK];
+    __shared__ float2 staged_xy[F3DG_BLOCK];
+    __shared__ unsigned staged_id[F3DG_BLOCK];
+
+    const size_t vP = (size_t)view * P;
+    const float* fT = final_T + (size_t)view * 4 * HW;
+    const unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+    const float* dpix = dL_dpixels + (size_t)view * F3DG_OUT_CHANNELS * HW;
+    const float* bg = background + (bg_per_view ? 3 * view : 0);
+
+    const float T_final = inside ? fT[pix_id] : 0;
+    float Tr = T_final;
+    const float final_D = inside ? fT[pix_id + HW] : 0;
+    const float final_A = 1 - T_final;
+    const float dL_dreg = inside ? dpix[8 * HW + pix_id] : 0;
+
+    unsigned contributor = (unsigned)toDo;
+    const int last_contributor = inside ? (int)nc[pix_id] : 0;
+    const int max_contributor = inside ? (int)nc[pix_id + HW] : 0;
+    float accum_rec0 = 0, accum_rec1 = 0, accum_rec2 = 0;
+    float dpx0 = 0, dpx1 = 0, dpx2 = 0, dn0 = 0, dn1 = 0, dn2 = 0, dL_dmax_depth = 0;
+    if (inside) {
+        dpx0 = dpix[pix_id]; dpx1 = dpix[HW + pix_id]; dpx2 = dpix[2 * HW + pix_id];
+        dn0 = dpix[3 * HW + pix_id]; dn1 = dpix[4 * HW + pix_id]; dn2 = dpix[5 * HW + pix_id];
+        dL_dmax_depth = dpix[6 * HW + pix_id];
+    }
+    float last_alpha = 0;
+    float last_c0 = 0, last_c1 = 0, last_c2 = 0;
+    float last_n0 = 0, last_n1 = 0, last_n2 = 0;
+    float acc_n0 = 0, acc_n1 = 0, acc_n2 = 0;
+    const float ddelx_dx = (float)(0.5 * W);
+    const float ddely_dy = (float)(0.5 * H);
+    const float bg_dot_dpixel = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
+    const bool lane0 = (threadIdx.x & 63u) == 0;
+
+    for (int i = 0; i < rounds; i++, toDo -= F3DG_BLOCK) {
+        __syncthreads();
+        const unsigned progress = (unsigned)i * F3DG_BLOCK + threadIdx.x;
+        if (range.x + progress < range.y) {
+            const unsigned id = point_list[range.y - progress - 1];       // back to front
+            const float4* src = reinterpret_cast<const float4*>(rec + vP + id);
+            staged[threadIdx.x * 4 + 0] = src[0];
+            staged[threadIdx.x * 4 + 1] = src[1];
+            staged[threadIdx.x * 4 + 2] = src[2];
+            staged[threadIdx.x * 4 + 3] = src[3];
+            staged_conic[threadIdx.x] = conic[vP + id];
+            staged_xy[threadIdx.x] = means2D[vP + id];
+            staged_id[threadIdx.x] = id;
+        }
+        __syncthreads();
+
+        const int n = min(F3DG_BLOCK, toDo);
+        for (int j = 0; j < n; j++) {
+            contributor--;
+            bool active = inside && !(contributor >= (unsigned)last_contributor);
+
+            const float4 q0 = staged[j * 4 + 0];
+            const float4 q1 = staged[j * 4 + 1];
+            const float4 q2 = staged[j * 4 + 2];
+            const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+            const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+            const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+            const double AA = ray_x * n0 + ray_y * n1 + n2;
+            const double BB = 2 * (q1.z * ray_x + q1.w * ray_y + q2.x);
+            const float CC = q2.y;
+            const float t = (float)(-BB / (2 * AA));
+            if (t <= F3DG_NEAR_PLANE) active = false;
+            const double min_value = -(BB / AA) * (BB / 4.) + CC;
+            float power = (float)(-0.5f * min_value);
+            if (power > 0.0f) power = 0.0f;
+            const float G = expf(power);
+            const float alpha = fminf(0.99f, q2.z * G);
+            if (alpha < 1.0f / 255.0f) active = false;
+
+            if (__ballot(active) == 0)      // no pixel of this 16x4 strip contributes: nothing to do for the wave
+                continue;
+
+            float g_col0 = 0, g_col1 = 0, g_col2 = 0, g_mx = 0, g_my = 0, g_mz = 0, g_op = 0;
+            float g_v0 = 0, g_v1 = 0, g_v2 = 0, g_v3 = 0, g_v4 = 0, g_v5 = 0, g_v6 = 0, g_v7 = 0, g_v8 = 0, g_v9 = 0;
+            if (active) {
+                const float4 q3 = staged[j * 4 + 3];
+                const float4 con = staged_conic[j];
+                const float2 xy = staged_xy[j];
+                const float d_x = (float)(xy.x - (pixf_x - 0.5)), d_y = (float)(xy.y - (pixf_y - 0.5));
+
+                const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
+                const float dmax_t_dd = (float)((F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t * t));
+                const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
+                const float nn0 = -n0 / length, nn1 = -n1 / length, nn2 = -n2 / length;
+
+                Tr = Tr / (1.f - alpha);
+                const float dchannel_dcolor = alpha * Tr;
+
+                float dL_dalpha = 0.0f;
+                const float c0 = q2.w, c1 = q3.x, c2 = q3.y;
+                accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0; last_c0 = c0;
+                dL_dalpha += (c0 - accum_rec0) * dpx0; g_col0 = dchannel_dcolor * dpx0;
+                accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1; last_c1 = c1;
+                dL_dalpha += (c1 - accum_rec1) * dpx1; g_col1 = dchannel_dcolor * dpx1;
+                accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2; last_c2 = c2;
+                dL_dalpha += (c2 - accum_rec2) * dpx2; g_col2 = dchannel_dcolor * dpx2;
+
+                // distortion: only dL/dmax_t survives, the weight gradient is detached (backward.cu:850-852) and
+                // last_dL_dT therefore stays 0
+                float dL_dmax_t = 0.0f;
+                dL_dmax_t += 2.0f * (Tr * alpha) * (mapped_max_t * final_A - final_D) * dL_dreg * dmax_t_dd;
+                dL_dalpha += 0.f - 0.f;
+
+                acc_n0 = last_alpha * last_n0 + (1.f - last_alpha) * acc_n0; last_n0 = nn0;
+                dL_dalpha += (nn0 - acc_n0) * dn0;
+                const float dnn0 = alpha * Tr * dn0;
+                acc_n1 = last_alpha * last_n1 + (1.f - last_alpha) * acc_n1; last_n1 = nn1;
+                dL_dalpha += (nn1 - acc_n1) * dn1;
+                const float dnn1 = alpha * Tr * dn1;
+                acc_n2 = last_alpha * last_n2 + (1.f - last_alpha) * acc_n2; last_n2 = nn2;
+                dL_dalpha += (nn2 - acc_n2) * dn2;
+                const float dnn2 = alpha * Tr * dn2;
+
+                float dL_dlength = (dnn0 * n0 + dnn1 * n1 + dnn2 * n2);
+                dL_dlength *= 1.f / (length * length);
+                float dLn0 = (-dnn0 + dL_dlength * n0) / length;
+                float dLn1 = (-dnn1 + dL_dlength * n1) / length;
+                float dLn2 = (-dnn2 + dL_dlength * n2) / length;
+
+                float dL_dt = dL_dmax_t;
+                if ((int)contributor == max_contributor - 1)
+                    dL_dt += dL_dmax_depth;
+
+                dL_dalpha *= Tr;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+                const float dL_dG = con.w * dL_dalpha;
+                const float gdx = G * d_x;
+                const float gdy = G * d_y;
+                const float dG_ddelx = -gdx * con.x - gdy * con.y;
+                const float dG_ddely = -gdy * con.z - gdx * con.y;
+                g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                g_my = dL_dG * dG_ddely * ddely_dy;
+                g_mz = fabsf(dL_dG * dG_ddelx * ddelx_dx) + fabsf(dL_dG * dG_ddely * ddely_dy);
+                g_op = G * dL_dalpha;
+
+                const float dL_dpower = dL_dG * G;
+                const float dL_dmin_value = dL_dpower * -0.5f;
+                double dL_dA = dL_dmin_value * (BB / AA) * (BB / AA) / 4.f;
+                double dL_dB = dL_dmin_value * -BB / (2 * AA);
+                const double dL_dC = dL_dmin_value * 1.0f;
+                dL_dA += dL_dt * BB / (2 * AA * AA);
+                dL_dB += dL_dt * -1.f / (2 * AA);
+                dLn0 += dL_dA * ray_x;
+                dLn1 += dL_dA * ray_y;
+                dLn2 += dL_dA;
+
+                g_v0 = dLn0 * ray_x;
+                g_v1 = dLn0 * ray_y + dLn1 * ray_x;
+                g_v2 = dLn0 + dLn2 * ray_x;
+                g_v3 = dLn1 * ray_y;
+                g_v4 = dLn1 + dLn2 * ray_y;
+                g_v5 = dLn2;
+                g_v6 = (float)(dL_dB * 2 * ray_x);
+                g_v7 = (float)(dL_dB * 2 * ray_y);
+                g_v8 = (float)(dL_dB * 2);
+                g_v9 = (float)dL_dC;
+            }
+
+            // sum the 17 partials over the wave's 64 pixels, then one lane updates memory
+            g_col0 = wave_sum(g_col0); g_col1 = wave_sum(g_col1); g_col2 = wave_sum(g_col2);
+            g_mx = wave_sum(g_mx); g_my = wave_sum(g_my); g_mz = wave_sum(g_mz); g_op = wave_sum(g_op);
+            const double s_v0 = wave_sum_f64(g_v0), s_v1 = wave_sum_f64(g_v1), s_v2 = wave_sum_f64(g_v2),
+                         s_v3 = wave_sum_f64(g_v3), s_v4 = wave_sum_f64(g_v4), s_v5 = wave_sum_f64(g_v5),
+                         s_v6 = wave_sum_f64(g_v6), s_v7 = wave_sum_f64(g_v7), s_v8 = wave_sum_f64(g_v8),
+                         s_v9 = wave_sum_f64(g_v9);
+            if (lane0) {
+                const unsigned id = staged_id[j];
+                const size_t gi = vP + id;
+                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 0], g_col0);
+                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 1], g_col1);
+                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 2], g_col2);
+                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 0], g_mx);
+                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 1], g_my);
+                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 2], g_mz);
+                unsafeAtomicAdd(&dL_dopacity[id], g_op);
+                double* a = dL_dv2g_acc + gi * 10;
+                unsafeAtomicAdd(a + 0, s_v0); unsafeAtomicAdd(a + 1, s_v1);
+                unsafeAtomicAdd(a + 2, s_v2); unsafeAtomicAdd(a + 3, s_v3);
+                unsafeAtomicAdd(a + 4, s_v4); unsafeAtomicAdd(a + 5, s_v5);
+                unsafeAtomicAdd(a + 6, s_v6); unsafeAtomicAdd(a + 7, s_v7);
+                unsafeAtomicAdd(a + 8, s_v8); unsafeAtomicAdd(a + 9, s_v9);
+            }
+        }
+    }
+}
+
+struct M3 { float m[3][3]; };
+struct M4 { float m[4][4]; };
+__device__ __forceinline__ M3 mul(const M3& a, const M3& b)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = a.m[0][q] * b.m[c][0] + a.m[1][q] * b.m[c][1] + a.m[2][q] * b.m[c][2];
+    return r;
+}
+__device__ __forceinline__ M3 transpose(const M3& a)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = a.m[q][c];
+    return r;
+}
+__device__ __forceinline__ M4 mul(const M4& a, const M4& b)
+{
+    M4 r;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            r.m[c][q] = a.m[0][q] * b.m[c][0] + a.m[1][q] * b.m[c][1] + a.m[2][q] * b.m[c][2] + a.m[3][q] * b.m[c][3];
+    return r;
+}
+
+__device__ __constant__ float B_SH_C0 = 0.28209479177387814f;
+__device__ __constant__ float B_SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float B_SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                             -1.0925484305920792f, 0.5462742152960396f };
+__device__ __constant__ float B_SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                             0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                             -0.5900435899266435f };
+
+// One thread per (view, Gaussian): view2gaussian backward + SH backward; per-Gaussian parameter gradients are
+// accumulated over the views of the call (for one view: written once into the zero-filled outputs).
+__global__ void __launch_bounds__(F3DG_BLOCK)
+preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
+                      const float* __restrict__ shs, const unsigned char* __restrict__ clamped,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      const float* __restrict__ viewmatrices, const float* __restrict__ cam_positions,
+                      const double* __restrict__ dL_dv2g_acc, float* __restrict__ dL_dv2g_out,
+                      const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
+                      float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+{
+    const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    const int v = blockIdx.y;
+    if (g >= P) return;
+    const size_t idx = (size_t)v * P + g;
+
+    float dv[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        dv[i] = (float)dL_dv2g_acc[idx * 10 + i];
+        dL_dv2g_out[idx * 10 + i] = dv[i];
+    }
+    if (!(radii[idx] > 0)) return;
+    const float* view = viewmatrices + 16 * v;
+
+    float dmean[3] = { 0, 0, 0 };
+    if (scales && rotations) {
+        const float sx = scales[3 * (size_t)g], sy = scales[3 * (size_t)g + 1], sz = scales[3 * (size_t)g + 2];
+        const float4 rot = reinterpret_cast<const float4*>(rotations)[g];
+        const float mx = means3D[3 * (size_t)g], my = means3D[3 * (size_t)g + 1], mz = means3D[3 * (size_t)g + 2];
+        const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+        M3 R;
+        R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[0][1] = 2.f * (x * y - r * z);       R.m[0][2] = 2.f * (x * z + r * y);
+        R.m[1][0] = 2.f * (x * y + r * z);       R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[1][2] = 2.f * (y * z - r * x);
+        R.m[2][0] = 2.f * (x * z - r * y);       R.m[2][1] = 2.f * (y * z + r * x);       R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+
+        M4 G2W, W2V;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            G2W.m[c][0] = R.m[0][c]; G2W.m[c][1] = R.m[1][c]; G2W.m[c][2] = R.m[2][c]; G2W.m[c][3] = 0.0f;
+        }
+        G2W.m[3][0] = mx; G2W.m[3][1] = my; G2W.m[3][2] = mz; G2W.m[3][3] = 1.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                W2V.m[c][q] = view[4 * c + q];
+        const M4 G2V = mul(W2V, G2W);
+
+        M3 Rt;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { Rt.m[c][0] = G2V.m[0][c]; Rt.m[c][1] = G2V.m[1][c]; Rt.m[c][2] = G2V.m[2][c]; }
+        const float tx = G2V.m[3][0], ty = G2V.m[3][1], tz = G2V.m[3][2];
+        float t2[3];
+        t2[0] = (-Rt.m[0][0]) * tx + (-Rt.m[1][0]) * ty + (-Rt.m[2][0]) * tz;
+        t2[1] = (-Rt.m[0][1]) * tx + (-Rt.m[1][1]) * ty + (-Rt.m[2][1]) * tz;
+        t2[2] = (-Rt.m[0][2]) * tx + (-Rt.m[1][2]) * ty + (-Rt.m[2][2]) * tz;
+
+        const double S[3] = { 1.0f / ((double)sx * sx + 1e-7), 1.0f / ((double)sy * sy + 1e-7), 1.0f / ((double)sz * sz + 1e-7) };
+        M3 SR;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                SR.m[c][q] = (float)(S[q] * Rt.m[c][q]);
+
+        M3 dSig;
+        dSig.m[0][0] = dv[0];        dSig.m[0][1] = 0.5f * dv[1]; dSig.m[0][2] = 0.5f * dv[2];
+        dSig.m[1][0] = 0.5f * dv[1]; dSig.m[1][1] = dv[3];        dSig.m[1][2] = 0.5f * dv[4];
+        dSig.m[2][0] = 0.5f * dv[2]; dSig.m[2][1] = 0.5f * dv[4]; dSig.m[2][2] = dv[5];
+        const float dB[3] = { dv[6], dv[7], dv[8] };
+        const float dC = dv[9];
+
+        M3 Dm = mul(Rt, dSig);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                Dm.m[i][j] = Dm.m[i][j] + t2[j] * dB[i];
+        M3 dRt = transpose(mul(dSig, transpose(SR)));
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                dRt.m[c][q] = dRt.m[c][q] + (float)(S[q] * Dm.m[c][q]);
+
+        float dS[3], dt2[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            dS[q] = Dm.m[0][q] * Rt.m[0][q] + Dm.m[1][q] * Rt.m[1][q] + Dm.m[2][q] * Rt.m[2][q];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            dt2[q] = (float)(2 * t2[q] * S[q] * dC + dB[0] * SR.m[0][q] + dB[1] * SR.m[1][q] + dB[2] * SR.m[2][q]);
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            dS[q] += dC * t2[q] * t2[q];
+        const float sc[3] = { sx, sy, sz };
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            unsafeAtomicAdd(&dL_dscale[3 * (size_t)g + q], (float)(-2 / sc[q] * S[q] * dS[q]));
+
+        const M3 dV2G_R_t = transpose(dRt);
+        M3 dG2V_R;
+        const float tv[3] = { tx, ty, tz };
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                dG2V_R.m[c][q] = dV2G_R_t.m[c][q] + (-dt2[c] * tv[q]);
+        const float nd[3] = { -dt2[0], -dt2[1], -dt2[2] };
+        float dG2V_t[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            dG2V_t[c] = Rt.m[c][0] * nd[0] + Rt.m[c][1] * nd[1] + Rt.m[c][2] * nd[2];
+
+        M4 dG2V, W2Vt;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            dG2V.m[c][0] = dG2V_R.m[c][0]; dG2V.m[c][1] = dG2V_R.m[c][1]; dG2V.m[c][2] = dG2V_R.m[c][2]; dG2V.m[c][3] = 0.0f;
+        }
+        dG2V.m[3][0] = dG2V_t[0]; dG2V.m[3][1] = dG2V_t[1]; dG2V.m[3][2] = dG2V_t[2]; dG2V.m[3][3] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                W2Vt.m[c][q] = W2V.m[q][c];
+        const M4 dG2W = mul(W2Vt, dG2V);
+
+        dmean[0] = dG2W.m[3][0]; dmean[1] = dG2W.m[3][1]; dmean[2] = dG2W.m[3][2];
+        float Mt[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                Mt[c][q] = dG2W.m[c][q];
+        const float q0 = 2 * z * (Mt[0][1] - Mt[1][0]) + 2 * y * (Mt[2][0] - Mt[0][2]) + 2 * x * (Mt[1][2] - Mt[2][1]);
+        const float q1 = 2 * y * (Mt[1][0] + Mt[0][1]) + 2 * z * (Mt[2][0] + Mt[0][2]) + 2 * r * (Mt[1][2] - Mt[2][1]) - 4 * x * (Mt[2][2] + Mt[1][1]);
+        const float q2 = 2 * x * (Mt[1][0] + Mt[0][1]) + 2 * r * (Mt[2][0] - Mt[0][2]) + 2 * z * (Mt[1][2] + Mt[2][1]) - 4 * y * (Mt[2][2] + Mt[0][0]);
+        const float q3 = 2 * r * (Mt[0][1] - Mt[1][0]) + 2 * x * (Mt[2][0] + Mt[0][2]) + 2 * y * (Mt[1][2] + Mt[2][1]) - 4 * z * (Mt[1][1] + Mt[0][0]);
+        unsafeAtomicAdd(&dL_drot[4 * (size_t)g + 0], q0);
+        unsafeAtomicAdd(&dL_drot[4 * (size_t)g + 1], q1);
+        unsafeAtomicAdd(&dL_drot[4 * (size_t)g + 2], q2);
+        unsafeAtomicAdd(&dL_drot[4 * (size_t)g + 3], q3);
+    }
+
+    if (shs) {
+        const float* campos = cam_positions + 3 * v;
+        const float o0 = means3D[3 * (size_t)g] - campos[0], o1 = means3D[3 * (size_t)g + 1] - campos[1], o2 = means3D[3 * (size_t)g + 2] - campos[2];
+        const float len = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+        const float x = o0 / len, y = o1 / len, z = o2 / len;
+        const float* sh = shs + (size_t)g * M * 3;
+        const unsigned char cl = clamped[idx];
+        float dRGB[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            dRGB[ch] = dL_dcolor[idx * 3 + ch] * ((cl >> ch) & 1 ? 0 : 1);
+        float ddx[3] = { 0, 0, 0 }, ddy[3] = { 0, 0, 0 }, ddz[3] = { 0, 0, 0 };
+        float* dsh = dL_dsh + (size_t)g * M * 3;
+#define F3DG_DSH(k, val) do { const float _w = (val); for (int ch = 0; ch < 3; ch++) unsafeAtomicAdd(&dsh[(k) * 3 + ch], _w * dRGB[ch]); } while (0)
+#define F3DG_SH(k, ch) sh[(k) * 3 + (ch)]
+        F3DG_DSH(0, B_SH_C0);
+        if (D > 0) {
+            F3DG_DSH(1, -B_SH_C1 * y);
+            F3DG_DSH(2, B_SH_C1 * z);
+            F3DG_DSH(3, -B_SH_C1 * x);
+            for (int ch = 0; ch < 3; ch++) {
+                ddx[ch] = -B_SH_C1 * F3DG_SH(3, ch);
+                ddy[ch] = -B_SH_C1 * F3DG_SH(1, ch);
+                ddz[ch] = B_SH_C1 * F3DG_SH(2, ch);
+            }
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z;
+                const float xy = x * y, yz = y * z, xz = x * z;
+                F3DG_DSH(4, B_SH_C2[0] * xy);
+                F3DG_DSH(5, B_SH_C2[1] * yz);
+                F3DG_DSH(6, B_SH_C2[2] * (2.f * zz - xx - yy));
+                F3DG_DSH(7, B_SH_C2[3] * xz);
+                F3DG_DSH(8, B_SH_C2[4] * (xx - yy));
+                for (int ch = 0; ch < 3; ch++) {
+                    ddx[ch] += B_SH_C2[0] * y * F3DG_SH(4, ch) + B_SH_C2[2] * 2.f * -x * F3DG_SH(6, ch) + B_SH_C2[3] * z * F3DG_SH(7, ch) + B_SH_C2[4] * 2.f * x * F3DG_SH(8, ch);
+                    ddy[ch] += B_SH_C2[0] * x * F3DG_SH(4, ch) + B_SH_C2[1] * z * F3DG_SH(5, ch) + B_SH_C2[2] * 2.f * -y * F3DG_SH(6, ch) + B_SH_C2[4] * 2.f * -y * F3DG_SH(8, ch);
+                    ddz[ch] += B_SH_C2[1] * y * F3DG_SH(5, ch) + B_SH_C2[2] * 2.f * 2.f * z * F3DG_SH(6, ch) + B_SH_C2[3] * x * F3DG_SH(7, ch);
+                }
+                if (D > 2) {
+                    F3DG_DSH(9, B_SH_C3[0] * y * (3.f * xx - yy));
+                    F3DG_DSH(10, B_SH_C3[1] * xy * z);
+                    F3DG_DSH(11, B_SH_C3[2] * y * (4.f * zz - xx - yy));
+                    F3DG_DSH(12, B_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                    F3DG_DSH(13, B_SH_C3[4] * x * (4.f * zz - xx - yy));
+                    F3DG_DSH(14, B_SH_C3[5] * z * (xx - yy));
+                    F3DG_DSH(15, B_SH_C3[6] * x * (xx - 3.f * yy));
+                    for (int ch = 0; ch < 3; ch++) {
+                        ddx[ch] += (
+                            B_SH_C3[0] * F3DG_SH(9, ch) * 3.f * 2.f * xy +
+                            B_SH_C3[1] * F3DG_SH(10, ch) * yz +
+                            B_SH_C3[2] * F3DG_SH(11, ch) * -2.f * xy +
+                            B_SH_C3[3] * F3DG_SH(12, ch) * -3.f * 2.f * xz +
+                            B_SH_C3[4] * F3DG_SH(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                            B_SH_C3[5] * F3DG_SH(14, ch) * 2.f * xz +
+                            B_SH_C3[6] * F3DG_SH(15, ch) * 3.f * (xx - yy));
+                        ddy[ch] += (
+                            B_SH_C3[0] * F3DG_SH(9, ch) * 3.f * (xx - yy) +
+                            B_SH_C3[1] * F3DG_SH(10, ch) * xz +
+                            B_SH_C3[2] * F3DG_SH(11, ch) * (-3.f * yy + 4.f * zz - xx) +
+                            B_SH_C3[3] * F3DG_SH(12, ch) * -3.f * 2.f * yz +
+                            B_SH_C3[4] * F3DG_SH(13, ch) * -2.f * xy +
+                            B_SH_C3[5] * F3DG_SH(14, ch) * -2.f * yz +
+                            B_SH_C3[6] * F3DG_SH(15, ch) * -3.f * 2.f * xy);
+                        ddz[ch] += (
+                            B_SH_C3[1] * F3DG_SH(10, ch) * xy +
+                            B_SH_C3[2] * F3DG_SH(11, ch) * 4.f * 2.f * yz +
+                            B_SH_C3[3] * F3DG_SH(12, ch) * 3.f * (2.f * zz - xx - yy) +
+                            B_SH_C3[4] * F3DG_SH(13, ch) * 4.f * 2.f * xz +
+                            B_SH_C3[5] * F3DG_SH(14, ch) * (xx - yy));
+                    }
+                }
+            }
+        }
+#undef F3DG_DSH
+#undef F3DG_SH
+        const float dd0 = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
+        const float dd1 = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
+        const float dd2 = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
+        // dnormvdv (auxiliary.h:145-155)
+        const float sum2 = o0 * o0 + o1 * o1 + o2 * o2;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean[0] += ((+sum2 - o0 * o0) * dd0 - o1 * o0 * dd1 - o2 * o0 * dd2) * invsum32;
+        dmean[1] += (-o0 * o1 * dd0 + (sum2 - o1 * o1) * dd1 - o2 * o1 * dd2) * invsum32;
+        dmean[2] += (-o0 * o2 * dd0 - o1 * o2 * dd1 + (sum2 - o2 * o2) * dd2) * invsum32;
+    }
+    unsafeAtomicAdd(&dL_dmeans[3 * (size_t)g + 0], dmean[0]);
+    unsafeAtomicAdd(&dL_dmeans[3 * (size_t)g + 1], dmean[1]);
+    unsafeAtomicAdd(&dL_dmeans[3 * (size_t)g + 2], dmean[2]);
+}
+
+} // namespace
 
 extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
                              int n_views, int P, int D, int M, const float* background, int W, int H,
@@ -11,7 +551,45 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
                              const int* radii, const float* dL_dpix,
                              float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                              float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                             float* dL_dview2gaussian)
+                             float* dL_dview2gaussian, unsigned flags)
 {
-    return F3DG_ERR_UNSUPPORTED;
+    (void)scale_modifier; (void)projmatrix; (void)kernel_size; (void)dL_dconic; (void)dL_dcov3D;
+    (void)cov3D_precomp; (void)colors_precomp; (void)view2gaussian_precomp;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_views <= 0 || P < 0 || W <= 0 || H <= 0 || !workspace || !dL_dpix || !background) return F3DG_ERR_BAD_ARG;
+    if (P == 0) return F3DG_OK;
+    if (!means3D || !viewmatrix || !cam_pos || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
+        !dL_dview2gaussian)
+        return F3DG_ERR_BAD_ARG;
+    if ((scales != nullptr) != (rotations != nullptr)) return F3DG_ERR_BAD_ARG;
+    if (scales && (!dL_dscale || !dL_drot)) return F3DG_ERR_BAD_ARG;
+    if (shs && !dL_dsh) return F3DG_ERR_BAD_ARG;
+    const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
+    if (workspace_bytes < L.total) return F3DG_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    const F3dgHeader* hdr = reinterpret_cast<const F3dgHeader*>(ws + L.header);
+    const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    const int T = tiles_x * tiles_y;
+    const float focal_y = H / (2.0f * tan_fovy);
+    const float focal_x = W / (2.0f * tan_fovx);
+    const int* radii_used = radii ? radii : reinterpret_cast<const int*>(ws + L.radii);
+
+    // float64 accumulator of dL/dview2gaussian (its own region of the workspace)
+    double* acc = reinterpret_cast<double*>(ws + L.bwd_acc);
+    F3DG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * 10 * (size_t)n_views * P, s));
+
+    const unsigned groups = (unsigned)((n_views + 7) / 8);
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(groups * 8u * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
+                       tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
+                       reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
+                       reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
+                       background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
+                       reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
+                       acc);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK, n_views), dim3(F3DG_BLOCK), 0, s, P,
+                       D, M, means3D, radii_used, shs, reinterpret_cast<const unsigned char*>(ws + L.clamped), scales,
+                       rotations, viewmatrix, cam_pos, acc, dL_dview2gaussian, dL_dcolor, dL_dmean3D, dL_dsh, dL_dscale,
+                       dL_drot);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
 }

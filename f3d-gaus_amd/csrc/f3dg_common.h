@@ -52,6 +52,7 @@ struct F3dgLayout {
     size_t ranges;         // [V*T] uint2
     size_t final_T;        // [V][4][H*W] float
     size_t n_contrib;      // [V][2][H*W] u32
+    size_t bwd_acc;        // [V*P][10] double: float64 accumulator of dL/dview2gaussian (backward only)
     size_t total;
     unsigned int sort_blocks;
     unsigned int scan_tmp_elems;

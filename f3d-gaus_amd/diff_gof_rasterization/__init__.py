@@ -180,9 +180,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 view2gaussian_precomp, raster_settings):
         rs = raster_settings
-        needs_grad = torch.is_grad_enabled() and any(
-            isinstance(t, torch.Tensor) and t.requires_grad
-            for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations))
+        needs_grad = any(ctx.needs_input_grad)      # (grad mode is always off inside Function.forward)
         device = means3D.device
         P = means3D.size(0) if means3D.ndim == 2 else 0
         key = device.index

@@ -127,7 +127,7 @@ int f3dg_backward(void* stream, void* workspace, size_t workspace_bytes, long lo
                   const int* radii, const float* dL_dpix,
                   float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                   float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                  float* dL_dview2gaussian);
+                  float* dL_dview2gaussian, unsigned flags /* F3DG_FLAG_BG_PER_VIEW as in the forward */);
 
 /* present[i] = (view-space z of means3D[i] > 0.2), auxiliary.h:177-202. present is uint8 [P]. */
 int f3dg_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,

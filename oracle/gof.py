@@ -41,8 +41,8 @@ def lib():
         L.gof_oracle_num_rendered.argtypes = [vp]
         L.gof_oracle_higher_msb.restype = C.c_uint32
         L.gof_oracle_higher_msb.argtypes = [C.c_uint32]
-        if hasattr(L, "gof_oracle_backward"):
-            L.gof_oracle_backward.restype = None
+        L.gof_oracle_backward.restype = None
+        L.gof_oracle_backward.argtypes = [vp] + [fp] * 17
         _LIB = L
     return _LIB
 
@@ -103,6 +103,24 @@ class Oracle:
         self.scale_modifier, self.kernel_size, self.tanfovx, self.tanfovy = scale_modifier, kernel_size, tanfovx, tanfovy
         self.out_color, self.radii = out, radii
         return out, radii, R
+
+    def backward(self, dL_dpix):
+        """Gradients of the last forward w.r.t. its inputs given dL/d(out_color) [9,H,W]. Returns a dict with the
+        nine tensors Rasterizer::backward produces (dL_dconic / dL_dcov3D are identically zero in the reference)."""
+        a, P, M = self.args, self.P, self.M
+        dL_dpix = _f32(dL_dpix).reshape(9, self.H, self.W)
+        g = dict(dL_dmean2D=np.zeros((P, 3), np.float32), dL_dopacity=np.zeros((P, 1), np.float32),
+                 dL_dcolor=np.zeros((P, 3), np.float32), dL_dmean3D=np.zeros((P, 3), np.float32),
+                 dL_dsh=np.zeros((P, max(M, 0), 3), np.float32), dL_dscale=np.zeros((P, 3), np.float32),
+                 dL_drot=np.zeros((P, 4), np.float32), dL_dview2gaussian=np.zeros((P, 10), np.float32))
+        self._L.gof_oracle_backward(
+            self._ctx, _ptr(a["bg"]), _ptr(a["means3D"]), _ptr(a["shs"]), _ptr(a["scales"]), _ptr(a["rotations"]),
+            _ptr(a["viewmatrix"]), _ptr(a["campos"]), _ptr(self.radii), _ptr(dL_dpix),
+            _ptr(g["dL_dmean2D"]), _ptr(g["dL_dopacity"]), _ptr(g["dL_dcolor"]), _ptr(g["dL_dmean3D"]),
+            _ptr(g["dL_dsh"]), _ptr(g["dL_dscale"]), _ptr(g["dL_drot"]), _ptr(g["dL_dview2gaussian"]))
+        g["dL_dconic"] = np.zeros((P, 2, 2), np.float32)
+        g["dL_dcov3D"] = np.zeros((P, 6), np.float32)
+        return g
 
     def intermediates(self):
         L, c, P, R = self._L, self._ctx, self.P, self.R

@@ -675,3 +675,422 @@ void gof_oracle_color_from_sh(int deg, int max_coeffs, const float* mean, const 
 {
     computeColorFromSH(0, deg, max_coeffs, mean, campos, sh, clamped_out, rgb_out);
 }
+
+/* ========================================================================================== */
+/*                                        BACKWARD                                            */
+/* ========================================================================================== */
+
+/* auxiliary.h:145-155 */
+static void dnormvdv3(const float v[3], const float dv[3], float out[3])
+{
+    float sum2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    out[0] = ((+sum2 - v[0] * v[0]) * dv[0] - v[1] * v[0] * dv[1] - v[2] * v[0] * dv[2]) * invsum32;
+    out[1] = (-v[0] * v[1] * dv[0] + (sum2 - v[1] * v[1]) * dv[1] - v[2] * v[1] * dv[2]) * invsum32;
+    out[2] = (-v[0] * v[2] * dv[0] - v[1] * v[2] * dv[1] + (sum2 - v[2] * v[2]) * dv[2]) * invsum32;
+}
+
+/* backward.cu:634-955, one pixel. Per-Gaussian sums are accumulated in DOUBLE here (the reference uses float
+ * atomicAdd in a nondeterministic order; a double sum is the order-free value every such execution rounds around). */
+static void render_pixel_backward(const gof_ctx* c, uint32_t px, uint32_t py, const uint32_t* list, int count,
+                                  const float* bg, const float* dL_dpixels,
+                                  double* dL_dmean2D, double* dL_dopacity, double* dL_dcolors, double* dL_dv2g)
+{
+    const int W = c->W, H = c->H;
+    const size_t HW = (size_t)H * W;
+    const uint32_t pix_id = (uint32_t)W * py + px;
+    const float pixf_x = (float)px + 0.5f, pixf_y = (float)py + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / c->focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / c->focal_y);
+
+    const float T_final = c->final_T[pix_id];
+    float T = T_final;
+    const float final_D = c->final_T[pix_id + HW];
+    const float final_A = 1 - T_final;
+    const float dL_dreg = dL_dpixels[DISTORTION_OFFSET * HW + pix_id];
+
+    float last_dL_dT = 0;
+    uint32_t contributor = (uint32_t)count;
+    const int last_contributor = (int)c->n_contrib[pix_id];
+    const int max_contributor = (int)c->n_contrib[pix_id + HW];
+    float accum_rec[3] = { 0 };
+    float dL_dpixel[3], dL_dnormal2D[3];
+    for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * HW + pix_id];
+    for (int i = 0; i < 3; i++) dL_dnormal2D[i] = dL_dpixels[(3 + i) * HW + pix_id];
+    const float dL_dmax_depth = dL_dpixels[DEPTH_OFFSET * HW + pix_id];
+
+    float last_alpha = 0;
+    float last_color[3] = { 0 };
+    float last_normal[3] = { 0 };
+    float accum_normal_rec[3] = { 0 };
+
+    const float ddelx_dx = (float)(0.5 * W);
+    const float ddely_dy = (float)(0.5 * H);
+
+    for (int j = 0; j < count; j++) {
+        contributor--;
+        if (contributor >= (uint32_t)last_contributor)
+            continue;
+        const uint32_t id = list[count - 1 - j];
+
+        const float xy_x = c->means2D[2 * (size_t)id], xy_y = c->means2D[2 * (size_t)id + 1];
+        const float d_x = (float)(xy_x - (pixf_x - 0.5)), d_y = (float)(xy_y - (pixf_y - 0.5));
+        const float* con_o = c->conic_opacity + 4 * (size_t)id;
+        const float* v = c->v2g_used + (size_t)id * 10;
+
+        const float normal[3] = {
+            v[0] * ray_x + v[1] * ray_y + v[2],
+            v[1] * ray_x + v[3] * ray_y + v[4],
+            v[2] * ray_x + v[4] * ray_y + v[5]
+        };
+        double AA = ray_x * normal[0] + ray_y * normal[1] + normal[2];
+        double BB = 2 * (v[6] * ray_x + v[7] * ray_y + v[8]);
+        float CC = v[9];
+
+        float t = (float)(-BB / (2 * AA));
+        if (t <= NEAR_PLANE)
+            continue;
+        double min_value = -(BB / AA) * (BB / 4.) + CC;
+        float power = (float)(-0.5f * min_value);
+        if (power > 0.0f)
+            power = 0.0f;
+
+        const float G = expf(power);
+        const float alpha = fminf(0.99f, con_o[3] * G);
+        if (alpha < 1.0f / 255.0f)
+            continue;
+
+        const float max_t = t;
+        const float mapped_max_t = (float)((FAR_PLANE * max_t - FAR_PLANE * NEAR_PLANE) / ((FAR_PLANE - NEAR_PLANE) * max_t));
+        float dmax_t_dd = (float)((FAR_PLANE * NEAR_PLANE) / ((FAR_PLANE - NEAR_PLANE) * max_t * max_t));
+
+        float length = (float)sqrt(normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2] + 1e-7);
+        const float nn[3] = { -normal[0] / length, -normal[1] / length, -normal[2] / length };
+
+        T = T / (1.f - alpha);
+        const float dchannel_dcolor = alpha * T;
+
+        float dL_dalpha = 0.0f;
+        for (int ch = 0; ch < 3; ch++) {
+            const float col = c->colors_used[(size_t)id * 3 + ch];
+            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+            last_color[ch] = col;
+            const float dL_dchannel = dL_dpixel[ch];
+            dL_dalpha += (col - accum_rec[ch]) * dL_dchannel;
+            dL_dcolors[(size_t)id * 3 + ch] += (double)(dchannel_dcolor * dL_dchannel);
+        }
+
+        float dL_dt = 0.0f;
+        float dL_dmax_t = 0.0f;
+        float dL_dweight = 0.0f;
+        dL_dmax_t += 2.0f * (T * alpha) * (mapped_max_t * final_A - final_D) * dL_dreg * dmax_t_dd;
+        /* the weight gradient of the distortion term is explicitly detached: backward.cu:850-852 */
+        dL_dweight = 0.f;
+        dL_dalpha += dL_dweight - last_dL_dT;
+        last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+
+        float dL_dnn[3] = { 0 };
+        for (int ch = 0; ch < 3; ch++) {
+            accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+            last_normal[ch] = nn[ch];
+            dL_dalpha += (nn[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
+            dL_dnn[ch] = alpha * T * dL_dnormal2D[ch];
+        }
+        float dL_dlength = (dL_dnn[0] * normal[0] + dL_dnn[1] * normal[1] + dL_dnn[2] * normal[2]);
+        dL_dlength *= 1.f / (length * length);
+        float dL_dnormal[3] = {
+            (-dL_dnn[0] + dL_dlength * normal[0]) / length,
+            (-dL_dnn[1] + dL_dlength * normal[1]) / length,
+            (-dL_dnn[2] + dL_dlength * normal[2]) / length
+        };
+
+        dL_dt = dL_dmax_t;
+        if ((int)contributor == max_contributor - 1)
+            dL_dt += dL_dmax_depth;
+
+        dL_dalpha *= T;
+        last_alpha = alpha;
+
+        float bg_dot_dpixel = 0;
+        for (int i = 0; i < 3; i++)
+            bg_dot_dpixel += bg[i] * dL_dpixel[i];
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+        const float dL_dG = con_o[3] * dL_dalpha;
+        const float gdx = G * d_x;
+        const float gdy = G * d_y;
+        const float dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
+        const float dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
+
+        dL_dmean2D[(size_t)id * 3 + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+        dL_dmean2D[(size_t)id * 3 + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
+        const float abs_dL_dmean2D = fabsf(dL_dG * dG_ddelx * ddelx_dx) + fabsf(dL_dG * dG_ddely * ddely_dy);
+        dL_dmean2D[(size_t)id * 3 + 2] += (double)abs_dL_dmean2D;
+
+        dL_dopacity[id] += (double)(G * dL_dalpha);
+
+        const float dG_dpower = G;
+        const float dL_dpower = dL_dG * dG_dpower;
+        const float dL_dmin_value = dL_dpower * -0.5f;
+        double dL_dA = dL_dmin_value * (BB / AA) * (BB / AA) / 4.f;
+        double dL_dB = dL_dmin_value * -BB / (2 * AA);
+        double dL_dC = dL_dmin_value * 1.0f;
+
+        dL_dA += dL_dt * BB / (2 * AA * AA);
+        dL_dB += dL_dt * -1.f / (2 * AA);
+
+        dL_dnormal[0] += dL_dA * ray_x;
+        dL_dnormal[1] += dL_dA * ray_y;
+        dL_dnormal[2] += dL_dA;
+
+        double* g = dL_dv2g + (size_t)id * 10;
+        g[0] += (double)(float)(dL_dnormal[0] * ray_x);
+        g[1] += (double)(float)(dL_dnormal[0] * ray_y + dL_dnormal[1] * ray_x);
+        g[2] += (double)(float)(dL_dnormal[0] + dL_dnormal[2] * ray_x);
+        g[3] += (double)(float)(dL_dnormal[1] * ray_y);
+        g[4] += (double)(float)(dL_dnormal[1] + dL_dnormal[2] * ray_y);
+        g[5] += (double)(float)(dL_dnormal[2]);
+        g[6] += (double)(float)(dL_dB * 2 * ray_x);
+        g[7] += (double)(float)(dL_dB * 2 * ray_y);
+        g[8] += (double)(float)(dL_dB * 2);
+        g[9] += (double)(float)(dL_dC);
+    }
+}
+
+/* backward.cu:381-587: gradients of the 10 view2gaussian entries w.r.t. mean, scale and (un-normalised) quaternion */
+static void computeView2Gaussian_backward(const float* scale, const float* mean, const float* rot, const float* view,
+                                          const float* dL_dv2g, float* dL_dmean, float* dL_dscale, float* dL_drot)
+{
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    mat3 R = quat_to_R(rot);
+    mat4 G2W;
+    G2W.c[0][0] = R.c[0][0]; G2W.c[0][1] = R.c[1][0]; G2W.c[0][2] = R.c[2][0]; G2W.c[0][3] = 0.0f;
+    G2W.c[1][0] = R.c[0][1]; G2W.c[1][1] = R.c[1][1]; G2W.c[1][2] = R.c[2][1]; G2W.c[1][3] = 0.0f;
+    G2W.c[2][0] = R.c[0][2]; G2W.c[2][1] = R.c[1][2]; G2W.c[2][2] = R.c[2][2]; G2W.c[2][3] = 0.0f;
+    G2W.c[3][0] = mean[0];   G2W.c[3][1] = mean[1];   G2W.c[3][2] = mean[2];   G2W.c[3][3] = 1.0f;
+    mat4 W2V;
+    for (int cc = 0; cc < 4; cc++)
+        for (int q = 0; q < 4; q++)
+            W2V.c[cc][q] = view[4 * cc + q];
+    mat4 G2V = m4_mul(W2V, G2W);
+
+    mat3 Rt;
+    Rt.c[0][0] = G2V.c[0][0]; Rt.c[0][1] = G2V.c[1][0]; Rt.c[0][2] = G2V.c[2][0];
+    Rt.c[1][0] = G2V.c[0][1]; Rt.c[1][1] = G2V.c[1][1]; Rt.c[1][2] = G2V.c[2][1];
+    Rt.c[2][0] = G2V.c[0][2]; Rt.c[2][1] = G2V.c[1][2]; Rt.c[2][2] = G2V.c[2][2];
+    vec3 t = { G2V.c[3][0], G2V.c[3][1], G2V.c[3][2] };
+    mat3 negRt;
+    for (int cc = 0; cc < 3; cc++)
+        for (int q = 0; q < 3; q++)
+            negRt.c[cc][q] = -Rt.c[cc][q];
+    vec3 t2 = m3_mul_v(negRt, t);
+
+    double S[3] = { 1.0f / ((double)scale[0] * scale[0] + 1e-7), 1.0f / ((double)scale[1] * scale[1] + 1e-7),
+                    1.0f / ((double)scale[2] * scale[2] + 1e-7) };
+    mat3 SR;
+    for (int cc = 0; cc < 3; cc++)
+        for (int q = 0; q < 3; q++)
+            SR.c[cc][q] = (float)(S[q] * Rt.c[cc][q]);
+
+    mat3 dL_dSigma;
+    dL_dSigma.c[0][0] = dL_dv2g[0];        dL_dSigma.c[0][1] = 0.5f * dL_dv2g[1]; dL_dSigma.c[0][2] = 0.5f * dL_dv2g[2];
+    dL_dSigma.c[1][0] = 0.5f * dL_dv2g[1]; dL_dSigma.c[1][1] = dL_dv2g[3];        dL_dSigma.c[1][2] = 0.5f * dL_dv2g[4];
+    dL_dSigma.c[2][0] = 0.5f * dL_dv2g[2]; dL_dSigma.c[2][1] = 0.5f * dL_dv2g[4]; dL_dSigma.c[2][2] = dL_dv2g[5];
+    const float dB[3] = { dL_dv2g[6], dL_dv2g[7], dL_dv2g[8] };
+    const float dL_dC = dL_dv2g[9];
+    const float t2v[3] = { t2.x, t2.y, t2.z };
+
+    /* dL_dS_inv_square_R = R_transpose * dL_dSigma + outerProduct(t2, dL_dB); outerProduct(c, r)[i][j] = c[j] * r[i] */
+    mat3 D = m3_mul(Rt, dL_dSigma);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            D.c[i][j] = D.c[i][j] + t2v[j] * dB[i];
+    mat3 dL_dRt = m3_transpose(m3_mul(dL_dSigma, m3_transpose(SR)));
+    for (int cc = 0; cc < 3; cc++)
+        for (int q = 0; q < 3; q++)
+            dL_dRt.c[cc][q] = dL_dRt.c[cc][q] + (float)(S[q] * D.c[cc][q]);
+
+    float dL_dS[3];
+    for (int q = 0; q < 3; q++)
+        dL_dS[q] = D.c[0][q] * Rt.c[0][q] + D.c[1][q] * Rt.c[1][q] + D.c[2][q] * Rt.c[2][q];
+    float dL_dt2[3];
+    for (int q = 0; q < 3; q++)
+        dL_dt2[q] = (float)(2 * t2v[q] * S[q] * dL_dC + dB[0] * SR.c[0][q] + dB[1] * SR.c[1][q] + dB[2] * SR.c[2][q]);
+    for (int q = 0; q < 3; q++)
+        dL_dS[q] += dL_dC * t2v[q] * t2v[q];
+    for (int q = 0; q < 3; q++)
+        dL_dscale[q] = (float)(-2 / scale[q] * S[q] * dL_dS[q]);
+
+    /* G2V_R_t == Rt, G2V_t == t */
+    mat3 dL_dV2G_R_t = m3_transpose(dL_dRt);
+    mat3 from_t;
+    for (int cc = 0; cc < 3; cc++) {
+        from_t.c[cc][0] = -dL_dt2[cc] * t.x;
+        from_t.c[cc][1] = -dL_dt2[cc] * t.y;
+        from_t.c[cc][2] = -dL_dt2[cc] * t.z;
+    }
+    mat3 dL_dG2V_R;
+    for (int cc = 0; cc < 3; cc++)
+        for (int q = 0; q < 3; q++)
+            dL_dG2V_R.c[cc][q] = dL_dV2G_R_t.c[cc][q] + from_t.c[cc][q];
+    vec3 ndt = { -dL_dt2[0], -dL_dt2[1], -dL_dt2[2] };
+    vec3 dL_dG2V_t = v_mul_m3(ndt, Rt);
+
+    mat4 dL_dG2V;
+    for (int cc = 0; cc < 3; cc++) {
+        dL_dG2V.c[cc][0] = dL_dG2V_R.c[cc][0]; dL_dG2V.c[cc][1] = dL_dG2V_R.c[cc][1];
+        dL_dG2V.c[cc][2] = dL_dG2V_R.c[cc][2]; dL_dG2V.c[cc][3] = 0.0f;
+    }
+    dL_dG2V.c[3][0] = dL_dG2V_t.x; dL_dG2V.c[3][1] = dL_dG2V_t.y; dL_dG2V.c[3][2] = dL_dG2V_t.z; dL_dG2V.c[3][3] = 0.0f;
+    mat4 W2Vt;
+    for (int cc = 0; cc < 4; cc++)
+        for (int q = 0; q < 4; q++)
+            W2Vt.c[cc][q] = W2V.c[q][cc];
+    mat4 dL_dG2W = m4_mul(W2Vt, dL_dG2V);
+
+    dL_dmean[0] = dL_dG2W.c[3][0];
+    dL_dmean[1] = dL_dG2W.c[3][1];
+    dL_dmean[2] = dL_dG2W.c[3][2];
+
+    float Mt[3][3];
+    for (int cc = 0; cc < 3; cc++)
+        for (int q = 0; q < 3; q++)
+            Mt[cc][q] = dL_dG2W.c[cc][q];
+    dL_drot[0] = 2 * z * (Mt[0][1] - Mt[1][0]) + 2 * y * (Mt[2][0] - Mt[0][2]) + 2 * x * (Mt[1][2] - Mt[2][1]);
+    dL_drot[1] = 2 * y * (Mt[1][0] + Mt[0][1]) + 2 * z * (Mt[2][0] + Mt[0][2]) + 2 * r * (Mt[1][2] - Mt[2][1]) - 4 * x * (Mt[2][2] + Mt[1][1]);
+    dL_drot[2] = 2 * x * (Mt[1][0] + Mt[0][1]) + 2 * r * (Mt[2][0] - Mt[0][2]) + 2 * z * (Mt[1][2] + Mt[2][1]) - 4 * y * (Mt[2][2] + Mt[0][0]);
+    dL_drot[3] = 2 * r * (Mt[0][1] - Mt[1][0]) + 2 * x * (Mt[2][0] + Mt[0][2]) + 2 * y * (Mt[1][2] + Mt[2][1]) - 4 * z * (Mt[1][1] + Mt[0][0]);
+}
+
+/* backward.cu:20-139 */
+static void computeColorFromSH_backward(int idx, int deg, int max_coeffs, const float* means, const float* campos,
+                                        const float* shs, const uint8_t* clamped, const float* dL_dcolor,
+                                        float* dL_dmeans, float* dL_dshs)
+{
+    const float dir_orig[3] = { means[3 * idx] - campos[0], means[3 * idx + 1] - campos[1], means[3 * idx + 2] - campos[2] };
+    float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
+    const float x = dir_orig[0] / len, y = dir_orig[1] / len, z = dir_orig[2] / len;
+    const float* sh = shs + (size_t)idx * max_coeffs * 3;
+    float dL_dRGB[3];
+    for (int ch = 0; ch < 3; ch++)
+        dL_dRGB[ch] = dL_dcolor[3 * (size_t)idx + ch] * (clamped[3 * idx + ch] ? 0 : 1);
+    float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+    float* dL_dsh = dL_dshs + (size_t)idx * max_coeffs * 3;
+#define SH(k, ch) sh[(k) * 3 + (ch)]
+#define DSH(k, val) do { float _w = (val); for (int ch = 0; ch < 3; ch++) dL_dsh[(k) * 3 + ch] = _w * dL_dRGB[ch]; } while (0)
+    DSH(0, SH_C0);
+    if (deg > 0) {
+        DSH(1, -SH_C1 * y);
+        DSH(2, SH_C1 * z);
+        DSH(3, -SH_C1 * x);
+        for (int ch = 0; ch < 3; ch++) {
+            dRGBdx[ch] = -SH_C1 * SH(3, ch);
+            dRGBdy[ch] = -SH_C1 * SH(1, ch);
+            dRGBdz[ch] = SH_C1 * SH(2, ch);
+        }
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float xy = x * y, yz = y * z, xz = x * z;
+            DSH(4, SH_C2[0] * xy);
+            DSH(5, SH_C2[1] * yz);
+            DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+            DSH(7, SH_C2[3] * xz);
+            DSH(8, SH_C2[4] * (xx - yy));
+            for (int ch = 0; ch < 3; ch++) {
+                dRGBdx[ch] += SH_C2[0] * y * SH(4, ch) + SH_C2[2] * 2.f * -x * SH(6, ch) + SH_C2[3] * z * SH(7, ch) + SH_C2[4] * 2.f * x * SH(8, ch);
+                dRGBdy[ch] += SH_C2[0] * x * SH(4, ch) + SH_C2[1] * z * SH(5, ch) + SH_C2[2] * 2.f * -y * SH(6, ch) + SH_C2[4] * 2.f * -y * SH(8, ch);
+                dRGBdz[ch] += SH_C2[1] * y * SH(5, ch) + SH_C2[2] * 2.f * 2.f * z * SH(6, ch) + SH_C2[3] * x * SH(7, ch);
+            }
+            if (deg > 2) {
+                DSH(9, SH_C3[0] * y * (3.f * xx - yy));
+                DSH(10, SH_C3[1] * xy * z);
+                DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
+                DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
+                DSH(14, SH_C3[5] * z * (xx - yy));
+                DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] += (
+                        SH_C3[0] * SH(9, ch) * 3.f * 2.f * xy +
+                        SH_C3[1] * SH(10, ch) * yz +
+                        SH_C3[2] * SH(11, ch) * -2.f * xy +
+                        SH_C3[3] * SH(12, ch) * -3.f * 2.f * xz +
+                        SH_C3[4] * SH(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                        SH_C3[5] * SH(14, ch) * 2.f * xz +
+                        SH_C3[6] * SH(15, ch) * 3.f * (xx - yy));
+                    dRGBdy[ch] += (
+                        SH_C3[0] * SH(9, ch) * 3.f * (xx - yy) +
+                        SH_C3[1] * SH(10, ch) * xz +
+                        SH_C3[2] * SH(11, ch) * (-3.f * yy + 4.f * zz - xx) +
+                        SH_C3[3] * SH(12, ch) * -3.f * 2.f * yz +
+                        SH_C3[4] * SH(13, ch) * -2.f * xy +
+                        SH_C3[5] * SH(14, ch) * -2.f * yz +
+                        SH_C3[6] * SH(15, ch) * -3.f * 2.f * xy);
+                    dRGBdz[ch] += (
+                        SH_C3[1] * SH(10, ch) * xy +
+                        SH_C3[2] * SH(11, ch) * 4.f * 2.f * yz +
+                        SH_C3[3] * SH(12, ch) * 3.f * (2.f * zz - xx - yy) +
+                        SH_C3[4] * SH(13, ch) * 4.f * 2.f * xz +
+                        SH_C3[5] * SH(14, ch) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    float dL_ddir[3] = {
+        dRGBdx[0] * dL_dRGB[0] + dRGBdx[1] * dL_dRGB[1] + dRGBdx[2] * dL_dRGB[2],
+        dRGBdy[0] * dL_dRGB[0] + dRGBdy[1] * dL_dRGB[1] + dRGBdy[2] * dL_dRGB[2],
+        dRGBdz[0] * dL_dRGB[0] + dRGBdz[1] * dL_dRGB[1] + dRGBdz[2] * dL_dRGB[2]
+    };
+    float dm[3];
+    dnormvdv3(dir_orig, dL_ddir, dm);
+    dL_dmeans[3 * (size_t)idx + 0] += dm[0];
+    dL_dmeans[3 * (size_t)idx + 1] += dm[1];
+    dL_dmeans[3 * (size_t)idx + 2] += dm[2];
+}
+
+/* rasterizer_impl.cu:409-526 after a gof_oracle_forward on the same context. All outputs must be zero-filled by
+ * the caller; dL_dcov3D [P,6] and dL_dconic [P,4] are never written (their kernels are dead code in the reference,
+ * backward.cu:992-1007, :627-630). */
+void gof_oracle_backward(gof_ctx* c, const float* background, const float* means3D, const float* shs,
+                         const float* scales, const float* rotations, const float* viewmatrix, const float* cam_pos,
+                         const int* radii, const float* dL_dpix,
+                         float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dsh,
+                         float* dL_dscale, float* dL_drot, float* dL_dview2gaussian)
+{
+    const int P = c->P, ntiles = c->gx * c->gy;
+    size_t Pn = P > 0 ? (size_t)P : 1;
+    double* a_m2 = calloc(Pn * 3, sizeof(double));
+    double* a_op = calloc(Pn, sizeof(double));
+    double* a_col = calloc(Pn * 3, sizeof(double));
+    double* a_v2g = calloc(Pn * 10, sizeof(double));
+    if (radii == NULL) radii = c->radii;
+
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int tx = tile % c->gx, ty = tile / c->gx;
+        const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                uint32_t px = (uint32_t)(tx * BLOCK_X + lx), py = (uint32_t)(ty * BLOCK_Y + ly);
+                if (px < (uint32_t)c->W && py < (uint32_t)c->H)
+                    render_pixel_backward(c, px, py, c->point_list + r0, (int)(r1 - r0), background, dL_dpix,
+                                          a_m2, a_op, a_col, a_v2g);
+            }
+    }
+    for (size_t i = 0; i < (size_t)P * 3; i++) { dL_dmean2D[i] = (float)a_m2[i]; dL_dcolor[i] = (float)a_col[i]; }
+    for (size_t i = 0; i < (size_t)P; i++) dL_dopacity[i] = (float)a_op[i];
+    for (size_t i = 0; i < (size_t)P * 10; i++) dL_dview2gaussian[i] = (float)a_v2g[i];
+    free(a_m2); free(a_op); free(a_col); free(a_v2g);
+
+    /* backward.cu:593-631 */
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0))
+            continue;
+        computeView2Gaussian_backward(scales + 3 * (size_t)idx, means3D + 3 * (size_t)idx, rotations + 4 * (size_t)idx,
+                                      viewmatrix, dL_dview2gaussian + 10 * (size_t)idx, dL_dmean3D + 3 * (size_t)idx,
+                                      dL_dscale + 3 * (size_t)idx, dL_drot + 4 * (size_t)idx);
+        if (shs)
+            computeColorFromSH_backward(idx, c->D, c->M, means3D, cam_pos, shs, c->clamped, dL_dcolor, dL_dmean3D, dL_dsh);
+    }
+}

@@ -1,0 +1,121 @@
+"""GPU parity of the backward pass (f3dg_backward through the C ABI, and through torch autograd) against the CPU oracle.
+
+Tolerances follow SURVEY section 8c: compositing-stage gradients (view2gaussian, opacity, colours, sh, mean2D) within
+1e-5 of the maximum; dmean3D / drot / dscale are cancellation-dominated in float32 -- the reference's own run-to-run
+spread is 3e-4 / 2e-2 / 0.4 -- so they are asserted as "error against the fp64 chain-rule truth no worse than the
+oracle's own error" (this build accumulates dL/dview2gaussian in float64, so it is typically equal or better)."""
+import numpy as np
+import pytest
+import torch
+
+import f3dgaus_amd as f3d
+from f3dgaus_amd.diff_gof_rasterization.backward import rasterize_backward_raw
+from grad_truth import per_gaussian_truth
+from helpers import make_scene, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_fwd_bwd(scene, dpix, device):
+    dev = lambda t: None if t is None else t.to(device)
+    out, radii, ws = f3d.rasterize_views(
+        dev(scene["means3D"]), dev(scene["opacities"]), dev(scene["viewmatrix"]), dev(scene["projmatrix"]),
+        dev(scene["campos"]), dev(scene["bg"]), image_height=scene["H"], image_width=scene["W"],
+        tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], sh=dev(scene["shs"]),
+        colors_precomp=dev(scene["colors_precomp"]), scales=dev(scene["scales"]), rotations=dev(scene["rotations"]),
+        sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"], kernel_size=scene["kernel_size"], save_aux=True)
+    g = rasterize_backward_raw(ws, dev(scene["means3D"]), dev(scene["shs"]), dev(scene["colors_precomp"]),
+                               dev(scene["scales"]), dev(scene["rotations"]), radii, torch.from_numpy(dpix).to(device),
+                               scene["sh_degree"], dev(scene["viewmatrix"]), dev(scene["projmatrix"]), dev(scene["campos"]),
+                               dev(scene["bg"]), scene["tanfovx"], scene["tanfovy"], scene["kernel_size"], scene["scale_modifier"])
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in g.items()}, radii.cpu().numpy()
+
+
+def _rel(a, b):
+    m = np.abs(b).max()
+    return 0.0 if m == 0 else float(np.abs(a.astype(np.float64) - b).max() / m)
+
+
+CASES = {
+    "B1_identity_rgb_ones": (dict(P=2000, res=(64, 64), s0=0.05, view="canonical"), "rgb_ones"),
+    "B1_identity_random": (dict(P=2000, res=(64, 64), s0=0.05, view="canonical"), "random"),
+    "B2_oblique_aniso_random": (dict(P=5000, res=(128, 128), s0=0.02, view="oblique", aniso=True, behind_fraction=0.05, bg=(0.3, 0.1, 0.6)), "random"),
+    "B3_filter_scalemod_random": (dict(P=3000, res=(96, 96), s0=0.05, view="oblique", kernel_size=0.1, scale_modifier=0.5), "random"),
+    "B4_colors_precomp": (dict(P=2500, res=(100, 72), s0=0.05, view="oblique", colors_precomp=True), "random"),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_backward_vs_oracle(name, gpu_device):
+    kw, mode = CASES[name]
+    scene = make_scene(**kw)
+    H, W = scene["H"], scene["W"]
+    if mode == "rgb_ones":
+        dpix = np.zeros((9, H, W), np.float32)
+        dpix[:3] = 1.0
+    else:
+        dpix = np.random.default_rng(5).standard_normal((9, H, W)).astype(np.float32)
+    o = run_oracle(scene)
+    go = o["oracle"].backward(dpix)
+    gh, radii = _hip_fwd_bwd(scene, dpix[None], gpu_device)
+    assert np.array_equal(radii[0], o["radii"])
+
+    assert not gh["dL_dconic"].any() and not gh["dL_dcov3D"].any()
+    culled = o["radii"] == 0
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity"):
+        assert not gh[k][culled].any(), k
+    # compositing stage + sh: tight
+    assert _rel(gh["dL_dview2gaussian"][0], go["dL_dview2gaussian"]) <= 1e-5, name
+    assert _rel(gh["dL_dopacity"], go["dL_dopacity"]) <= 1e-5
+    assert _rel(gh["dL_dcolors"][0], go["dL_dcolor"]) <= 1e-5
+    assert _rel(gh["dL_dmeans2D"][0], go["dL_dmean2D"]) <= 2e-5
+    if scene["shs"] is not None:
+        assert _rel(gh["dL_dsh"], go["dL_dsh"]) <= 1e-5
+    # per-Gaussian stage: no worse than the oracle against the fp64 truth
+    truth = per_gaussian_truth(scene, 0, o["radii"], go["dL_dview2gaussian"], go["dL_dcolor"])
+    # floor = the reference's own run-to-run spread for that gradient (3e-4 / 2e-2 / 0.4 of the maximum)
+    for hk, ok, floor in (("dL_dmeans3D", "dL_dmean3D", 3e-4), ("dL_drotations", "dL_drot", 2e-2), ("dL_dscales", "dL_dscale", 0.4)):
+        e_h, e_o = _rel(gh[hk], truth[ok]), _rel(go[ok], truth[ok])
+        print(f"{name} {hk}: hip-vs-fp64 {e_h:.2e}  oracle-vs-fp64 {e_o:.2e}")
+        assert e_h <= max(2.0 * e_o, floor), (name, hk, e_h, e_o)
+
+
+def test_autograd_function_matches_raw_backward(gpu_device):
+    scene = make_scene(P=3000, res=(64, 64), s0=0.05, view="oblique")
+    dev = lambda t: t.to(gpu_device)
+    leaf = {k: dev(scene[k]).clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+    means2D = torch.zeros_like(leaf["means3D"], requires_grad=True)
+    rs = f3d.GaussianRasterizationSettings_GOF(64, 64, scene["tanfovx"], scene["tanfovy"], 0.0, torch.zeros(0), dev(scene["bg"]), 1.0,
+                                               dev(scene["viewmatrix"][0]), dev(scene["projmatrix"][0]), 1, dev(scene["campos"][0]), False, False)
+    color, radii = f3d.GaussianRasterizer_GOF(rs)(means3D=leaf["means3D"], means2D=means2D, shs=leaf["shs"],
+                                                 opacities=leaf["opacities"], scales=leaf["scales"], rotations=leaf["rotations"])
+    assert color.shape == (9, 64, 64) and radii.dtype == torch.int32 and not radii.requires_grad
+    w = torch.from_numpy(np.random.default_rng(2).standard_normal((9, 64, 64)).astype(np.float32)).to(gpu_device)
+    (color * w).sum().backward()
+    gh, _ = _hip_fwd_bwd(scene, w.cpu().numpy()[None], gpu_device)
+    assert _rel(leaf["opacities"].grad.cpu().numpy(), gh["dL_dopacity"]) <= 1e-5
+    assert _rel(means2D.grad.cpu().numpy(), gh["dL_dmeans2D"][0]) <= 1e-5
+    assert _rel(leaf["shs"].grad.cpu().numpy(), gh["dL_dsh"]) <= 1e-5
+    for k, hk in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations")):
+        assert leaf[k].grad is not None and leaf[k].grad.shape == leaf[k].shape
+        assert _rel(leaf[k].grad.cpu().numpy(), gh[hk]) <= 1e-3, k      # float32 atomics order on dcolor feeds the SH->mean path
+
+
+def test_multi_view_backward_sums_single_view_backwards(gpu_device):
+    scene = make_scene(P=2500, res=(64, 64), s0=0.05, view=[1, 4, 7])
+    V = 3
+    dpix = np.random.default_rng(9).standard_normal((V, 9, 64, 64)).astype(np.float32)
+    gb, _ = _hip_fwd_bwd(scene, dpix, gpu_device)
+    acc = None
+    for v in range(V):
+        sv = dict(scene)
+        for k in ("viewmatrix", "projmatrix", "campos"):
+            sv[k] = scene[k][v:v + 1]
+        g1, _ = _hip_fwd_bwd(sv, dpix[v:v + 1], gpu_device)
+        assert _rel(gb["dL_dview2gaussian"][v], g1["dL_dview2gaussian"][0]) <= 1e-6
+        assert _rel(gb["dL_dcolors"][v], g1["dL_dcolors"][0]) <= 1e-5
+        assert _rel(gb["dL_dmeans2D"][v], g1["dL_dmeans2D"][0]) <= 1e-5
+        acc = {k: g1[k].astype(np.float64) for k in g1} if acc is None else {k: acc[k] + g1[k] for k in g1}
+    for k in ("dL_dopacity", "dL_dsh", "dL_dmeans3D"):
+        assert _rel(gb[k], acc[k]) <= 1e-4, k
