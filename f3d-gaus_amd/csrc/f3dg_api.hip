@@ -60,6 +60,18 @@ inline void prof_mark(ProfCall* c, int stage_done, hipStream_t s) { if (c) (void
 
 } // namespace
 
+int g_f3dg_render_pretest = 1;
+int g_f3dg_render_cull = 1;
+int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
+
+extern "C" int f3dg_set_option(const char* name, int value)
+{
+    if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
+    return F3DG_ERR_BAD_ARG;
+}
+
 extern "C" int f3dg_profile_enable(int on)
 {
     g_prof.enabled = on != 0;
@@ -115,6 +127,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.header = take(sizeof(F3dgHeader));
     L.rec = take(VP * sizeof(F3dgRec));
     L.means2D = take(VP * sizeof(float2));
+    L.bbox = take(VP * sizeof(float4));
     L.conic = take(VP * sizeof(float4));
     L.radii = take(VP * sizeof(int));
     L.tiles = take(VP * sizeof(unsigned));
@@ -187,6 +200,7 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
                                     reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
+                                    reinterpret_cast<float4*>(ws + L.bbox),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
                                     reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
@@ -200,7 +214,8 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
     rc = f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
                               reinterpret_cast<const uint2*>(ws + L.ranges),
                               reinterpret_cast<const unsigned*>(ws + L.vals[0]),
-                              reinterpret_cast<const F3dgRec*>(ws + L.rec), background,
+                              reinterpret_cast<const F3dgRec*>(ws + L.rec),
+                              reinterpret_cast<const float4*>(ws + L.bbox), background,
                               (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color,
                               reinterpret_cast<float*>(ws + L.final_T),
                               reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux);

@@ -164,7 +164,7 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 const float dchannel_dcolor = alpha * Tr;
 
                 float dL_dalpha = 0.0f;
-                const float c0 = q2.w, c1 = q3.x, c2 = q3.y;
+                const float c0 = q3.x, c1 = q3.y, c2 = q3.z;
                 accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0; last_c0 = c0;
                 dL_dalpha += (c0 - accum_rec0) * dpx0; g_col0 = dchannel_dcolor * dpx0;
                 accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1; last_c1 = c1;

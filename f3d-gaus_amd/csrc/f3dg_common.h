@@ -28,11 +28,12 @@ struct F3dgHeader {
 };
 
 // Per-(view, Gaussian) record consumed by the compositing kernel: one 64-byte line.
-//   f[0..9]  view2gaussian (Sigma' upper triangle, B, C)      forward.cu:268-277
-//   f[10]    opacity * coef (conic_opacity.w)                  forward.cu:392
-//   f[11..13] rgb                                              forward.cu:379-384
-//   f[14]    view-space depth                                  forward.cu:388
-//   f[15]    unused
+//   f[0..9]   view2gaussian (Sigma' upper triangle, B, C)     forward.cu:268-277
+//   f[10]     opacity * coef (conic_opacity.w)                 forward.cu:392
+//   f[11]     power threshold: alpha < 1/255 is CERTAIN when the exponent is below it (see f3dg_render.hip)
+//   f[12..14] rgb                                              forward.cu:379-384
+//   f[15]     view-space depth                                 forward.cu:388
+// The first three float4 are everything the conservative pre-test needs; the 4th is only read by contributors.
 struct __attribute__((aligned(16))) F3dgRec { float f[F3DG_REC_FLOATS]; };
 
 // Host-side description of where each array lives inside the workspace (byte offsets).
@@ -40,6 +41,7 @@ struct F3dgLayout {
     size_t header;
     size_t rec;            // [V*P] F3dgRec
     size_t means2D;        // [V*P] float2
+    size_t bbox;           // [V*P] float4: conservative pixel-space box (x0,x1,y0,y1) outside of which alpha < 1/255 is certain
     size_t conic;          // [V*P] float4 (conic.xyz, opacity*coef) -- backward only
     size_t radii;          // [V*P] int   (internal copy when the caller passes none)
     size_t tiles;          // [V*P] u32   tiles_touched
@@ -75,7 +77,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float4* conic, int* radii, unsigned* tiles,
+                           F3dgRec* rec, float2* means2D, float4* bbox, float4* conic, int* radii, unsigned* tiles,
                            unsigned char* clamped, int save_aux);
 
 int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out, unsigned long long n,
@@ -84,7 +86,10 @@ int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out,
 
 int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii);
 
+extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test enabled; 0: plain path (A/B, tests)
+extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
+
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
-                       const float* background, int bg_per_view, float* out_color, float* final_T,
+                       const float4* bbox, const float* background, int bg_per_view, float* out_color, float* final_T,
                        unsigned* n_contrib, int save_aux);

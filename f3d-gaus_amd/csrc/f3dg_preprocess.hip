@@ -10,6 +10,8 @@
 // The arithmetic keeps the reference's float/double operation order (file is built with -ffp-contract=off).
 #include "f3dg_common.h"
 
+extern int g_f3dg_debug_skip_all;
+
 namespace {
 
 __device__ __constant__ float SH_C0 = 0.28209479177387814f;
@@ -58,6 +60,48 @@ __device__ __forceinline__ M3 quat_to_R(float4 q)
 
 __device__ __forceinline__ float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
+// Conservative pixel-space box of the region where this Gaussian's alpha can reach 1/255 in the compositing kernel.
+//   alpha >= 1/255  =>  p = -(C - b^2/a)/2 >= thr  <=>  (C - k) a - b^2 <= 0, k = -2 thr, a = r^T Sigma' r, b = B^T r, r = (x, y, 1):
+// a conic in ray space with matrix M = (C - k) Sigma' - B B^T; its axis-aligned extent follows from the dual conic adj(M).
+// k is widened by a worst-case bound on the float32 evaluation error of the reference's own a and b:
+//   |da| <= 6 eps |r|^2 tr(Sigma'),  a >= S_min |r|^2 (S_min = min_i 1/(s_i^2 + 1e-7))  =>  da/a <= 6 eps tr(Sigma')/S_min;
+//   |db| <= 3 eps |B||r| with |B||r|/|b| <~ S_max/S_min near the splat                 =>  db/b <= 3 eps tr(Sigma')/S_min;
+//   dp = q (da/a + 2 db/b)/2 <= 6 eps C tr(Sigma')/S_min; 8 is used. Everything is done in float64, and the box is
+// inflated by 0.1 % + 0.25 px. Anything degenerate (camera inside the level set, non-finite,
+// ill-conditioned, precomputed view2gaussian without scales) returns the "everything" box, i.e. no culling.
+__device__ __forceinline__ float4 conservative_box(const float* vg, float thr, float3 scale, bool have_scale, int W, int H,
+                                                   float focal_x, float focal_y)
+{
+    const float4 all = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);
+    if (!have_scale || !(thr < 3.0e38f)) return all;        // thr = +inf (alpha always < 1/255) is handled by the pre-test
+    const double C = vg[9];
+    const double eps = 5.9604644775390625e-08;
+    const double Sx = 1.0 / ((double)scale.x * scale.x + 1e-7), Sy = 1.0 / ((double)scale.y * scale.y + 1e-7),
+                 Sz = 1.0 / ((double)scale.z * scale.z + 1e-7);
+    const double Smin = fmin(Sx, fmin(Sy, Sz));
+    const double trS = (double)vg[0] + (double)vg[3] + (double)vg[5];
+    const double dp = fabs(C) * eps * 8.0 * fabs(trS) / Smin + 1e-3;
+    const double k = -2.0 * (double)thr + 2.0 * dp;
+    const double cK = C - k;
+    if (!(cK > 0.0)) return all;
+    const double B0 = vg[6], B1 = vg[7], B2 = vg[8];
+    const double m00 = cK * vg[0] - B0 * B0, m01 = cK * vg[1] - B0 * B1, m02 = cK * vg[2] - B0 * B2;
+    const double m11 = cK * vg[3] - B1 * B1, m12 = cK * vg[4] - B1 * B2, m22 = cK * vg[5] - B2 * B2;
+    const double D00 = m11 * m22 - m12 * m12, D11 = m00 * m22 - m02 * m02, D22 = m00 * m11 - m01 * m01;
+    const double D02 = m01 * m12 - m02 * m11, D12 = m01 * m02 - m00 * m12;
+    if (!(m00 > 0.0) || !(D22 > 1e-9 * fabs(m00 * m11))) return all;
+    const double dx = D02 * D02 - D00 * D22, dy = D12 * D12 - D11 * D22;
+    if (!(dx >= 0.0) || !(dy >= 0.0)) return all;
+    const double cx = D02 / D22, cy = D12 / D22;
+    const double hx = sqrt(dx) / D22 * 1.001 + 0.25 / focal_x, hy = sqrt(dy) / D22 * 1.001 + 0.25 / focal_y;
+    const double x0 = (cx - hx) * focal_x + W / 2. - 0.5, x1 = (cx + hx) * focal_x + W / 2. - 0.5;
+    const double y0 = (cy - hy) * focal_y + H / 2. - 0.5, y1 = (cy + hy) * focal_y + H / 2. - 0.5;
+    if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) return all;
+    // round outwards when narrowing to float
+    return make_float4((float)x0 - 1e-3f * (1.0f + fabsf((float)x0)), (float)x1 + 1e-3f * (1.0f + fabsf((float)x1)),
+                       (float)y0 - 1e-3f * (1.0f + fabsf((float)y0)), (float)y1 + 1e-3f * (1.0f + fabsf((float)y1)));
+}
+
 __global__ void __launch_bounds__(F3DG_BLOCK)
 preprocess_kernel(int P, int D, int M,
                   const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
@@ -67,9 +111,10 @@ preprocess_kernel(int P, int D, int M,
                   const float* __restrict__ viewmatrices, const float* __restrict__ projmatrices,
                   const float* __restrict__ cam_positions, int W, int H, int grid_x, int grid_y,
                   float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                  F3dgRec* __restrict__ rec, float2* __restrict__ means2D, float4* __restrict__ conic_out,
+                  F3dgRec* __restrict__ rec, float2* __restrict__ means2D, float4* __restrict__ bbox_out,
+                  float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
-                  unsigned char* __restrict__ clamped, int save_aux)
+                  unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all)
 {
     const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
@@ -84,6 +129,7 @@ preprocess_kernel(int P, int D, int M,
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;   // the 64-byte record
     float2 xy = make_float2(0, 0);
     float4 con = make_float4(0, 0, 0, 0);
+    float4 box = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);     // "everything" unless proven smaller
     unsigned char clamp_bits = 0;
 
     const float px_ = means3D[3 * (size_t)g], py_ = means3D[3 * (size_t)g + 1], pz_ = means3D[3 * (size_t)g + 2];
@@ -284,8 +330,14 @@ preprocess_kernel(int P, int D, int M,
                 con = make_float4(conic_x, conic_y, conic_z, opac);
                 r0 = make_float4(vg[0], vg[1], vg[2], vg[3]);
                 r1 = make_float4(vg[4], vg[5], vg[6], vg[7]);
-                r2 = make_float4(vg[8], vg[9], opac, cr);
-                r3 = make_float4(cg, cb, pvz, 0.0f);
+                // exponent threshold of the compositing pre-test: alpha = min(.99, opac*exp(power)) < 1/255 whenever
+                // power < log(1/(255*opac)); 1e-4 of slack covers logf/expf ulps and the final float rounding of power.
+                // opac <= 0 (or NaN) -> +inf / NaN: +inf skips everything (alpha <= 0 < 1/255 for any power <= 0),
+                // NaN disables the pre-test for this Gaussian.
+                const float thr = debug_skip_all ? __builtin_inff() : opac > 0.0f ? logf(1.0f / (255.0f * opac)) - 1e-4f : (opac <= 0.0f ? __builtin_inff() : opac);
+                box = conservative_box(vg, thr, scale, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y);
+                r2 = make_float4(vg[8], vg[9], opac, thr);
+                r3 = make_float4(cr, cg, cb, pvz);
             }
         }
     }
@@ -293,6 +345,7 @@ preprocess_kernel(int P, int D, int M,
     radii[idx] = my_radii;
     tiles_touched[idx] = my_tiles;
     means2D[idx] = xy;
+    bbox_out[idx] = box;
     float4* dst = reinterpret_cast<float4*>(rec + idx);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
     if (save_aux) {
@@ -318,7 +371,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float4* conic, int* radii, unsigned* tiles,
+                           F3dgRec* rec, float2* means2D, float4* bbox, float4* conic, int* radii, unsigned* tiles,
                            unsigned char* clamped, int save_aux)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
@@ -326,7 +379,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
-                       conic, radii, tiles, clamped, save_aux);
+                       bbox, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

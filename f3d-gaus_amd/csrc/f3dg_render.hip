@@ -13,17 +13,35 @@
 // -(1/2)(C - B^2/4A) cancels 1e5..1e6 x and any re-association moves isolated pixels by 1e-2.
 //
 // Only `done`-voting and staging are cooperative; there is no inter-pixel arithmetic, hence no MFMA.
+//
+// ALU diet that does not change results (the kernel is VALU-bound, ~200 pixel tests per 72-byte instance):
+//  * conservative pre-test. Only ~5 % of (pixel, Gaussian) tests end in a blend; the rest leave through
+//    `alpha < 1/255` (or `t <= 0.2`), both of which are a bare `continue`. A float32 estimate of the exponent,
+//    p32 = -(C - b^2/a)/2 with b = BB/2, a = AA, differs from the reference's float64 evaluation of the same float
+//    inputs by at most ~3 ulp of q = b^2/a (one product rounding, a 1-ulp v_rcp_f32, one more product rounding;
+//    the subtraction and the halving are exact or harmless), i.e. |p32 - p| <= 1e-7*|q|. The record carries
+//    thr = log(1/(255*opacity)) - 1e-4, so  p32 + 4e-7*|q| + 1e-5 < thr  PROVES alpha < 1/255 and the pair is
+//    skipped before any float64 instruction, expf or divide. NaN/inf fall through to the exact path. The tests run
+//    every scene with the pre-test on and off and require bit-identical outputs.
+//  * per-strip culling. A tile's list holds every Gaussian whose 3-sigma SQUARE touches the 16x16 tile, but a wave
+//    owns a 16x4 strip and only ~1/3 of the (strip, Gaussian) pairs contain a pixel with alpha >= 1/255. The staging
+//    thread therefore also fetches the Gaussian's conservative alpha >= 1/255 box (f3dg_preprocess.hip) and publishes
+//    a 4-bit strip mask; each wave compacts the 256 staged entries to its own index list with ballots and walks only
+//    those. Skipped entries would have been a bare `continue` for all 64 lanes, and `contributor` is set from the
+//    entry's position, so every output and auxiliary plane is bit-identical (asserted with the option on and off).
+//  * t = -BB/(2*AA) is a double quotient of float-valued operands rounded to float: identical to ONE IEEE float32
+//    divide (double rounding is innocuous for p = 24, q = 53 >= 2p + 2), so the float64 divide is not needed.
 #include "f3dg_common.h"
 
 namespace {
 
-template <bool SAVE_AUX>
+template <bool SAVE_AUX, bool PRETEST, bool CULL>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
-                  const float* __restrict__ background, int bg_per_view, float* __restrict__ out_color,
-                  float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+                  const float4* __restrict__ bbox, const float* __restrict__ background, int bg_per_view,
+                  float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
 {
     // XCD-aware placement: consecutive workgroup ids land on different XCDs (id % 8), so give every XCD its
     // own views: all tiles of a view then share one XCD's L2 for the record gather.
@@ -50,8 +68,13 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     int toDo = (int)(range.y - range.x);
 
     __shared__ float4 staged[F3DG_BLOCK * 4];     // 256 records x 64 B = 16 KiB
+    __shared__ unsigned char strip_mask[CULL ? F3DG_BLOCK : 1];
+    __shared__ unsigned short wave_list[CULL ? F3DG_BLOCK / 64 : 1][CULL ? F3DG_BLOCK : 1];
 
     const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vbox = bbox + (size_t)view * P;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const float tile_px0 = (float)(tile_x * F3DG_TILE), tile_py0 = (float)(tile_y * F3DG_TILE);
 
     bool done = !inside;
     float Tr = 1.0f;
@@ -73,25 +96,66 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             staged[threadIdx.x * 4 + 1] = b;
             staged[threadIdx.x * 4 + 2] = c;
             staged[threadIdx.x * 4 + 3] = d;
+            if (CULL) {
+                const float4 bx = vbox[id];                       // (x0, x1, y0, y1) in pixel coordinates
+                unsigned m = 0;
+                if (bx.x <= tile_px0 + 15.0f && bx.y >= tile_px0) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; sidx++)
+                        if (bx.z <= tile_py0 + (float)(4 * sidx + 3) && bx.w >= tile_py0 + (float)(4 * sidx)) m |= 1u << sidx;
+                }
+                strip_mask[threadIdx.x] = (unsigned char)m;
+            }
+        } else if (CULL) {
+            strip_mask[threadIdx.x] = 0;
         }
         __syncthreads();
 
         const int n = min(F3DG_BLOCK, toDo);
-        for (int j = 0; !done && j < n; j++) {
-            contributor++;
+        int count = n;
+        if (CULL) {
+            // this wave's compacted list of staged entries whose box touches its strip (order preserved)
+            count = 0;
+#pragma unroll
+            for (int c = 0; c < F3DG_BLOCK / 64; c++) {
+                const unsigned e = c * 64 + lane;
+                const bool bit = (strip_mask[e] >> wave) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                if (bit) wave_list[wave][count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+                count += __popcll(bal);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const unsigned round_base = (unsigned)i * F3DG_BLOCK;
+        for (int kk = 0; !done && kk < count; kk++) {
+            const int j = CULL ? (int)wave_list[wave][kk] : kk;
+            contributor = round_base + (unsigned)j + 1u;
             const float4 q0 = staged[j * 4 + 0];      // v0 v1 v2 v3
             const float4 q1 = staged[j * 4 + 1];      // v4 v5 v6 v7
-            const float4 q2 = staged[j * 4 + 2];      // v8 v9 opac r
+            const float4 q2 = staged[j * 4 + 2];      // v8 v9 opac thr
 
             const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
             const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
 
-            const double AA = ray_x * n0 + ray_y * n1 + n2;
-            const double BB = 2 * (q1.z * ray_x + q1.w * ray_y + q2.x);
+            const float aaf = ray_x * n0 + ray_y * n1 + n2;
+            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
             const float CC = q2.y;
 
-            const float t = (float)(-BB / (2 * AA));
+            if (PRETEST) {
+                const float q32 = bhalf * bhalf * __builtin_amdgcn_rcpf(aaf);
+                const float p32 = -0.5f * (CC - q32);
+                if (p32 + 4e-7f * fabsf(q32) + 1e-5f < q2.w)      // certainly alpha < 1/255 (false for NaN)
+                    continue;
+            }
+
+            const double AA = aaf;
+            const float bbf = 2 * bhalf;
+            const double BB = bbf;
+
+            const float t = -bbf / (2.0f * aaf);                  // == (float)(-BB / (2 * AA)), see header
             if (t <= F3DG_NEAR_PLANE)
                 continue;
 
@@ -109,7 +173,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 continue;
             }
 
-            const float4 q3 = staged[j * 4 + 3];      // g b depth -
+            const float4 q3 = staged[j * 4 + 3];      // r g b depth
             const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
 
             const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
@@ -121,9 +185,9 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             dist1 += mapped_max_t * alpha * Tr;
             dist2 += mapped_max_t * mapped_max_t * alpha * Tr;
 
-            C0 += q2.w * alpha * Tr;
-            C1 += q3.x * alpha * Tr;
-            C2 += q3.y * alpha * Tr;
+            C0 += q3.x * alpha * Tr;
+            C1 += q3.y * alpha * Tr;
+            C2 += q3.z * alpha * Tr;
             C3 += nn0 * alpha * Tr;
             C4 += nn1 * alpha * Tr;
             C5 += nn2 * alpha * Tr;
@@ -170,19 +234,28 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
-                       const float* background, int bg_per_view, float* out_color, float* final_T,
+                       const float4* bbox, const float* background, int bg_per_view, float* out_color, float* final_T,
                        unsigned* n_contrib, int save_aux)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
     const unsigned groups = (unsigned)((V + 7) / 8);
     dim3 grid(groups * 8u * (unsigned)T);
-    if (save_aux)
-        hipLaunchKernelGGL(render_fwd_kernel<true>, grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T, focal_x,
-                           focal_y, hdr, ranges, point_list, rec, background, bg_per_view, out_color, final_T, n_contrib);
-    else
-        hipLaunchKernelGGL(render_fwd_kernel<false>, grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T, focal_x,
-                           focal_y, hdr, ranges, point_list, rec, background, bg_per_view, out_color, final_T, n_contrib);
+#define F3DG_LAUNCH(AUX, PRE, CUL) hipLaunchKernelGGL((render_fwd_kernel<AUX, PRE, CUL>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, \
+                                                       tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, bbox,         \
+                                                       background, bg_per_view, out_color, final_T, n_contrib)
+    const int variant = (save_aux ? 4 : 0) | (g_f3dg_render_pretest ? 2 : 0) | (g_f3dg_render_cull ? 1 : 0);
+    switch (variant) {
+    case 0: F3DG_LAUNCH(false, false, false); break;
+    case 1: F3DG_LAUNCH(false, false, true); break;
+    case 2: F3DG_LAUNCH(false, true, false); break;
+    case 3: F3DG_LAUNCH(false, true, true); break;
+    case 4: F3DG_LAUNCH(true, false, false); break;
+    case 5: F3DG_LAUNCH(true, false, true); break;
+    case 6: F3DG_LAUNCH(true, true, false); break;
+    default: F3DG_LAUNCH(true, true, true); break;
+    }
+#undef F3DG_LAUNCH
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -159,6 +159,13 @@ int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* r
                          const float* c2w, float fx, float fy,
                          float* normal_world, float* depth_normal);
 
+/* Runtime switches (process-wide). Known names: "render_pretest" (default 1): the compositing kernel first runs a
+ * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;
+ * results are bit-identical with it on or off (asserted by the tests). "render_cull" (default 1): every 16x4 pixel strip
+ * of a tile walks only the staged Gaussians whose conservative alpha >= 1/255 box touches it; also bit-identical.
+ * Returns F3DG_ERR_BAD_ARG for unknown names. */
+int f3dg_set_option(const char* name, int value);
+
 /* Optional per-stage timing of the forward path with HIP events recorded on the caller's stream (this is what
  * bench.py uses for the live roofline figure). f3dg_profile_enable(1) makes every following
  * f3dg_forward_batched on this host thread record 4 events; f3dg_profile_collect() is BLOCKING, sums the
@@ -170,7 +177,7 @@ int f3dg_profile_collect(double* h_stage_ms, int* h_calls);
 /* Test/inspection hook: device-to-device copies of the library's internal per-call state into caller buffers
  * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the
  * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
- *   rec [V*P*16] (view2gaussian[10], opacity*coef, rgb[3], depth, 0), means2D [V*P*2], conic [V*P*4] (SAVE_AUX),
+ *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], depth), means2D [V*P*2], conic [V*P*4] (SAVE_AUX),
  *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped; SAVE_AUX), keys_sorted [cap] u64,
  *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX). */
 int f3dg_debug_export(void* stream, const void* workspace, int P, int W, int H, int n_views,

@@ -90,7 +90,7 @@ def run_hip(scene, device, save_aux=True, max_rendered=None):
     rec = e["rec"].cpu().numpy().reshape(V, max(P, 1), 16)
     res = dict(
         out_color=out.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R,
-        view2gaussian=rec[:, :, 0:10], opac=rec[:, :, 10], rgb=rec[:, :, 11:14], depths=rec[:, :, 14],
+        view2gaussian=rec[:, :, 0:10], opac=rec[:, :, 10], rgb=rec[:, :, 12:15], depths=rec[:, :, 15],
         means2D=e["means2D"].cpu().numpy().reshape(V, max(P, 1), 2),
         conic_opacity=e["conic"].cpu().numpy().reshape(V, max(P, 1), 4),
         tiles_touched=e["tiles"].cpu().numpy().view(np.uint32).reshape(V, max(P, 1)),

@@ -19,6 +19,7 @@ SCENES = {
     "F5_odd_size": dict(P=4000, res=(100, 72), s0=0.04, view="oblique"),
     "F6_small_splats": dict(P=30000, res=(128, 128), s0=0.01, view="oblique"),
     "F8_sh0": dict(P=1500, res=(64, 64), s0=0.05, view="oblique", sh_degree=0),
+    "F9_long_tile_lists": dict(P=30000, res=(128, 128), s0=0.05, view="oblique"),      # lists > 4096: global-memory tile sort path
 }
 
 
@@ -127,3 +128,29 @@ def test_c1_full_size_single_view(gpu_device):
     assert np.array_equal(h["point_list"], o["point_list"])
     _check_view(h, o, 0, "C1")
     assert_render_parity(h["out_color"][0], o["out_color"], "C1")
+
+
+@pytest.mark.parametrize("name", ["F1_tiny_identity", "F2_oblique_aniso", "F5_odd_size", "F6_small_splats", "F4_filter_scalemod", "C1", "tiny_sigma", "huge_sigma"])
+def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
+    """The float32 pre-test of the compositing kernel may only skip pairs whose alpha is certainly < 1/255:
+    every output and every auxiliary plane must be bit-identical with it on and off."""
+    from f3dgaus_amd import _lib
+    extra = {"C1": dict(P=65536, res=(256, 256), s0=0.01, view="oblique"),
+             "tiny_sigma": dict(P=20000, res=(256, 256), s0=0.003, view="oblique"),
+             "huge_sigma": dict(P=1500, res=(64, 64), s0=0.3, view="canonical")}
+    scene = make_scene(**(SCENES[name] if name in SCENES else extra[name]))
+    L = _lib.lib()
+    try:
+        assert L.f3dg_set_option(b"render_pretest", 0) == 0 and L.f3dg_set_option(b"render_cull", 0) == 0
+        a = run_hip(scene, gpu_device)              # plain transcription-order kernel
+        variants = []
+        for pre, cull in ((1, 0), (0, 1), (1, 1)):
+            assert L.f3dg_set_option(b"render_pretest", pre) == 0 and L.f3dg_set_option(b"render_cull", cull) == 0
+            variants.append(run_hip(scene, gpu_device))
+    finally:
+        L.f3dg_set_option(b"render_pretest", 1)
+        L.f3dg_set_option(b"render_cull", 1)
+    for b in variants:
+        for k in ("out_color", "final_T", "n_contrib"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert L.f3dg_set_option(b"no_such_option", 1) == _lib.ERR_BAD_ARG
