@@ -29,13 +29,81 @@
 //    a 4-bit strip mask; each wave compacts the 256 staged entries to its own index list with ballots and walks only
 //    those. Skipped entries would have been a bare `continue` for all 64 lanes, and `contributor` is set from the
 //    entry's position, so every output and auxiliary plane is bit-identical (asserted with the option on and off).
+//  * per-lane work queues. After the two filters above the expensive exact path still ran with ~1/4 of the lanes
+//    active, because a wave executes it whenever ANY of its 64 pixels passes. The loop is therefore split in two
+//    phases per window of 64 (compacted) entries: phase 1 runs only the cheap pre-test for all 64 entries with all
+//    lanes busy and leaves a 64-bit pass mask per pixel; phase 2 lets every pixel walk ITS OWN set bits in ascending
+//    order (per-lane LDS addresses, hence the SoA staging arrays), so the wave executes max-over-lanes(#passes)
+//    exact iterations instead of #(entries with any pass) -- about half as many, at twice the lane utilisation.
+//    Per pixel the sequence of blended Gaussians and every arithmetic operation on them is unchanged.
 //  * t = -BB/(2*AA) is a double quotient of float-valued operands rounded to float: identical to ONE IEEE float32
 //    divide (double rounding is innocuous for p = 24, q = 53 >= 2p + 2), so the float64 divide is not needed.
 #include "f3dg_common.h"
 
 namespace {
 
-template <bool SAVE_AUX, bool PRETEST, bool CULL>
+struct PixelState {
+    float Tr;
+    unsigned last_contributor, max_contributor;
+    float C0, C1, C2, C3, C4, C5, C6, C7;
+    float dist1, dist2, distortion;
+};
+
+// The reference's per-(pixel, Gaussian) arithmetic after the geometric terms (forward.cu:511-579), in its operation
+// order. Returns true when the pixel saturates (`done = true`); `contributor` is the 1-based position in the tile list.
+__device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor, float n0, float n1, float n2, float aaf,
+                                            float bhalf, float CC, float opac, float cr, float cg, float cb)
+{
+    const double AA = aaf;
+    const float bbf = 2 * bhalf;
+    const double BB = bbf;
+
+    const float t = -bbf / (2.0f * aaf);                  // == (float)(-BB / (2 * AA)), see header
+    if (t <= F3DG_NEAR_PLANE)
+        return false;
+
+    const double min_value = -(BB / AA) * (BB / 4.) + CC;
+    float power = (float)(-0.5f * min_value);
+    if (power > 0.0f)
+        power = 0.0f;
+
+    const float alpha = fminf(0.99f, opac * expf(power));
+    if (alpha < 1.0f / 255.0f)
+        return false;
+    const float Tr = st.Tr;
+    const float test_T = Tr * (1 - alpha);
+    if (test_T < 0.0001f)
+        return true;
+
+    const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
+
+    const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
+    const float nn0 = -n0 / length, nn1 = -n1 / length, nn2 = -n2 / length;
+
+    const float A = 1 - Tr;
+    const float error = mapped_max_t * mapped_max_t * A + st.dist2 - 2 * mapped_max_t * st.dist1;
+    st.distortion += error * alpha * Tr;
+    st.dist1 += mapped_max_t * alpha * Tr;
+    st.dist2 += mapped_max_t * mapped_max_t * alpha * Tr;
+
+    st.C0 += cr * alpha * Tr;
+    st.C1 += cg * alpha * Tr;
+    st.C2 += cb * alpha * Tr;
+    st.C3 += nn0 * alpha * Tr;
+    st.C4 += nn1 * alpha * Tr;
+    st.C5 += nn2 * alpha * Tr;
+    if (Tr > 0.5) {
+        st.C6 = t;
+        st.max_contributor = contributor;
+    }
+    st.C7 += alpha * Tr;
+
+    st.Tr = test_T;
+    st.last_contributor = contributor;
+    return false;
+}
+
+template <bool SAVE_AUX, bool PRETEST, bool CULL, bool QUEUE>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
@@ -67,7 +135,11 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     const int rounds = (int)((range.y - range.x + F3DG_BLOCK - 1) / F3DG_BLOCK);
     int toDo = (int)(range.y - range.x);
 
-    __shared__ float4 staged[F3DG_BLOCK * 4];     // 256 records x 64 B = 16 KiB
+    // 256 staged records, structure-of-arrays by float4 so that per-lane (divergent) reads spread over the banks
+    __shared__ float4 sq0[F3DG_BLOCK];            // v0 v1 v2 v3
+    __shared__ float4 sq1[F3DG_BLOCK];            // v4 v5 v6 v7
+    __shared__ float4 sq2[F3DG_BLOCK];            // v8 v9 opac thr
+    __shared__ float4 sq3[F3DG_BLOCK];            // r g b depth
     __shared__ unsigned char strip_mask[CULL ? F3DG_BLOCK : 1];
     __shared__ unsigned short wave_list[CULL ? F3DG_BLOCK / 64 : 1][CULL ? F3DG_BLOCK : 1];
 
@@ -77,10 +149,11 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     const float tile_px0 = (float)(tile_x * F3DG_TILE), tile_py0 = (float)(tile_y * F3DG_TILE);
 
     bool done = !inside;
-    float Tr = 1.0f;
-    unsigned contributor = 0, last_contributor = 0, max_contributor = (unsigned)-1;
-    float C0 = 0, C1 = 0, C2 = 0, C3 = 0, C4 = 0, C5 = 0, C6 = 0, C7 = 0;
-    float dist1 = 0, dist2 = 0, distortion = 0;
+    PixelState st;
+    st.Tr = 1.0f;
+    st.last_contributor = 0; st.max_contributor = (unsigned)-1;
+    st.C0 = st.C1 = st.C2 = st.C3 = st.C4 = st.C5 = st.C6 = st.C7 = 0;
+    st.dist1 = st.dist2 = st.distortion = 0;
 
     for (int i = 0; i < rounds; i++, toDo -= F3DG_BLOCK) {
         const int num_done = __syncthreads_count(done);
@@ -92,10 +165,10 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             const unsigned id = point_list[range.x + progress];
             const float4* src = reinterpret_cast<const float4*>(vrec + id);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
-            staged[threadIdx.x * 4 + 0] = a;
-            staged[threadIdx.x * 4 + 1] = b;
-            staged[threadIdx.x * 4 + 2] = c;
-            staged[threadIdx.x * 4 + 3] = d;
+            sq0[threadIdx.x] = a;
+            sq1[threadIdx.x] = b;
+            sq2[threadIdx.x] = c;
+            sq3[threadIdx.x] = d;
             if (CULL) {
                 const float4 bx = vbox[id];                       // (x0, x1, y0, y1) in pixel coordinates
                 unsigned m = 0;
@@ -129,103 +202,91 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const unsigned round_base = (unsigned)i * F3DG_BLOCK;
-        for (int kk = 0; !done && kk < count; kk++) {
-            const int j = CULL ? (int)wave_list[wave][kk] : kk;
-            contributor = round_base + (unsigned)j + 1u;
-            const float4 q0 = staged[j * 4 + 0];      // v0 v1 v2 v3
-            const float4 q1 = staged[j * 4 + 1];      // v4 v5 v6 v7
-            const float4 q2 = staged[j * 4 + 2];      // v8 v9 opac thr
 
-            const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
-            const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
-            const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
-
-            const float aaf = ray_x * n0 + ray_y * n1 + n2;
-            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-            const float CC = q2.y;
-
-            if (PRETEST) {
-                const float q32 = bhalf * bhalf * __builtin_amdgcn_rcpf(aaf);
-                const float p32 = -0.5f * (CC - q32);
-                if (p32 + 4e-7f * fabsf(q32) + 1e-5f < q2.w)      // certainly alpha < 1/255 (false for NaN)
-                    continue;
+        if (!QUEUE) {
+            // ---- reference-shaped loop: every lane visits every (remaining) entry
+            for (int kk = 0; !done && kk < count; kk++) {
+                const int j = CULL ? (int)wave_list[wave][kk] : kk;
+                const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j];
+                const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+                const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+                const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+                const float aaf = ray_x * n0 + ray_y * n1 + n2;
+                const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+                if (PRETEST) {
+                    const float q32 = bhalf * bhalf * __builtin_amdgcn_rcpf(aaf);
+                    const float p32 = -0.5f * (q2.y - q32);
+                    if (p32 + 4e-7f * fabsf(q32) + 1e-5f < q2.w)      // certainly alpha < 1/255 (false for NaN)
+                        continue;
+                }
+                const float4 q3 = sq3[j];
+                done = blend_entry(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
             }
-
-            const double AA = aaf;
-            const float bbf = 2 * bhalf;
-            const double BB = bbf;
-
-            const float t = -bbf / (2.0f * aaf);                  // == (float)(-BB / (2 * AA)), see header
-            if (t <= F3DG_NEAR_PLANE)
-                continue;
-
-            const double min_value = -(BB / AA) * (BB / 4.) + CC;
-            float power = (float)(-0.5f * min_value);
-            if (power > 0.0f)
-                power = 0.0f;
-
-            const float alpha = fminf(0.99f, q2.z * expf(power));
-            if (alpha < 1.0f / 255.0f)
-                continue;
-            const float test_T = Tr * (1 - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        } else {
+            // ---- two-phase loop over windows of 64 entries
+            for (int w0 = 0; w0 < count; w0 += 64) {
+                const int wn = min(64, count - w0);
+                unsigned long long pass = 0;
+                if (PRETEST) {
+                    if (!done) {
+                        for (int kk = 0; kk < wn; kk++) {        // phase 1: cheap test, wave-uniform entry (LDS broadcast)
+                            const int j = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
+                            const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j];
+                            const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+                            const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+                            const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+                            const float aaf = ray_x * n0 + ray_y * n1 + n2;
+                            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+                            const float q32 = bhalf * bhalf * __builtin_amdgcn_rcpf(aaf);
+                            const float p32 = -0.5f * (q2.y - q32);
+                            if (!(p32 + 4e-7f * fabsf(q32) + 1e-5f < q2.w))
+                                pass |= 1ull << kk;
+                        }
+                    }
+                } else {
+                    pass = done ? 0ull : (wn == 64 ? ~0ull : ((1ull << wn) - 1ull));
+                }
+                while (pass != 0 && !done) {                     // phase 2: this pixel's own passing entries, in order
+                    const int kk = __builtin_ctzll(pass);
+                    pass &= pass - 1;
+                    const int j = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
+                    const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
+                    const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+                    const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+                    const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+                    const float aaf = ray_x * n0 + ray_y * n1 + n2;
+                    const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+                    done = blend_entry(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+                }
             }
-
-            const float4 q3 = staged[j * 4 + 3];      // r g b depth
-            const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
-
-            const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
-            const float nn0 = -n0 / length, nn1 = -n1 / length, nn2 = -n2 / length;
-
-            const float A = 1 - Tr;
-            const float error = mapped_max_t * mapped_max_t * A + dist2 - 2 * mapped_max_t * dist1;
-            distortion += error * alpha * Tr;
-            dist1 += mapped_max_t * alpha * Tr;
-            dist2 += mapped_max_t * mapped_max_t * alpha * Tr;
-
-            C0 += q3.x * alpha * Tr;
-            C1 += q3.y * alpha * Tr;
-            C2 += q3.z * alpha * Tr;
-            C3 += nn0 * alpha * Tr;
-            C4 += nn1 * alpha * Tr;
-            C5 += nn2 * alpha * Tr;
-            if (Tr > 0.5) {
-                C6 = t;
-                max_contributor = contributor;
-            }
-            C7 += alpha * Tr;
-
-            Tr = test_T;
-            last_contributor = contributor;
         }
     }
 
     if (inside) {
         const float* bg = background + (bg_per_view ? 3 * view : 0);
-        const float distortion_before_normalized = distortion;
-        distortion = (float)(distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
 
         if (SAVE_AUX) {
             float* fT = final_T + (size_t)view * 4 * HW;
             fT[pix_id] = Tr;
-            fT[pix_id + HW] = dist1;
-            fT[pix_id + 2 * HW] = dist2;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
             fT[pix_id + 3 * HW] = distortion_before_normalized;
             unsigned* nc = n_contrib + (size_t)view * 2 * HW;
-            nc[pix_id] = last_contributor;
-            nc[pix_id + HW] = max_contributor;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
         }
         float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
-        out[0 * HW + pix_id] = C0 + Tr * bg[0];
-        out[1 * HW + pix_id] = C1 + Tr * bg[1];
-        out[2 * HW + pix_id] = C2 + Tr * bg[2];
-        out[3 * HW + pix_id] = C3;
-        out[4 * HW + pix_id] = C4;
-        out[5 * HW + pix_id] = C5;
-        out[6 * HW + pix_id] = C6;
-        out[7 * HW + pix_id] = C7;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
         out[8 * HW + pix_id] = distortion;
     }
 }
@@ -241,20 +302,22 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     const int T = tiles_x * tiles_y;
     const unsigned groups = (unsigned)((V + 7) / 8);
     dim3 grid(groups * 8u * (unsigned)T);
-#define F3DG_LAUNCH(AUX, PRE, CUL) hipLaunchKernelGGL((render_fwd_kernel<AUX, PRE, CUL>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, \
-                                                       tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, bbox,         \
-                                                       background, bg_per_view, out_color, final_T, n_contrib)
+#define F3DG_LAUNCH(AUX, PRE, CUL, QUE) hipLaunchKernelGGL((render_fwd_kernel<AUX, PRE, CUL, QUE>), grid, dim3(F3DG_BLOCK), 0, s, V, P, \
+                                                            W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec,   \
+                                                            bbox, background, bg_per_view, out_color, final_T, n_contrib)
+#define F3DG_LAUNCH_Q(AUX, PRE, CUL) do { if (g_f3dg_render_queue) F3DG_LAUNCH(AUX, PRE, CUL, true); else F3DG_LAUNCH(AUX, PRE, CUL, false); } while (0)
     const int variant = (save_aux ? 4 : 0) | (g_f3dg_render_pretest ? 2 : 0) | (g_f3dg_render_cull ? 1 : 0);
     switch (variant) {
-    case 0: F3DG_LAUNCH(false, false, false); break;
-    case 1: F3DG_LAUNCH(false, false, true); break;
-    case 2: F3DG_LAUNCH(false, true, false); break;
-    case 3: F3DG_LAUNCH(false, true, true); break;
-    case 4: F3DG_LAUNCH(true, false, false); break;
-    case 5: F3DG_LAUNCH(true, false, true); break;
-    case 6: F3DG_LAUNCH(true, true, false); break;
-    default: F3DG_LAUNCH(true, true, true); break;
+    case 0: F3DG_LAUNCH_Q(false, false, false); break;
+    case 1: F3DG_LAUNCH_Q(false, false, true); break;
+    case 2: F3DG_LAUNCH_Q(false, true, false); break;
+    case 3: F3DG_LAUNCH_Q(false, true, true); break;
+    case 4: F3DG_LAUNCH_Q(true, false, false); break;
+    case 5: F3DG_LAUNCH_Q(true, false, true); break;
+    case 6: F3DG_LAUNCH_Q(true, true, false); break;
+    default: F3DG_LAUNCH_Q(true, true, true); break;
     }
+#undef F3DG_LAUNCH_Q
 #undef F3DG_LAUNCH
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

@@ -163,7 +163,8 @@ int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* r
  * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;
  * results are bit-identical with it on or off (asserted by the tests). "render_cull" (default 1): every 16x4 pixel strip
  * of a tile walks only the staged Gaussians whose conservative alpha >= 1/255 box touches it; also bit-identical.
- * Returns F3DG_ERR_BAD_ARG for unknown names. */
+ * "render_queue" (default 1): two-phase compositing loop (cheap test for 64 entries, then per-pixel queues of the passing
+ * ones); also bit-identical. Returns F3DG_ERR_BAD_ARG for unknown names. */
 int f3dg_set_option(const char* name, int value);
 
 /* Optional per-stage timing of the forward path with HIP events recorded on the caller's stream (this is what

@@ -141,15 +141,16 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
     scene = make_scene(**(SCENES[name] if name in SCENES else extra[name]))
     L = _lib.lib()
     try:
-        assert L.f3dg_set_option(b"render_pretest", 0) == 0 and L.f3dg_set_option(b"render_cull", 0) == 0
+        for o in (b"render_pretest", b"render_cull", b"render_queue"):
+            assert L.f3dg_set_option(o, 0) == 0
         a = run_hip(scene, gpu_device)              # plain transcription-order kernel
         variants = []
-        for pre, cull in ((1, 0), (0, 1), (1, 1)):
-            assert L.f3dg_set_option(b"render_pretest", pre) == 0 and L.f3dg_set_option(b"render_cull", cull) == 0
+        for pre, cull, que in ((1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)):
+            L.f3dg_set_option(b"render_pretest", pre); L.f3dg_set_option(b"render_cull", cull); L.f3dg_set_option(b"render_queue", que)
             variants.append(run_hip(scene, gpu_device))
     finally:
-        L.f3dg_set_option(b"render_pretest", 1)
-        L.f3dg_set_option(b"render_cull", 1)
+        for o in (b"render_pretest", b"render_cull", b"render_queue"):
+            L.f3dg_set_option(o, 1)
     for b in variants:
         for k in ("out_color", "final_T", "n_contrib"):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
