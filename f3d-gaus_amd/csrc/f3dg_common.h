@@ -30,7 +30,7 @@ struct F3dgHeader {
 // Per-(view, Gaussian) record consumed by the compositing kernel: one 64-byte line.
 //   f[0..9]   view2gaussian (Sigma' upper triangle, B, C)     forward.cu:268-277
 //   f[10]     opacity * coef (conic_opacity.w)                 forward.cu:392
-//   f[11]     power threshold: alpha < 1/255 is CERTAIN when the exponent is below it (see f3dg_render.hip)
+//   f[11]     pre-test constant K: alpha < 1/255 is CERTAIN when b^2 < K*a (see f3dg_render.hip)
 //   f[12..14] rgb                                              forward.cu:379-384
 //   f[15]     view-space depth                                 forward.cu:388
 // The first three float4 are everything the conservative pre-test needs; the 4th is only read by contributors.

@@ -330,13 +330,21 @@ preprocess_kernel(int P, int D, int M,
                 con = make_float4(conic_x, conic_y, conic_z, opac);
                 r0 = make_float4(vg[0], vg[1], vg[2], vg[3]);
                 r1 = make_float4(vg[4], vg[5], vg[6], vg[7]);
-                // exponent threshold of the compositing pre-test: alpha = min(.99, opac*exp(power)) < 1/255 whenever
-                // power < log(1/(255*opac)); 1e-4 of slack covers logf/expf ulps and the final float rounding of power.
-                // opac <= 0 (or NaN) -> +inf / NaN: +inf skips everything (alpha <= 0 < 1/255 for any power <= 0),
-                // NaN disables the pre-test for this Gaussian.
+                // Pre-test constants of the compositing kernel. alpha = min(.99, opac*exp(power)) < 1/255 whenever
+                // power < thr = log(1/(255*opac)); 1e-4 of slack covers logf/expf ulps and the final float rounding of
+                // power. With power = -(C - b^2/a)/2 that is  b^2 < K0 * a,  K0 = C + 2 thr.  The kernel evaluates
+                // fl(b*b) < fl(K*a) in float32; K = K0 (1 - 5e-7) absorbs both product roundings and the narrowing of K
+                // itself. K is clamped at 0 (never skip) so that a <= 0 or K0 <= 0 cannot produce a false skip.
+                // opac <= 0 -> alpha <= 0 always: K = +inf skips everything finite; NaN opacity disables the test.
                 const float thr = debug_skip_all ? __builtin_inff() : opac > 0.0f ? logf(1.0f / (255.0f * opac)) - 1e-4f : (opac <= 0.0f ? __builtin_inff() : opac);
+                float Kpre;
+                if (thr == __builtin_inff()) Kpre = __builtin_inff();
+                else {
+                    const double K0 = ((double)vg[9] + 2.0 * (double)thr) * (1.0 - 5e-7);
+                    Kpre = K0 > 0.0 ? (float)K0 : 0.0f;          // NaN -> 0 (comparison false)
+                }
                 box = conservative_box(vg, thr, scale, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y);
-                r2 = make_float4(vg[8], vg[9], opac, thr);
+                r2 = make_float4(vg[8], vg[9], opac, Kpre);
                 r3 = make_float4(cr, cg, cb, pvz);
             }
         }

@@ -17,11 +17,12 @@
 // ALU diet that does not change results (the kernel is VALU-bound, ~200 pixel tests per 72-byte instance):
 //  * conservative pre-test. Only ~5 % of (pixel, Gaussian) tests end in a blend; the rest leave through
 //    `alpha < 1/255` (or `t <= 0.2`), both of which are a bare `continue`. A float32 estimate of the exponent,
-//    p32 = -(C - b^2/a)/2 with b = BB/2, a = AA, differs from the reference's float64 evaluation of the same float
-//    inputs by at most ~3 ulp of q = b^2/a (one product rounding, a 1-ulp v_rcp_f32, one more product rounding;
-//    the subtraction and the halving are exact or harmless), i.e. |p32 - p| <= 1e-7*|q|. The record carries
-//    thr = log(1/(255*opacity)) - 1e-4, so  p32 + 4e-7*|q| + 1e-5 < thr  PROVES alpha < 1/255 and the pair is
-//    skipped before any float64 instruction, expf or divide. NaN/inf fall through to the exact path. The tests run
+//    With b = BB/2 and a = AA (the reference's own float32 values, computed in its order) the exponent is
+//    p = -(C - b^2/a)/2, and alpha < 1/255 is certain when p < thr = log(1/(255*opacity)) - 1e-4, i.e. when
+//    b^2 < K0*a with K0 = C + 2 thr. The record carries K = K0*(1 - 5e-7) (>= 0), which absorbs the two float32
+//    product roundings of the test  fl(b*b) < fl(K*a)  -- three VALU instructions -- so a true test PROVES
+//    alpha < 1/255 and the pair is skipped before any float64 instruction, expf or divide. NaN falls through to the
+//    exact path. The tests run
 //    every scene with the pre-test on and off and require bit-identical outputs.
 //  * per-strip culling. A tile's list holds every Gaussian whose 3-sigma SQUARE touches the 16x16 tile, but a wave
 //    owns a 16x4 strip and only ~1/3 of the (strip, Gaussian) pairs contain a pixel with alpha >= 1/255. The staging
@@ -214,9 +215,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 const float aaf = ray_x * n0 + ray_y * n1 + n2;
                 const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
                 if (PRETEST) {
-                    const float q32 = bhalf * bhalf * __builtin_amdgcn_rcpf(aaf);
-                    const float p32 = -0.5f * (q2.y - q32);
-                    if (p32 + 4e-7f * fabsf(q32) + 1e-5f < q2.w)      // certainly alpha < 1/255 (false for NaN)
+                    if (bhalf * bhalf < q2.w * aaf)                   // certainly alpha < 1/255 (false for NaN)
                         continue;
                 }
                 const float4 q3 = sq3[j];
@@ -237,9 +236,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
                             const float aaf = ray_x * n0 + ray_y * n1 + n2;
                             const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-                            const float q32 = bhalf * bhalf * __builtin_amdgcn_rcpf(aaf);
-                            const float p32 = -0.5f * (q2.y - q32);
-                            if (!(p32 + 4e-7f * fabsf(q32) + 1e-5f < q2.w))
+                            if (!(bhalf * bhalf < q2.w * aaf))
                                 pass |= 1ull << kk;
                         }
                     }
