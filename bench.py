@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--views", type=int, default=120)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--sigma0", type=float, default=0.01)
-    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("F3DG_VIEWS_PER_CALL", "40")))
+    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("F3DG_VIEWS_PER_CALL", "120")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
     return ap.parse_args()
@@ -149,8 +149,9 @@ def main():
                        % (P, args.sigma0, V, RES, RES), "gaussians": P, "views": V, "resolution": RES,
                        "instances_per_step": R_total, "views_per_call": args.views_per_call,
                        "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "render_fwd_kernel<false>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "render_fwd_kernel<SAVE_AUX=false, PRETEST, CULL, QUEUE>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(P, V, RES, args.views_per_call),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": render_ms_per_launch,
                          "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
                                                "compositing": stage_ms[2] / args.steps}},
@@ -161,6 +162,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(P, V, RES, views_per_call):
+    """HBM bytes per compositing launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    runs of this same command; gfx950 FETCH_SIZE correction applied) -- only when they were taken on this exact
+    configuration, else null. PMC counters cannot be collected from inside the process."""
+    path = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
+    try:
+        t = json.load(open(path))
+        c = t["config"]
+        if (c["gaussians"], c["views"], c["resolution"], c["views_per_call"]) == (P, V, RES, views_per_call):
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(g, cams, shs, P, RES, n_sample):
