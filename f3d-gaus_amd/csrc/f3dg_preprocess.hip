@@ -60,6 +60,17 @@ __device__ __forceinline__ M3 quat_to_R(float4 q)
 
 __device__ __forceinline__ float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
+// Pre-test constant K of the compositing kernel. alpha = min(.99, opac*exp(power)) < 1/255 whenever
+// power = -(C - b^2/a)/2 < thr, i.e. b^2 < K0 * a with K0 = C + 2 thr (a, b, C: the reference's own float32 values).
+// The kernel evaluates fl(b*b) < fl(K*a) in float32; K = K0 (1 - 5e-7) absorbs both product roundings and the
+// narrowing of K itself. K is clamped at 0 ("never skip") so that a <= 0 or K0 <= 0 cannot produce a false skip.
+__device__ __forceinline__ float pretest_constant(const float* vg, float thr)
+{
+    if (thr == __builtin_inff()) return __builtin_inff();      // opacity <= 0: alpha <= 0 always
+    const double K0 = ((double)vg[9] + 2.0 * (double)thr) * (1.0 - 5e-7);
+    return K0 > 0.0 ? (float)K0 : 0.0f;                         // NaN -> 0
+}
+
 // Conservative pixel-space box of the region where this Gaussian's alpha can reach 1/255 in the compositing kernel.
 //   alpha >= 1/255  =>  p = -(C - b^2/a)/2 >= thr  <=>  (C - k) a - b^2 <= 0, k = -2 thr, a = r^T Sigma' r, b = B^T r, r = (x, y, 1):
 // a conic in ray space with matrix M = (C - k) Sigma' - B B^T; its axis-aligned extent follows from the dual conic adj(M).
@@ -330,19 +341,11 @@ preprocess_kernel(int P, int D, int M,
                 con = make_float4(conic_x, conic_y, conic_z, opac);
                 r0 = make_float4(vg[0], vg[1], vg[2], vg[3]);
                 r1 = make_float4(vg[4], vg[5], vg[6], vg[7]);
-                // Pre-test constants of the compositing kernel. alpha = min(.99, opac*exp(power)) < 1/255 whenever
-                // power < thr = log(1/(255*opac)); 1e-4 of slack covers logf/expf ulps and the final float rounding of
-                // power. With power = -(C - b^2/a)/2 that is  b^2 < K0 * a,  K0 = C + 2 thr.  The kernel evaluates
-                // fl(b*b) < fl(K*a) in float32; K = K0 (1 - 5e-7) absorbs both product roundings and the narrowing of K
-                // itself. K is clamped at 0 (never skip) so that a <= 0 or K0 <= 0 cannot produce a false skip.
-                // opac <= 0 -> alpha <= 0 always: K = +inf skips everything finite; NaN opacity disables the test.
+                // Pre-test constant of the compositing kernel (see pretest_constant). alpha = min(.99, opac*exp(power))
+                // < 1/255 whenever power < thr = log(1/(255*opac)); 1e-4 of slack covers logf/expf ulps and the final float
+                // rounding of power. opac <= 0 -> alpha <= 0 always (K = +inf); NaN opacity disables the test.
                 const float thr = debug_skip_all ? __builtin_inff() : opac > 0.0f ? logf(1.0f / (255.0f * opac)) - 1e-4f : (opac <= 0.0f ? __builtin_inff() : opac);
-                float Kpre;
-                if (thr == __builtin_inff()) Kpre = __builtin_inff();
-                else {
-                    const double K0 = ((double)vg[9] + 2.0 * (double)thr) * (1.0 - 5e-7);
-                    Kpre = K0 > 0.0 ? (float)K0 : 0.0f;          // NaN -> 0 (comparison false)
-                }
+                const float Kpre = pretest_constant(vg, thr);
                 box = conservative_box(vg, thr, scale, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y);
                 r2 = make_float4(vg[8], vg[9], opac, Kpre);
                 r3 = make_float4(cr, cg, cb, pvz);

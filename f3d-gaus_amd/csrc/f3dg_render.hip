@@ -105,7 +105,7 @@ __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor
 }
 
 template <bool SAVE_AUX, bool PRETEST, bool CULL, bool QUEUE>
-__global__ void __launch_bounds__(F3DG_BLOCK)
+__global__ void __launch_bounds__(F3DG_BLOCK, 8)
 render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
@@ -228,16 +228,28 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 unsigned long long pass = 0;
                 if (PRETEST) {
                     if (!done) {
-                        for (int kk = 0; kk < wn; kk++) {        // phase 1: cheap test, wave-uniform entry (LDS broadcast)
-                            const int j = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
-                            const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j];
+                        // phase 1: cheap test, wave-uniform entries (LDS broadcast); two entries per trip so that the
+                        // second entry's index + record loads are in flight while the first is evaluated
+                        auto test = [&](const float4& q0, const float4& q1, const float4& q2) -> bool {
                             const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
                             const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
                             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
                             const float aaf = ray_x * n0 + ray_y * n1 + n2;
                             const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-                            if (!(bhalf * bhalf < q2.w * aaf))
-                                pass |= 1ull << kk;
+                            return !(bhalf * bhalf < q2.w * aaf);
+                        };
+                        int kk = 0;
+                        for (; kk + 1 < wn; kk += 2) {
+                            const int j0 = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
+                            const int j1 = CULL ? (int)wave_list[wave][w0 + kk + 1] : (w0 + kk + 1);
+                            const float4 a0 = sq0[j0], a1 = sq1[j0], a2 = sq2[j0];
+                            const float4 b0 = sq0[j1], b1 = sq1[j1], b2 = sq2[j1];
+                            if (test(a0, a1, a2)) pass |= 1ull << kk;
+                            if (test(b0, b1, b2)) pass |= 2ull << kk;
+                        }
+                        if (kk < wn) {
+                            const int j0 = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
+                            if (test(sq0[j0], sq1[j0], sq2[j0])) pass |= 1ull << kk;
                         }
                     }
                 } else {

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import f3dgaus_amd as f
 L = f._lib.lib()
 import runpy
-for opt in ([], [(b"render_queue", 0)], [(b"render_queue", 0), (b"render_cull", 0)]):
+for opt in ([], [(b"debug_skip_all", 1)], [(b"render_queue", 0)]):
     for k, v in [(b"debug_skip_all", 0), (b"render_pretest", 1), (b"render_cull", 1), (b"render_queue", 1)] + opt:
         L.f3dg_set_option(k, v)
     sys.argv = ["bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
