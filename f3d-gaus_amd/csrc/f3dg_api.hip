@@ -122,7 +122,8 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.sort_blocks = (unsigned)((C + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK);
     const size_t scan_a = (VP + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
     const size_t scan_b = ((size_t)256 * L.sort_blocks + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
-    L.scan_tmp_elems = (unsigned)((scan_a > scan_b ? scan_a : scan_b) + 1);
+    const size_t scan_c = ((size_t)V * T + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
+    L.scan_tmp_elems = (unsigned)((scan_a > scan_b ? (scan_a > scan_c ? scan_a : scan_c) : (scan_b > scan_c ? scan_b : scan_c)) + 1);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -140,7 +141,15 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.keys[1] = take(C * 8);
     L.vals[0] = take(C * 4);
     L.vals[1] = take(C * 4);
-    L.hist = take((size_t)256 * L.sort_blocks * sizeof(unsigned));
+    L.keys[2] = take(C * 8);
+    L.vals[2] = take(C * 4);
+    L.gstart = take((size_t)2 * V * T * sizeof(unsigned));          // gstart[V*T] immediately followed by gend[V*T]
+    L.gend = L.gstart + (size_t)V * T * sizeof(unsigned);
+    L.gcount = take((size_t)V * T * sizeof(unsigned));
+    {   // radix histograms [256][sort_blocks]; also reused for the inclusive scan of the V*T group sizes
+        const size_t h = (size_t)256 * L.sort_blocks, gseg = (size_t)V * T;
+        L.hist = take((h > gseg ? h : gseg) * sizeof(unsigned));
+    }
     L.ranges = take((size_t)V * T * sizeof(uint2));
     L.final_T = take((size_t)V * 4 * HW * sizeof(float));
     L.n_contrib = take((size_t)V * 2 * HW * sizeof(unsigned));

@@ -5,12 +5,15 @@
 //   the blocking D2H of num_rendered   :336      -> count stays on the device (workspace header)
 //   duplicateWithKeys                  :70-111   -> duplicate_keys_kernel
 //   cub::DeviceRadixSort::SortPairs    :358-363  -> radix_hist_kernel + scan + radix_scatter_kernel (8 bits/pass)
-//   cudaMemset(ranges) + identifyTileRanges :365, :149-171 -> tile_ranges_kernel
+//   cudaMemset(ranges) + identifyTileRanges :365, :149-171 -> group_bounds / group_counts / scan / group_ranges kernels
 //
-// Keys are (view * T + tile) << 32 | float_bits(depth): the view index rides in the high bits so that one sort
-// orders every view of the batch; within a view the order is exactly the reference's (tile, depth, then input
-// order = ascending Gaussian id, because the sort is stable). Depths are > 0.2 so their IEEE bits order as
-// unsigned integers.
+// Keys are ((view << tile_bits) | tile) << 32 | float_bits(depth). Instances are GENERATED in (view, Gaussian) order,
+// so only the tile bits need a global sort: after the stable tile-digit pass(es) every (tile, view) group is contiguous
+// and internally in ascending Gaussian-id order; group bounds + a scan over the V*T groups in (view, tile) order give
+// each group its final place, and the per-group depth sort (tile_sort_kernel) reads the group where the tile pass left
+// it and writes it, depth-sorted, where the compositing kernel expects it. One global pass at 256^2 (T = 256) for any
+// number of views, instead of the six a flat 47-bit sort needs. Within a view the final order is exactly the
+// reference's (tile, depth, then ascending Gaussian id). Depths are > 0.2 so their IEEE bits order as unsigned ints.
 //
 // Wave64 notes: the in-block ranking of the scatter uses 64-lane ballots (one per digit bit) to find, for every
 // lane, the set of lanes holding the same digit; ranks are popcounts of that 64-bit mask below the lane. Keys
@@ -112,7 +115,7 @@ scan_apply_kernel(const u32* in, u32* out /* may alias in */, u64 n, const u32* 
 
 // ------------------------------------------------------------------------------------------------ keys
 __global__ void __launch_bounds__(F3DG_BLOCK)
-duplicate_keys_kernel(int P, int T, int grid_x, int grid_y, const float2* __restrict__ means2D,
+duplicate_keys_kernel(int P, int tile_bits, int grid_x, int grid_y, const float2* __restrict__ means2D,
                       const F3dgRec* __restrict__ rec, const u32* __restrict__ offsets,
                       const int* __restrict__ radii, const F3dgHeader* __restrict__ hdr,
                       u64* __restrict__ keys, u32* __restrict__ vals)
@@ -131,10 +134,10 @@ duplicate_keys_kernel(int P, int T, int grid_x, int grid_y, const float2* __rest
         const int rmaxx = min(grid_x, max(0, (int)((p.x + radius + F3DG_TILE - 1) / F3DG_TILE)));
         const int rmaxy = min(grid_y, max(0, (int)((p.y + radius + F3DG_TILE - 1) / F3DG_TILE)));
         const u32 depth_bits = __float_as_uint(rec[idx].f[15]);
-        const u64 view_base = (u64)v * (u64)T;
+        const u64 view_base = (u64)v << tile_bits;
         for (int y = rminy; y < rmaxy; y++)
             for (int x = rminx; x < rmaxx; x++) {
-                u64 key = view_base + (u64)(y * grid_x + x);
+                u64 key = view_base | (u64)(y * grid_x + x);
                 key <<= 32;
                 key |= depth_bits;
                 keys[off] = key;
@@ -287,9 +290,42 @@ __device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 l
     return prev + below;
 }
 
+// (view, tile) groups of the tile-sorted buffer: first / one-past-last index of every group, indexed view * T + tile
 __global__ void __launch_bounds__(F3DG_BLOCK)
-tile_sort_kernel(const uint2* __restrict__ ranges, u32 n_segments, const F3dgHeader* __restrict__ hdr,
-                 u64* __restrict__ keys_a, u32* __restrict__ vals_a, u64* __restrict__ keys_b, u32* __restrict__ vals_b)
+group_bounds_kernel(const u64* __restrict__ keys, const F3dgHeader* __restrict__ hdr, int tile_bits, int T,
+                    u32* __restrict__ gstart, u32* __restrict__ gend)
+{
+    const u32 L = hdr->overflow ? 0u : hdr->num_rendered;
+    const u32 tmask = (1u << tile_bits) - 1u;
+    for (u64 idx = (u64)blockIdx.x * F3DG_BLOCK + threadIdx.x; idx < L; idx += (u64)gridDim.x * F3DG_BLOCK) {
+        const u32 cur = (u32)(keys[idx] >> 32);
+        const u32 seg = (cur >> tile_bits) * (u32)T + (cur & tmask);
+        if (idx == 0 || (u32)(keys[idx - 1] >> 32) != cur) gstart[seg] = (u32)idx;
+        if (idx == L - 1 || (u32)(keys[idx + 1] >> 32) != cur) gend[seg] = (u32)idx + 1u;
+    }
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+group_counts_kernel(u32 nseg, const u32* __restrict__ gstart, const u32* __restrict__ gend, u32* __restrict__ gcount)
+{
+    const u32 i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    if (i < nseg) gcount[i] = gend[i] - gstart[i];
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restrict__ gcum /* inclusive scan */,
+                    uint2* __restrict__ ranges)
+{
+    const u32 i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    if (i < nseg) ranges[i] = gcount[i] ? make_uint2(gcum[i] - gcount[i], gcum[i]) : make_uint2(0u, 0u);
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
+                 const F3dgHeader* __restrict__ hdr,
+                 const u64* __restrict__ keys_src, const u32* __restrict__ vals_src,     // tile-grouped buffer
+                 u64* __restrict__ keys_dst, u32* __restrict__ vals_dst,                 // final buffer (half 0)
+                 u64* __restrict__ keys_tmp, u32* __restrict__ vals_tmp)                 // scratch for long segments
 {
     __shared__ u32 cnt[F3DG_BLOCK / 64][256];
     __shared__ u32 cursor[256];
@@ -304,18 +340,20 @@ tile_sort_kernel(const uint2* __restrict__ ranges, u32 n_segments, const F3dgHea
     for (u32 seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
         const uint2 range = ranges[seg];
         const u32 n = range.y - range.x;
-        if (n <= 1) continue;
+        if (n == 0) continue;
+        const u32 src0 = gstart[seg];
         __syncthreads();
 
         if (n <= F3DG_TILE_SORT_CAP) {
             // ---------------- LDS-resident path
+            const u64 hi = keys_src[src0] & 0xFFFFFFFF00000000ull;       // (view, tile) bits: constant over the segment
             for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
-                sdepth[0][i] = (u32)keys_a[range.x + i];
-                sval[0][i] = vals_a[range.x + i];
+                sdepth[0][i] = (u32)keys_src[src0 + i];
+                sval[0][i] = vals_src[src0 + i];
             }
             int cur = 0;
             const u32 wave_base = (u32)wave * (64 * F3DG_SORT_ITEMS);
-            for (int pass = 0; pass < 4; pass++) {
+            for (int pass = 0; pass < 4 && n > 1; pass++) {
                 const int shift = 8 * pass;
 #pragma unroll
                 for (int w = 0; w < F3DG_BLOCK / 64; w++) cnt[w][threadIdx.x] = 0;
@@ -366,18 +404,23 @@ tile_sort_kernel(const uint2* __restrict__ ranges, u32 n_segments, const F3dgHea
                 cur ^= 1;
                 __syncthreads();
             }
-            const u64 hi = (u64)seg << 32;
             for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
-                vals_a[range.x + i] = sval[cur][i];
-                keys_a[range.x + i] = hi | sdepth[cur][i];
+                vals_dst[range.x + i] = sval[cur][i];
+                keys_dst[range.x + i] = hi | sdepth[cur][i];
             }
             continue;
         }
 
-        // ---------------- long segment: ping-pong over its slice of the two global halves
-        u64* ksrc = keys_a + range.x; u32* vsrc = vals_a + range.x;
-        u64* kdst = keys_b + range.x; u32* vdst = vals_b + range.x;
-        bool in_a = true;
+        // ---------------- long segment: copy to the scratch slice, then ping-pong scratch <-> final slice
+        for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
+            keys_tmp[range.x + i] = keys_src[src0 + i];
+            vals_tmp[range.x + i] = vals_src[src0 + i];
+        }
+        __threadfence_block();
+        __syncthreads();
+        u64* ksrc = keys_tmp + range.x; u32* vsrc = vals_tmp + range.x;
+        u64* kdst = keys_dst + range.x; u32* vdst = vals_dst + range.x;
+        bool in_dst = false;
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 8 * pass;
             // digit histogram of the whole segment (wave-aggregated: one LDS add per distinct digit per wave round)
@@ -454,34 +497,13 @@ tile_sort_kernel(const uint2* __restrict__ ranges, u32 n_segments, const F3dgHea
                 __syncthreads();
             }
             { u64* tk = ksrc; ksrc = kdst; kdst = tk; u32* tv = vsrc; vsrc = vdst; vdst = tv; }
-            in_a = !in_a;
+            in_dst = !in_dst;
             __threadfence_block();
             __syncthreads();
         }
-        if (!in_a) {                                  // an odd number of passes moved data: bring the result home
+        if (!in_dst) {                                // an even number of passes moved data: the result sits in the scratch
             for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) { kdst[i] = ksrc[i]; vdst[i] = vsrc[i]; }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ ranges
-__global__ void __launch_bounds__(F3DG_BLOCK)
-tile_ranges_kernel(const u64* __restrict__ keys, const F3dgHeader* __restrict__ hdr, uint2* __restrict__ ranges)
-{
-    const u32 L = hdr->overflow ? 0u : hdr->num_rendered;
-    for (u64 idx = (u64)blockIdx.x * F3DG_BLOCK + threadIdx.x; idx < L; idx += (u64)gridDim.x * F3DG_BLOCK) {
-        const u32 currtile = (u32)(keys[idx] >> 32);
-        if (idx == 0)
-            ranges[currtile].x = 0;
-        else {
-            const u32 prevtile = (u32)(keys[idx - 1] >> 32);
-            if (currtile != prevtile) {
-                ranges[prevtile].y = (u32)idx;
-                ranges[currtile].x = (u32)idx;
-            }
-        }
-        if (idx == L - 1)
-            ranges[currtile].y = L;
     }
 }
 
@@ -507,40 +529,47 @@ int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out,
     return F3DG_OK;
 }
 
-// Number of 8-bit GLOBAL passes: only the (view, tile) bits are sorted globally; the 32 depth bits are sorted per
-// tile by tile_sort_kernel.
+int f3dg_tile_bits(int T) { return bits_for((unsigned long long)T); }
+
+// Number of 8-bit GLOBAL passes: only the tile bits are sorted globally (instances are generated in view order); the 32
+// depth bits are sorted per (view, tile) group by tile_sort_kernel.
 int f3dg_sort_passes(int V, int T)
 {
-    const int bits = bits_for((unsigned long long)V * (unsigned long long)T);
-    return (bits + 7) / 8;
+    (void)V;
+    const int bits = f3dg_tile_bits(T);
+    return bits == 0 ? 0 : (bits + 7) / 8;
 }
 
 int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = grid_x * grid_y;
+    const int tile_bits = f3dg_tile_bits(T);
     F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
     u32* tiles = reinterpret_cast<u32*>(ws + L.tiles);
     u32* offsets = reinterpret_cast<u32*>(ws + L.offsets);
     u32* scan_tmp = reinterpret_cast<u32*>(ws + L.scan_tmp);
-    u64* keys[2] = { reinterpret_cast<u64*>(ws + L.keys[0]), reinterpret_cast<u64*>(ws + L.keys[1]) };
-    u32* vals[2] = { reinterpret_cast<u32*>(ws + L.vals[0]), reinterpret_cast<u32*>(ws + L.vals[1]) };
+    u64* keys[3] = { reinterpret_cast<u64*>(ws + L.keys[0]), reinterpret_cast<u64*>(ws + L.keys[1]), reinterpret_cast<u64*>(ws + L.keys[2]) };
+    u32* vals[3] = { reinterpret_cast<u32*>(ws + L.vals[0]), reinterpret_cast<u32*>(ws + L.vals[1]), reinterpret_cast<u32*>(ws + L.vals[2]) };
     u32* hist = reinterpret_cast<u32*>(ws + L.hist);
     uint2* ranges = reinterpret_cast<uint2*>(ws + L.ranges);
+    u32* gstart = reinterpret_cast<u32*>(ws + L.gstart);
+    u32* gend = reinterpret_cast<u32*>(ws + L.gend);
+    u32* gcount = reinterpret_cast<u32*>(ws + L.gcount);
+    const u32 nseg = (u32)V * (u32)T;
 
     // 1. inclusive prefix sum of tiles_touched over all (view, Gaussian); total -> header (+ overflow flag)
     int rc = f3dg_launch_scan_inclusive(s, tiles, offsets, (unsigned long long)V * P, scan_tmp, L.scan_tmp_elems, 0, hdr);
     if (rc != F3DG_OK) return rc;
 
-    // 2. keys/values into ping-pong half `src`; chosen so that the last global pass lands in half 0
+    // 2. keys/values, generated in (view, Gaussian) order, into the half from which the tile pass(es) end in half 1
     const int passes = f3dg_sort_passes(V, T);
-    int src = passes & 1;
-    hipLaunchKernelGGL(duplicate_keys_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V), dim3(F3DG_BLOCK), 0, s, P, T,
+    int src = (passes & 1) ? 0 : 1;
+    hipLaunchKernelGGL(duplicate_keys_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V), dim3(F3DG_BLOCK), 0, s, P, tile_bits,
                        grid_x, grid_y, reinterpret_cast<const float2*>(ws + L.means2D),
                        reinterpret_cast<const F3dgRec*>(ws + L.rec), offsets, radii, hdr, keys[src], vals[src]);
 
-    // 3a. level 1: stable LSD radix passes over the (view, tile) bits only (bits 32 and up), 8 bits per pass.
-    //     Within a (view, tile) segment the instances stay in generation order = ascending Gaussian id.
+    // 3. level 1: stable LSD radix pass(es) over the TILE bits only, 8 bits per pass (one pass up to 256 tiles)
     const u32 nb = L.sort_blocks;
     for (int p = 0; p < passes; p++) {
         const int shift = 32 + 8 * p;
@@ -551,16 +580,19 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
                            vals[src ^ 1], hdr, shift, nb, hist);
         src ^= 1;
     }
-    // grouped-by-tile result is now in half 0 (src == 0)
+    // tile-grouped instances are now in half 1 (src == 1); every (tile, view) group is contiguous, in Gaussian-id order
 
-    // 4. tile ranges (they depend on the tile bits only)
-    F3DG_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)V * T, s));
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(2048), dim3(F3DG_BLOCK), 0, s, keys[0], hdr, ranges);
+    // 4. (view, tile) group bounds -> final ranges by a scan over the groups in (view, tile) order
+    F3DG_HIP_CHECK(hipMemsetAsync(gstart, 0, sizeof(u32) * 2 * (size_t)nseg, s));      // gstart[nseg] + gend[nseg], adjacent
+    hipLaunchKernelGGL(group_bounds_kernel, dim3(2048), dim3(F3DG_BLOCK), 0, s, keys[1], hdr, tile_bits, T, gstart, gend);
+    hipLaunchKernelGGL(group_counts_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gstart, gend, gcount);
+    rc = f3dg_launch_scan_inclusive(s, gcount, hist /* reuse as gcum */, nseg, scan_tmp, L.scan_tmp_elems, 0, nullptr);
+    if (rc != F3DG_OK) return rc;
+    hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges);
 
-    // 3b. level 2: per-(view, tile) stable sort by the depth bits, in place in half 0 (half 1 is its scratch)
-    const u32 nseg = (u32)V * (u32)T;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg < 65535u * 16u ? nseg : 65535u * 16u), dim3(F3DG_BLOCK), 0, s, ranges, nseg,
-                       hdr, keys[0], vals[0], keys[1], vals[1]);
+    // 5. level 2: per-(view, tile) stable sort by the depth bits: gather the group from half 1, write it sorted to half 0
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg < 65535u * 16u ? nseg : 65535u * 16u), dim3(F3DG_BLOCK), 0, s, ranges, gstart,
+                       nseg, hdr, keys[1], vals[1], keys[0], vals[0], keys[2], vals[2]);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

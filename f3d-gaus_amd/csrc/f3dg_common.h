@@ -48,8 +48,9 @@ struct F3dgLayout {
     size_t offsets;        // [V*P] u32   inclusive scan of tiles_touched
     size_t clamped;        // [V*P] u8    bit c set when SH colour channel c was clamped
     size_t scan_tmp;       // u32 block sums for the scans
-    size_t keys[2];        // [cap] u64 ping-pong
-    size_t vals[2];        // [cap] u32 ping-pong
+    size_t keys[3];        // [cap] u64: [0] final (tile, depth)-sorted, [1] tile-grouped / ping-pong, [2] scratch of long tile sorts
+    size_t vals[3];        // [cap] u32, same roles; vals[0] is the compositing kernel's point list
+    size_t gstart, gend, gcount;   // [V*T] u32 each: (view, tile) group bounds in the tile-grouped buffer and sizes
     size_t hist;           // [256 * sort_blocks] u32
     size_t ranges;         // [V*T] uint2
     size_t final_T;        // [V][4][H*W] float

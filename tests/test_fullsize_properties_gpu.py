@@ -33,7 +33,10 @@ def test_c2_full_size_properties(gpu_device):
     assert (np.diff(keys.astype(np.uint64)) >= 0).all()                                   # sorted by (view, tile, depth)
     ties = np.diff(keys.astype(np.uint64)) == 0
     assert (np.diff(pl.astype(np.int64))[ties] > 0).all()                                 # stable: ties by Gaussian id
-    seg = (keys >> np.uint64(32)).astype(np.int64)
+    tb = int(T - 1).bit_length()                          # key = ((view << tile_bits) | tile) << 32 | depth bits
+    hi = (keys >> np.uint64(32)).astype(np.int64)
+    seg = (hi >> tb) * T + (hi & ((1 << tb) - 1))
+    assert (np.diff(seg) >= 0).all()
     counts = np.bincount(seg, minlength=V * T)
     rng_ = h["ranges"].reshape(V * T, 2).astype(np.int64)
     assert np.array_equal(rng_[:, 1] - rng_[:, 0], counts)                                # ranges = segment sizes

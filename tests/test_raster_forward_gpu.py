@@ -80,8 +80,10 @@ def test_forward_batched_views_equal_single_views(gpu_device):
         seg = h["point_list"][total:total + R]
         assert np.array_equal(seg, o["point_list"]), f"view {v} point list"
         assert np.array_equal(h["ranges"][v] - np.uint32(total) * (h["ranges"][v].sum(1, keepdims=True) > 0), o["ranges"])
-        assert np.array_equal((h["keys_sorted"][total:total + R] >> np.uint64(32)) - np.uint64(v * T),
-                              o["keys_sorted"] >> np.uint64(32))
+        tb = int(T - 1).bit_length()                      # key = ((view << tile_bits) | tile) << 32 | depth bits
+        hi = (h["keys_sorted"][total:total + R] >> np.uint64(32)).astype(np.int64)
+        assert (hi >> tb == v).all() and np.array_equal(hi & ((1 << tb) - 1), (o["keys_sorted"] >> np.uint64(32)).astype(np.int64))
+        assert np.array_equal(h["keys_sorted"][total:total + R] & np.uint64(0xFFFFFFFF), o["keys_sorted"] & np.uint64(0xFFFFFFFF))
         assert_render_parity(h["out_color"][v], o["out_color"], f"view{v}")
         total += R
     assert total == h["num_rendered"]
