@@ -131,6 +131,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.rec = take(VP * sizeof(F3dgRec));
     L.means2D = take(VP * sizeof(float2));
     L.bbox = take(VP * sizeof(float4));
+    L.depths = take(VP * sizeof(float));
     L.conic = take(VP * sizeof(float4));
     L.radii = take(VP * sizeof(int));
     L.tiles = take(VP * sizeof(unsigned));
@@ -211,7 +212,7 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
                                     reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
-                                    reinterpret_cast<float4*>(ws + L.bbox),
+                                    reinterpret_cast<float*>(ws + L.depths), reinterpret_cast<float4*>(ws + L.bbox),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
                                     reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);

@@ -116,7 +116,7 @@ scan_apply_kernel(const u32* in, u32* out /* may alias in */, u64 n, const u32* 
 // ------------------------------------------------------------------------------------------------ keys
 __global__ void __launch_bounds__(F3DG_BLOCK)
 duplicate_keys_kernel(int P, int tile_bits, int grid_x, int grid_y, const float2* __restrict__ means2D,
-                      const F3dgRec* __restrict__ rec, const u32* __restrict__ offsets,
+                      const float* __restrict__ depths, const u32* __restrict__ offsets,
                       const int* __restrict__ radii, const F3dgHeader* __restrict__ hdr,
                       u64* __restrict__ keys, u32* __restrict__ vals)
 {
@@ -133,7 +133,7 @@ duplicate_keys_kernel(int P, int tile_bits, int grid_x, int grid_y, const float2
         const int rminy = min(grid_y, max(0, (int)((p.y - radius) / F3DG_TILE)));
         const int rmaxx = min(grid_x, max(0, (int)((p.x + radius + F3DG_TILE - 1) / F3DG_TILE)));
         const int rmaxy = min(grid_y, max(0, (int)((p.y + radius + F3DG_TILE - 1) / F3DG_TILE)));
-        const u32 depth_bits = __float_as_uint(rec[idx].f[15]);
+        const u32 depth_bits = __float_as_uint(depths[idx]);
         const u64 view_base = (u64)v << tile_bits;
         for (int y = rminy; y < rmaxy; y++)
             for (int x = rminx; x < rmaxx; x++) {
@@ -269,18 +269,21 @@ radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ va
 //     12 B read + 4 B written per instance of global traffic instead of four more 24-B trips through HBM;
 //   * longer segments fall back to ping-pong passes over their own slice of the two global halves (just written, so
 //     L2 / Infinity-Cache resident), chunk by chunk with running per-digit cursors.
-// A pass whose digit is constant over the segment (typically the exponent byte) moves nothing.
+// The LDS path first ORs (key ^ first key) over the segment: only the depth bits that actually vary inside the tile are
+// sorted, in ceil(bits/9) passes of <= 9 bits (three passes for the 25 varying bits of depths in [6.7, 8.7], not four).
 #define F3DG_TILE_SORT_CAP F3DG_SORT_CHUNK
 
 // stable in-wave ranking of one digit per lane; returns the lane's rank among equal digits seen so far by this wave
-__device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 lane_lt)
+__device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 lane_lt, int digit_bits = 8)
 {
     u64 same = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const bool bit = (d >> b) & 1u;
-        const u64 bal = __ballot(bit);
-        same &= bit ? bal : ~bal;
+    for (int b = 0; b < 9; b++) {
+        if (b < digit_bits) {                 // wave-uniform
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
     }
     const u32 below = (u32)__popcll(same & lane_lt);
     const u32 prev = wave_cnt[d];
@@ -327,7 +330,7 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
                  u64* __restrict__ keys_dst, u32* __restrict__ vals_dst,                 // final buffer (half 0)
                  u64* __restrict__ keys_tmp, u32* __restrict__ vals_tmp)                 // scratch for long segments
 {
-    __shared__ u32 cnt[F3DG_BLOCK / 64][256];
+    __shared__ u32 cnt[F3DG_BLOCK / 64][512];          // per-wave digit counters (up to 9-bit digits in the LDS path)
     __shared__ u32 cursor[256];
     __shared__ u32 wtot[F3DG_BLOCK / 64];
     __shared__ u32 skip_flag;
@@ -346,18 +349,43 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
 
         if (n <= F3DG_TILE_SORT_CAP) {
             // ---------------- LDS-resident path
-            const u64 hi = keys_src[src0] & 0xFFFFFFFF00000000ull;       // (view, tile) bits: constant over the segment
-            for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
-                sdepth[0][i] = (u32)keys_src[src0 + i];
-                sval[0][i] = vals_src[src0 + i];
+            const u64 first = keys_src[src0];
+            const u64 hi = first & 0xFFFFFFFF00000000ull;               // (view, tile) bits: constant over the segment
+            u32 diff = 0;
+            {
+                // all of this thread's global loads are issued before the first one is consumed (the segment is short:
+                // a dependent load per loop trip would serialise ~10 memory latencies per workgroup)
+                u32 kd[F3DG_SORT_ITEMS], vv[F3DG_SORT_ITEMS];
+#pragma unroll
+                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
+                    const u32 i = threadIdx.x + (u32)r * F3DG_BLOCK;
+                    kd[r] = i < n ? (u32)keys_src[src0 + i] : (u32)first;
+                    vv[r] = i < n ? vals_src[src0 + i] : 0u;
+                }
+#pragma unroll
+                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
+                    const u32 i = threadIdx.x + (u32)r * F3DG_BLOCK;
+                    if (i < n) { sdepth[0][i] = kd[r]; sval[0][i] = vv[r]; }
+                    diff |= kd[r] ^ (u32)first;
+                }
             }
+            // number of depth bits that actually vary inside this tile -> as few, as narrow (<= 9 bit) passes as possible
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) diff |= __shfl_xor(diff, m, 64);
+            if (lane == 0) wtot[wave] = diff;
+            __syncthreads();
+            diff = wtot[0] | wtot[1] | wtot[2] | wtot[3];
+            const int vbits = diff ? 32 - __builtin_clz(diff) : 0;
+            const int npass = (vbits + 8) / 9;
+            const int dbits = npass ? (vbits + npass - 1) / npass : 0;   // <= 9
+            const u32 dmask = (1u << dbits) - 1u;
             int cur = 0;
             const u32 wave_base = (u32)wave * (64 * F3DG_SORT_ITEMS);
-            for (int pass = 0; pass < 4 && n > 1; pass++) {
-                const int shift = 8 * pass;
-#pragma unroll
-                for (int w = 0; w < F3DG_BLOCK / 64; w++) cnt[w][threadIdx.x] = 0;
-                if (threadIdx.x == 0) skip_flag = 0;
+            for (int pass = 0; pass < npass; pass++) {
+                const int shift = dbits * pass;
+                __syncthreads();
+                cnt[0][threadIdx.x] = 0; cnt[0][threadIdx.x + 256] = 0; cnt[1][threadIdx.x] = 0; cnt[1][threadIdx.x + 256] = 0;
+                cnt[2][threadIdx.x] = 0; cnt[2][threadIdx.x + 256] = 0; cnt[3][threadIdx.x] = 0; cnt[3][threadIdx.x + 256] = 0;
                 __syncthreads();
                 u32 dk[F3DG_SORT_ITEMS], rank[F3DG_SORT_ITEMS];
 #pragma unroll
@@ -367,46 +395,51 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
                     if (wave_base + (u32)r * 64 < n) {           // wave-uniform
                         const bool valid = i < n;
                         dk[r] = valid ? sdepth[cur][i] : 0xFFFFFFFFu;
-                        rank[r] = wave_rank((dk[r] >> shift) & 255u, valid, cnt[wave], lane_lt);
+                        rank[r] = wave_rank((dk[r] >> shift) & dmask, valid, cnt[wave], lane_lt, dbits);
                     }
                 }
                 __syncthreads();
                 {
-                    const u32 d = threadIdx.x;
-                    const u32 c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
-                    const u32 tot = c0 + c1 + c2 + c3;
-                    if (tot == n) skip_flag = 1;
-                    u32 x = tot;
+                    // thread t owns digits 2t and 2t+1: chunk-wide exclusive scan over the (up to) 512 digits
+                    const u32 d0 = 2u * threadIdx.x, d1 = d0 + 1u;
+                    const u32 a0 = cnt[0][d0], a1 = cnt[1][d0], a2 = cnt[2][d0], a3 = cnt[3][d0];
+                    const u32 b0 = cnt[0][d1], b1 = cnt[1][d1], b2 = cnt[2][d1], b3 = cnt[3][d1];
+                    const u32 t0 = a0 + a1 + a2 + a3, t1 = b0 + b1 + b2 + b3;
+                    u32 x = t0 + t1;
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
                         const u32 y = __shfl_up(x, off, 64);
                         if (lane >= off) x += y;
                     }
+                    __syncthreads();
                     if (lane == 63) wtot[wave] = x;
                     __syncthreads();
-                    u32 excl = x - tot;
-                    for (int w = 0; w < wave; w++) excl += wtot[w];
-                    cnt[0][d] = excl; cnt[1][d] = excl + c0; cnt[2][d] = excl + c0 + c1; cnt[3][d] = excl + c0 + c1 + c2;
+                    u32 e0 = x - (t0 + t1);
+                    for (int w = 0; w < wave; w++) e0 += wtot[w];
+                    const u32 e1 = e0 + t0;
+                    cnt[0][d0] = e0; cnt[1][d0] = e0 + a0; cnt[2][d0] = e0 + a0 + a1; cnt[3][d0] = e0 + a0 + a1 + a2;
+                    cnt[0][d1] = e1; cnt[1][d1] = e1 + b0; cnt[2][d1] = e1 + b0 + b1; cnt[3][d1] = e1 + b0 + b1 + b2;
                 }
                 __syncthreads();
-                const bool skip_pass = skip_flag != 0;
-                __syncthreads();              // everyone has read the flag before the next pass resets it
-                if (skip_pass) continue;
 #pragma unroll
                 for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
                     const u32 i = wave_base + (u32)r * 64 + lane;
                     if (i < n) {
-                        const u32 pos = cnt[wave][(dk[r] >> shift) & 255u] + rank[r];
+                        const u32 pos = cnt[wave][(dk[r] >> shift) & dmask] + rank[r];
                         sdepth[cur ^ 1][pos] = dk[r];
                         sval[cur ^ 1][pos] = sval[cur][i];
                     }
                 }
                 cur ^= 1;
-                __syncthreads();
             }
-            for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
-                vals_dst[range.x + i] = sval[cur][i];
-                keys_dst[range.x + i] = hi | sdepth[cur][i];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
+                const u32 i = threadIdx.x + (u32)r * F3DG_BLOCK;
+                if (i < n) {
+                    vals_dst[range.x + i] = sval[cur][i];
+                    keys_dst[range.x + i] = hi | sdepth[cur][i];
+                }
             }
             continue;
         }
@@ -567,7 +600,7 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
     int src = (passes & 1) ? 0 : 1;
     hipLaunchKernelGGL(duplicate_keys_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V), dim3(F3DG_BLOCK), 0, s, P, tile_bits,
                        grid_x, grid_y, reinterpret_cast<const float2*>(ws + L.means2D),
-                       reinterpret_cast<const F3dgRec*>(ws + L.rec), offsets, radii, hdr, keys[src], vals[src]);
+                       reinterpret_cast<const float*>(ws + L.depths), offsets, radii, hdr, keys[src], vals[src]);
 
     // 3. level 1: stable LSD radix pass(es) over the TILE bits only, 8 bits per pass (one pass up to 256 tiles)
     const u32 nb = L.sort_blocks;

@@ -41,6 +41,7 @@ struct F3dgLayout {
     size_t header;
     size_t rec;            // [V*P] F3dgRec
     size_t means2D;        // [V*P] float2
+    size_t depths;         // [V*P] float: view-space depth again, compact, for key generation (4 B instead of a 64-B record line)
     size_t bbox;           // [V*P] float4: conservative pixel-space box (x0,x1,y0,y1) outside of which alpha < 1/255 is certain
     size_t conic;          // [V*P] float4 (conic.xyz, opacity*coef) -- backward only
     size_t radii;          // [V*P] int   (internal copy when the caller passes none)
@@ -78,8 +79,8 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float4* bbox, float4* conic, int* radii, unsigned* tiles,
-                           unsigned char* clamped, int save_aux);
+                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox, float4* conic, int* radii,
+                           unsigned* tiles, unsigned char* clamped, int save_aux);
 
 int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out, unsigned long long n,
                                unsigned* tmp, unsigned tmp_elems, int exclusive,

@@ -122,7 +122,8 @@ preprocess_kernel(int P, int D, int M,
                   const float* __restrict__ viewmatrices, const float* __restrict__ projmatrices,
                   const float* __restrict__ cam_positions, int W, int H, int grid_x, int grid_y,
                   float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                  F3dgRec* __restrict__ rec, float2* __restrict__ means2D, float4* __restrict__ bbox_out,
+                  F3dgRec* __restrict__ rec, float2* __restrict__ means2D, float* __restrict__ depths_out,
+                  float4* __restrict__ bbox_out,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
                   unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all)
@@ -356,6 +357,7 @@ preprocess_kernel(int P, int D, int M,
     radii[idx] = my_radii;
     tiles_touched[idx] = my_tiles;
     means2D[idx] = xy;
+    depths_out[idx] = r3.w;
     bbox_out[idx] = box;
     float4* dst = reinterpret_cast<float4*>(rec + idx);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
@@ -382,15 +384,15 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float4* bbox, float4* conic, int* radii, unsigned* tiles,
-                           unsigned char* clamped, int save_aux)
+                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox, float4* conic, int* radii,
+                           unsigned* tiles, unsigned char* clamped, int save_aux)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
-                       bbox, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
+                       depths, bbox, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
