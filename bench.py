@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--sigma0", type=float, default=0.01)
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("F3DG_VIEWS_PER_CALL", "120")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("F3DG_STREAMS", "1")),
+                    help="HIP streams the view chunks are distributed over (chunk i -> stream i %% streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
     return ap.parse_args()
@@ -72,9 +74,10 @@ def main():
     radii = torch.empty((V, P), dtype=torch.int32, device=device)
     chunks = [(a, min(a + args.views_per_call, V)) for a in range(0, V, args.views_per_call)]
     workspaces = {}
+    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
 
     def render_chunk(a, b, check):
-        ws = workspaces.get(b - a)
+        ws = workspaces.get((a, b) if streams else b - a)
         o, r, ws = f3d.rasterize_views(
             g["xyz"], g["opacity"], cams["viewmatrix"][a:b], cams["projmatrix"][a:b], cams["campos"][a:b], bg,
             image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs,
@@ -89,7 +92,12 @@ def main():
         counts.append((b - a, ws.num_rendered))
     for n in set(c[0] for c in counts):
         cap = int(max(c[1] for c in counts if c[0] == n) * 1.25) + 4096
-        workspaces[n] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
+        if streams:      # concurrent chunks need their own workspace
+            for (a, b) in chunks:
+                if b - a == n:
+                    workspaces[(a, b)] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
+        else:
+            workspaces[n] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
     R_total = sum(c[1] for c in counts)
 
     gather_buf = None
@@ -97,8 +105,18 @@ def main():
         gather_buf = [torch.empty((V, 3, RES, RES), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
 
     def step():
-        for a, b in chunks:
-            render_chunk(a, b, check=False)
+        if streams:
+            main = torch.cuda.current_stream()
+            for i, (a, b) in enumerate(chunks):
+                st = streams[i % len(streams)]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    render_chunk(a, b, check=False)
+            for st in streams:
+                main.wait_stream(st)
+        else:
+            for a, b in chunks:
+                render_chunk(a, b, check=False)
         if world > 1:     # final gather of the RGB frames (the only exchange of the path)
             dist.gather(out[:, :3].contiguous(), gather_buf, dst=0)
 

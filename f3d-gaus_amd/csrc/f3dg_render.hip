@@ -114,10 +114,15 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 {
     // XCD-aware placement: consecutive workgroup ids land on different XCDs (id % 8), so give every XCD its
     // own views: all tiles of a view then share one XCD's L2 for the record gather.
+#ifdef F3DG_PLAIN_MAP
+    const unsigned view = blockIdx.x / (unsigned)T;
+    const unsigned tile = blockIdx.x % (unsigned)T;
+#else
     const unsigned xcd = blockIdx.x & 7u;
     const unsigned slot = blockIdx.x >> 3;
     const unsigned view = (slot / (unsigned)T) * 8u + xcd;
     const unsigned tile = slot % (unsigned)T;
+#endif
     if (view >= (unsigned)V)
         return;
 
