@@ -52,14 +52,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
+    # F3DG_DIST_BACKEND=gloo is a functional check of the N>1 logic on a box with fewer GPUs than ranks (ranks share
+    # devices, frames are gathered through host memory); the measured configuration is always nccl = RCCL.
+    backend = os.environ.get("F3DG_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    comm_device = device if backend == "nccl" else torch.device("cpu")
 
     import f3dgaus_amd as f3d
     from f3dgaus_amd import _lib, synthetic
@@ -100,9 +105,14 @@ def main():
             workspaces[n] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
     R_total = sum(c[1] for c in counts)
 
+    # final exchange of the path: the rendered frames go to rank 0 as 8-bit RGB, which is what the reference turns every
+    # frame into before writing the video (visualize.py:416); 120 x 3 x 256 x 256 B = 23.6 MB per rank and step. The
+    # gather is asynchronous on RCCL's stream and overlaps the next step's rendering; all of them are waited for inside
+    # the timed region.
     gather_buf = None
+    pending = []
     if world > 1:
-        gather_buf = [torch.empty((V, 3, RES, RES), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+        gather_buf = [torch.empty((V, 3, RES, RES), dtype=torch.uint8, device=comm_device) for _ in range(world)] if rank == 0 else None
 
     def step():
         if streams:
@@ -118,9 +128,15 @@ def main():
             for a, b in chunks:
                 render_chunk(a, b, check=False)
         if world > 1:     # final gather of the RGB frames (the only exchange of the path)
-            dist.gather(out[:, :3].contiguous(), gather_buf, dst=0)
+            frames = (out[:, :3].clamp(0, 1) * 255.0).to(torch.uint8).to(comm_device)
+            work = dist.gather(frames, gather_buf, dst=0, async_op=True)
+            pending.append((work, frames))
+            while len(pending) > 1:           # at most one gather in flight behind the current step
+                pending.pop(0)[0].wait()
 
     def barrier():
+        while pending:
+            pending.pop(0)[0].wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -141,7 +157,7 @@ def main():
     for n, ws in workspaces.items():      # no overflow happened in the timed region
         f3d.diff_gof_rasterization.read_status(ws)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device if world > 1 else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

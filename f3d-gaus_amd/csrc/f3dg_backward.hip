@@ -132,19 +132,28 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
             const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
-            const double AA = ray_x * n0 + ray_y * n1 + n2;
-            const double BB = 2 * (q1.z * ray_x + q1.w * ray_y + q2.x);
-            const float CC = q2.y;
-            const float t = (float)(-BB / (2 * AA));
-            if (t <= F3DG_NEAR_PLANE) active = false;
-            const double min_value = -(BB / AA) * (BB / 4.) + CC;
-            float power = (float)(-0.5f * min_value);
-            if (power > 0.0f) power = 0.0f;
-            const float G = expf(power);
-            const float alpha = fminf(0.99f, q2.z * G);
-            if (alpha < 1.0f / 255.0f) active = false;
+            const float aaf = ray_x * n0 + ray_y * n1 + n2;
+            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+            // the forward's conservative pre-test (f3dg_render.hip): a true test proves alpha < 1/255, i.e. `continue`
+            if (bhalf * bhalf < q2.w * aaf) active = false;
+            if (__ballot(active) == 0)      // no pixel of this strip can contribute: skip before any float64 / expf work
+                continue;
 
-            if (__ballot(active) == 0)      // no pixel of this 16x4 strip contributes: nothing to do for the wave
+            const double AA = aaf;
+            const double BB = 2 * bhalf;
+            const float CC = q2.y;
+            float t = 0, G = 0, alpha = 0;
+            if (active) {
+                t = (float)(-BB / (2 * AA));
+                if (t <= F3DG_NEAR_PLANE) active = false;
+                const double min_value = -(BB / AA) * (BB / 4.) + CC;
+                float power = (float)(-0.5f * min_value);
+                if (power > 0.0f) power = 0.0f;
+                G = expf(power);
+                alpha = fminf(0.99f, q2.z * G);
+                if (alpha < 1.0f / 255.0f) active = false;
+            }
+            if (__ballot(active) == 0)
                 continue;
 
             float g_col0 = 0, g_col1 = 0, g_col2 = 0, g_mx = 0, g_my = 0, g_mz = 0, g_op = 0;
