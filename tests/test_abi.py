@@ -71,3 +71,23 @@ def test_python_api_errors_without_gpu(f3d):
     with pytest.raises(RuntimeError, match="HIP device"):       # no silent CPU fallback
         r(means3D=x, means2D=x, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 4, 3), scales=x,
           rotations=torch.zeros(4, 4))
+
+
+def test_missing_extension_fails_loudly(f3d, monkeypatch, tmp_path):
+    """No silent CPU / PyTorch fallback: without the built HIP library the binding raises."""
+    from f3dgaus_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libf3dg_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        _lib.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    import re
+    pkg = os.path.join(ROOT, "f3d-gaus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
+                assert "libgof_oracle" not in txt, os.path.join(dirpath, f)
