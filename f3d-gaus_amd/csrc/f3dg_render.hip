@@ -24,11 +24,11 @@
 //    alpha < 1/255 and the pair is skipped before any float64 instruction, expf or divide. NaN falls through to the
 //    exact path. The tests run
 //    every scene with the pre-test on and off and require bit-identical outputs.
-//  * per-wave culling. A tile's list holds every Gaussian whose 3-sigma SQUARE touches the 16x16 tile, but a wave
-//    owns an 8x8 quadrant and only ~1/3 of the (quadrant, Gaussian) pairs contain a pixel with alpha >= 1/255. The staging
+//  * per-group culling. A tile's list holds every Gaussian whose 3-sigma SQUARE touches the 16x16 tile, but a 16-lane
+//    group owns a 4x4 pixel block and only ~1/5 of the (block, Gaussian) pairs contain a pixel with alpha >= 1/255. The staging
 //    thread therefore also fetches the Gaussian's conservative alpha >= 1/255 box (f3dg_preprocess.hip) and publishes
-//    a 4-bit strip mask; each wave compacts the 256 staged entries to its own index list with ballots and walks only
-//    those. Skipped entries would have been a bare `continue` for all 64 lanes, and `contributor` is set from the
+//    a 16-bit block mask; each wave compacts the 256 staged entries into FOUR index lists (one per 16-lane group) with
+//    ballots, and every group walks only its own (per-lane LDS addresses; a broadcast inside the group). Skipped entries would have been a bare `continue` for all 64 lanes, and `contributor` is set from the
 //    entry's position, so every output and auxiliary plane is bit-identical (asserted with the option on and off).
 //  * per-lane work queues. After the two filters above the expensive exact path still ran with ~1/4 of the lanes
 //    active, because a wave executes it whenever ANY of its 64 pixels passes. The loop is therefore split in two
@@ -104,6 +104,8 @@ __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor
     return false;
 }
 
+#define F3DG_ROUND (F3DG_BLOCK - 1)     // list entries staged per round; LDS slot F3DG_ROUND is the sentinel
+
 template <bool SAVE_AUX, bool PRETEST, bool CULL, bool QUEUE>
 __global__ void __launch_bounds__(F3DG_BLOCK, 8)
 render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
@@ -127,10 +129,12 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
         return;
 
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
-    // each wave owns an 8x8 pixel quadrant of the tile (not a 16x4 strip): the more compact footprint is touched by
-    // ~12 % fewer Gaussians, which is what the per-wave culling below removes
+    // each wave owns an 8x8 pixel quadrant of the tile and each of its four 16-lane groups a 4x4 block of it: the culled
+    // entry lists below are kept PER 16-LANE GROUP (a 4x4 block is touched by ~40 % fewer Gaussians than an 8x8 quadrant)
     const unsigned lane_ = threadIdx.x & 63u, wave_ = threadIdx.x >> 6;
-    const unsigned lx = (wave_ & 1u) * 8u + (lane_ & 7u), ly = (wave_ >> 1) * 8u + (lane_ >> 3);
+    const unsigned grp_ = lane_ >> 4, gi_ = lane_ & 15u;
+    const unsigned blk_x = (wave_ & 1u) * 2u + (grp_ & 1u), blk_y = (wave_ >> 1) * 2u + (grp_ >> 1);    // 4x4 block in tile
+    const unsigned lx = blk_x * 4u + (gi_ & 3u), ly = blk_y * 4u + (gi_ >> 2);
     const unsigned pix_x = tile_x * F3DG_TILE + lx, pix_y = tile_y * F3DG_TILE + ly;
     const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
     const size_t HW = (size_t)H * W;
@@ -141,16 +145,29 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 
     uint2 range = ranges[(size_t)view * T + tile];
     if (hdr->overflow) range = make_uint2(0, 0);
-    const int rounds = (int)((range.y - range.x + F3DG_BLOCK - 1) / F3DG_BLOCK);
+    const int rounds = (int)((range.y - range.x + F3DG_ROUND - 1) / F3DG_ROUND);
     int toDo = (int)(range.y - range.x);
 
     // 256 staged records, structure-of-arrays by float4 so that per-lane (divergent) reads spread over the banks
+    // A round stages F3DG_ROUND = 255 list entries; slot 255 holds the sentinel record that pads the culled lists (so
+    // that list entries fit a byte and the whole block fits 20 KB of LDS = 8 blocks per CU).
     __shared__ float4 sq0[F3DG_BLOCK];            // v0 v1 v2 v3
     __shared__ float4 sq1[F3DG_BLOCK];            // v4 v5 v6 v7
     __shared__ float4 sq2[F3DG_BLOCK];            // v8 v9 opac thr
-    __shared__ float4 sq3[F3DG_BLOCK];            // r g b depth
-    __shared__ unsigned char strip_mask[CULL ? F3DG_BLOCK : 1];
-    __shared__ unsigned short wave_list[CULL ? F3DG_BLOCK / 64 : 1][CULL ? F3DG_BLOCK : 1];
+    __shared__ float4 sq3[F3DG_BLOCK];            // r g b, and (culling) the 16-bit block mask in place of the depth
+    if (threadIdx.x == F3DG_ROUND) {
+        // sentinel: A = x^2 + y^2 + 1 > 0, B = 0, K = +inf  =>  fails the pre-test (0 < inf), and in blend_entry t = -0 is
+        // behind the near plane; opacity 0. It can never contribute, whatever filters are enabled.
+        sq0[F3DG_ROUND] = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
+        sq1[F3DG_ROUND] = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+        sq2[F3DG_ROUND] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());
+        sq3[F3DG_ROUND] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // block mask 0: in no list; .x/.y: see done_cnt
+    }
+    // block-wide count of finished pixels, double buffered by round parity. It lives in the sentinel's (never used)
+    // colour so that the block needs exactly 20480 B of LDS; __syncthreads_count would add a 256 B scratch array.
+    int* done_cnt = reinterpret_cast<int*>(&sq3[F3DG_ROUND]);
+    __syncthreads();
+    __shared__ __align__(16) unsigned char grp_list[CULL ? F3DG_BLOCK / 64 : 1][CULL ? 4 : 1][CULL ? F3DG_BLOCK : 1];   // per wave, per 16-lane group
 
     const F3dgRec* vrec = rec + (size_t)view * P;
     const float4* vbox = bbox + (size_t)view * P;
@@ -164,59 +181,85 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     st.C0 = st.C1 = st.C2 = st.C3 = st.C4 = st.C5 = st.C6 = st.C7 = 0;
     st.dist1 = st.dist2 = st.distortion = 0;
 
-    for (int i = 0; i < rounds; i++, toDo -= F3DG_BLOCK) {
-        const int num_done = __syncthreads_count(done);
+    for (int i = 0; i < rounds; i++, toDo -= F3DG_ROUND) {
+        {
+            const unsigned long long dl = __ballot(done);
+            if ((threadIdx.x & 63u) == 0)
+                atomicAdd(&done_cnt[i & 1], __popcll(dl));
+        }
+        __syncthreads();
+        const int num_done = done_cnt[i & 1];
+        if (threadIdx.x == 0)
+            done_cnt[(i + 1) & 1] = 0;          // everyone has read it (round i - 1); next added to after the barrier below
         if (num_done == F3DG_BLOCK)
             break;
 
-        const unsigned progress = (unsigned)i * F3DG_BLOCK + threadIdx.x;
-        if (range.x + progress < range.y) {
+        const unsigned progress = (unsigned)i * F3DG_ROUND + threadIdx.x;
+        if (threadIdx.x < F3DG_ROUND && range.x + progress < range.y) {
             const unsigned id = point_list[range.x + progress];
             const float4* src = reinterpret_cast<const float4*>(vrec + id);
-            const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+            const float4 a = src[0], b = src[1], c = src[2];
+            float4 d = src[3];
             sq0[threadIdx.x] = a;
             sq1[threadIdx.x] = b;
             sq2[threadIdx.x] = c;
-            sq3[threadIdx.x] = d;
             if (CULL) {
                 const float4 bx = vbox[id];                       // (x0, x1, y0, y1) in pixel coordinates
-                // bit w = the box touches wave w's quadrant: x half (w & 1), y half (w >> 1)
-                const unsigned mx = (bx.x <= tile_px0 + 7.0f && bx.y >= tile_px0 ? 1u : 0u) |
-                                    (bx.x <= tile_px0 + 15.0f && bx.y >= tile_px0 + 8.0f ? 2u : 0u);
-                const unsigned my = (bx.z <= tile_py0 + 7.0f && bx.w >= tile_py0 ? 1u : 0u) |
-                                    (bx.z <= tile_py0 + 15.0f && bx.w >= tile_py0 + 8.0f ? 2u : 0u);
-                const unsigned m = ((mx & 1u) && (my & 1u) ? 1u : 0u) | ((mx & 2u) && (my & 1u) ? 2u : 0u) |
-                                   ((mx & 1u) && (my & 2u) ? 4u : 0u) | ((mx & 2u) && (my & 2u) ? 8u : 0u);
-                strip_mask[threadIdx.x] = (unsigned char)m;
+                unsigned mx = 0, my = 0;                          // which of the 4 block columns / rows the box touches
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (bx.x <= tile_px0 + (float)(4 * q + 3) && bx.y >= tile_px0 + (float)(4 * q)) mx |= 1u << q;
+                    if (bx.z <= tile_py0 + (float)(4 * q + 3) && bx.w >= tile_py0 + (float)(4 * q)) my |= 1u << q;
+                }
+                const unsigned m = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 4 : 0u) | ((my & 4u) ? mx << 8 : 0u) |
+                                   ((my & 8u) ? mx << 12 : 0u);
+                d.w = __uint_as_float(m);
             }
+            sq3[threadIdx.x] = d;
         } else if (CULL) {
-            strip_mask[threadIdx.x] = 0;
+            sq3[threadIdx.x].w = 0.0f;
         }
         __syncthreads();
 
-        const int n = min(F3DG_BLOCK, toDo);
-        int count = n;
+        const int n = min(F3DG_ROUND, toDo);
+        int count = n;          // wave-uniform trip count: the longest of the wave's four group lists when culling
         if (CULL) {
-            // this wave's compacted list of staged entries whose box touches its strip (order preserved)
-            count = 0;
+            // four compacted lists per wave, one per 16-lane group: the staged entries whose box touches the group's
+            // 4x4 block, in list order. The lists are first filled with the index of the never-visible sentinel record, so
+            // that the three shorter lists are padded to the longest one and the loops below need no per-lane bounds.
+            {
+                uint4* fill = reinterpret_cast<uint4*>(&grp_list[wave][0][0]);       // 4 lists x 256 x u8 = 64 x 16 B
+                const unsigned ss = 0x01010101u * F3DG_ROUND;
+                fill[lane] = make_uint4(ss, ss, ss, ss);
+            }
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            const unsigned qx2 = (wave & 1u) * 2u, qy2 = (wave >> 1) * 2u;
+            const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
             for (int c = 0; c < F3DG_BLOCK / 64; c++) {
                 const unsigned e = c * 64 + lane;
-                const bool bit = (strip_mask[e] >> wave) & 1u;
-                const unsigned long long bal = __ballot(bit);
-                if (bit) wave_list[wave][count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
-                count += __popcll(bal);
+                const unsigned m = __float_as_uint(sq3[e].w);
+                const bool b0 = (m >> ((qy2 + 0u) * 4u + qx2 + 0u)) & 1u, b1 = (m >> ((qy2 + 0u) * 4u + qx2 + 1u)) & 1u;
+                const bool b2 = (m >> ((qy2 + 1u) * 4u + qx2 + 0u)) & 1u, b3 = (m >> ((qy2 + 1u) * 4u + qx2 + 1u)) & 1u;
+                const unsigned long long l0 = __ballot(b0), l1 = __ballot(b1), l2 = __ballot(b2), l3 = __ballot(b3);
+                if (b0) grp_list[wave][0][c0 + __popcll(l0 & lt)] = (unsigned char)e;
+                if (b1) grp_list[wave][1][c1 + __popcll(l1 & lt)] = (unsigned char)e;
+                if (b2) grp_list[wave][2][c2 + __popcll(l2 & lt)] = (unsigned char)e;
+                if (b3) grp_list[wave][3][c3 + __popcll(l3 & lt)] = (unsigned char)e;
+                c0 += __popcll(l0); c1 += __popcll(l1); c2 += __popcll(l2); c3 += __popcll(l3);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            count = max(max(c0, c1), max(c2, c3));
         }
-        const unsigned round_base = (unsigned)i * F3DG_BLOCK;
+        const unsigned char* my_list = CULL ? grp_list[wave][grp_] : nullptr;
+        const unsigned round_base = (unsigned)i * F3DG_ROUND;
 
         if (!QUEUE) {
             // ---- reference-shaped loop: every lane visits every (remaining) entry
             for (int kk = 0; !done && kk < count; kk++) {
-                const int j = CULL ? (int)wave_list[wave][kk] : kk;
+                const int j = CULL ? (int)my_list[kk] : kk;
                 const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j];
                 const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
                 const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
@@ -237,8 +280,9 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 unsigned long long pass = 0;
                 if (PRETEST) {
                     if (!done) {
-                        // phase 1: cheap test, wave-uniform entries (LDS broadcast); two entries per trip so that the
-                        // second entry's index + record loads are in flight while the first is evaluated
+                        // phase 1: cheap test; every 16-lane group walks ITS list (4 distinct LDS addresses per read, a
+                        // broadcast inside each group); two entries per trip so that the second entry's index + record
+                        // loads are in flight while the first is evaluated
                         auto test = [&](const float4& q0, const float4& q1, const float4& q2) -> bool {
                             const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
                             const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
@@ -249,15 +293,15 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                         };
                         int kk = 0;
                         for (; kk + 1 < wn; kk += 2) {
-                            const int j0 = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
-                            const int j1 = CULL ? (int)wave_list[wave][w0 + kk + 1] : (w0 + kk + 1);
+                            const int j0 = CULL ? (int)my_list[w0 + kk] : (w0 + kk);
+                            const int j1 = CULL ? (int)my_list[w0 + kk + 1] : (w0 + kk + 1);
                             const float4 a0 = sq0[j0], a1 = sq1[j0], a2 = sq2[j0];
                             const float4 b0 = sq0[j1], b1 = sq1[j1], b2 = sq2[j1];
                             if (test(a0, a1, a2)) pass |= 1ull << kk;
                             if (test(b0, b1, b2)) pass |= 2ull << kk;
                         }
                         if (kk < wn) {
-                            const int j0 = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
+                            const int j0 = CULL ? (int)my_list[w0 + kk] : (w0 + kk);
                             if (test(sq0[j0], sq1[j0], sq2[j0])) pass |= 1ull << kk;
                         }
                     }
@@ -267,7 +311,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 while (pass != 0 && !done) {                     // phase 2: this pixel's own passing entries, in order
                     const int kk = __builtin_ctzll(pass);
                     pass &= pass - 1;
-                    const int j = CULL ? (int)wave_list[wave][w0 + kk] : (w0 + kk);
+                    const int j = CULL ? (int)my_list[w0 + kk] : (w0 + kk);
                     const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
                     const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
                     const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
