@@ -165,6 +165,49 @@ extern "C" size_t f3dg_workspace_bytes(int P, int W, int H, int n_views, long lo
     return f3dg_layout(P, W, H, n_views, max_rendered).total;
 }
 
+namespace {
+
+int check_gaussian_args(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                        const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* cam_pos)
+{
+    (void)P;
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos) return F3DG_ERR_BAD_ARG;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return F3DG_ERR_BAD_ARG;       // exactly one (rast_py:205)
+    const bool have_sr = scales != nullptr && rotations != nullptr;
+    if (have_sr == (cov3D_precomp != nullptr)) return F3DG_ERR_BAD_ARG;                 // exactly one (rast_py:208)
+    if (!have_sr && view2gaussian_precomp == nullptr) return F3DG_ERR_BAD_ARG;          // view2gaussian needs scale/rot
+    if (shs && (M <= 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)) return F3DG_ERR_BAD_ARG;
+    return F3DG_OK;
+}
+
+// projection + binning of n_views views: everything of Rasterizer::forward / ::integrate before the tile kernel
+int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int P, int D, int M, int W, int H,
+                 const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
+                 int* radii_used, int save_aux, ProfCall* prof)
+{
+    int rc = f3dg_launch_preprocess(s, n_views, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+                                    cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
+                                    cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
+                                    reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
+                                    reinterpret_cast<float*>(ws + L.depths), reinterpret_cast<float4*>(ws + L.bbox),
+                                    reinterpret_cast<float4*>(ws + L.conic), radii_used,
+                                    reinterpret_cast<unsigned*>(ws + L.tiles),
+                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
+    if (rc != F3DG_OK) return rc;
+    prof_mark(prof, ST_PREPROCESS, s);
+    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, radii_used);
+    if (rc != F3DG_OK) return rc;
+    prof_mark(prof, ST_BINNING, s);
+    return F3DG_OK;
+}
+
+} // namespace
+
 extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
                                     int n_views, int P, int D, int M,
                                     const float* background, int W, int H,
@@ -195,12 +238,9 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
     }
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos) return F3DG_ERR_BAD_ARG;
-    if ((shs == nullptr) == (colors_precomp == nullptr)) return F3DG_ERR_BAD_ARG;       // exactly one (rast_py:205)
-    const bool have_sr = scales != nullptr && rotations != nullptr;
-    if (have_sr == (cov3D_precomp != nullptr)) return F3DG_ERR_BAD_ARG;                 // exactly one (rast_py:208)
-    if (!have_sr && view2gaussian_precomp == nullptr) return F3DG_ERR_BAD_ARG;          // view2gaussian needs scale/rot
-    if (shs && (M <= 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)) return F3DG_ERR_BAD_ARG;
+    int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                 view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
+    if (rc != F3DG_OK) return rc;
 
     const float focal_y = H / (2.0f * tan_fovy);       // float32, rasterizer_impl.cu:274-275
     const float focal_x = W / (2.0f * tan_fovx);
@@ -208,20 +248,10 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
     int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
 
     ProfCall* prof = prof_begin(s);
-    int rc = f3dg_launch_preprocess(s, n_views, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
-                                    cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
-                                    cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
-                                    reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
-                                    reinterpret_cast<float*>(ws + L.depths), reinterpret_cast<float4*>(ws + L.bbox),
-                                    reinterpret_cast<float4*>(ws + L.conic), radii_used,
-                                    reinterpret_cast<unsigned*>(ws + L.tiles),
-                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
+    rc = run_geometry(s, ws, L, n_views, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                      rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, save_aux, prof);
     if (rc != F3DG_OK) return rc;
-    prof_mark(prof, ST_PREPROCESS, s);
-
-    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, radii_used);
-    if (rc != F3DG_OK) return rc;
-    prof_mark(prof, ST_BINNING, s);
 
     rc = f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
                               reinterpret_cast<const uint2*>(ws + L.ranges),
@@ -233,6 +263,65 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
                               reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux);
     prof_mark(prof, ST_RENDER, s);
     return rc;
+}
+
+extern "C" size_t f3dg_integrate_workspace_bytes(int P, int W, int H, long long max_rendered)
+{
+    if (P < 0 || W <= 0 || H <= 0 || max_rendered < 0) return 0;
+    return f3dg_integ_layout(P, W, H, max_rendered).total;
+}
+
+extern "C" long long f3dg_integrate(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                    int PN, int P, int D, int M, const float* background, int W, int H,
+                                    const float* points3D, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* scales,
+                                    float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                    const float* view2gaussian_precomp, const float* viewmatrix,
+                                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                    float kernel_size, const float* subpixel_offset, int prefiltered,
+                                    float* out_color, int* radii, float* out_alpha_integrated,
+                                    float* out_color_integrated, long long* h_needed)
+{
+    (void)subpixel_offset;   // forward.cu:838 loads it into `depth_input`, which nothing reads
+    (void)prefiltered;       // only traps on a culled point (auxiliary.h:194-198)
+    hipStream_t s = (hipStream_t)stream;
+    if (PN < 0 || P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace) return F3DG_ERR_BAD_ARG;
+    if (PN > 0 && (!points3D || !out_alpha_integrated || !out_color_integrated)) return F3DG_ERR_BAD_ARG;
+    if (max_rendered > 0xFFFFFFF0ll) return F3DG_ERR_BAD_ARG;
+    const F3dgLayout L = f3dg_layout(P, W, H, 1, max_rendered);
+    const F3dgIntegLayout I = f3dg_integ_layout(P, W, H, max_rendered);
+    if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
+    if (h_needed) *h_needed = 0;
+
+    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
+    if (P == 0 || PN == 0) {                               // rasterize_points.cu:300: nothing runs, the fills stay
+        int rc = f3dg_launch_integrate_fill(s, W, H, PN, out_color, out_alpha_integrated, out_color_integrated);
+        if (rc != F3DG_OK) return rc;
+        F3DG_HIP_CHECK(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (!background) return F3DG_ERR_BAD_ARG;
+    int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                 view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
+    if (rc != F3DG_OK) return rc;
+
+    const float focal_y = H / (2.0f * tan_fovy);           // rasterizer_impl.cu:567-568
+    const float focal_x = W / (2.0f * tan_fovx);
+    int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
+    rc = run_geometry(s, ws, L, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                      rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, nullptr);
+    if (rc != F3DG_OK) return rc;
+    rc = f3dg_launch_integrate(s, PN, P, W, H, focal_x, focal_y, L, I, ws, points3D, viewmatrix, background, out_color,
+                               out_alpha_integrated, out_color_integrated);
+    if (rc != F3DG_OK) return rc;
+    long long n = 0;
+    rc = f3dg_read_status(stream, workspace, &n);
+    if (h_needed) *h_needed = n;
+    if (rc != F3DG_OK) return rc;
+    return n;
 }
 
 extern "C" int f3dg_read_status(void* stream, const void* workspace, long long* h_num_rendered)

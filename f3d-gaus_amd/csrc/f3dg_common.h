@@ -64,6 +64,17 @@ struct F3dgLayout {
 
 F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap);
 
+// Extra arrays of f3dg_integrate, carved behind the one-view forward layout (byte offsets into the same workspace)
+struct F3dgIntegLayout {
+    size_t pix_points;     // [H*W] u32: points per pixel                      } cleared together,
+    size_t tile_last;      // [T] u64: max (depth bits << 32 | point index)    } clear_bytes from pix_points
+    size_t clear_bytes;
+    size_t contrib_n;      // [H*W] u32: entries of the pixel's contributor list
+    size_t contrib_ids;    // [H*W][1024] u16: 1-based list positions of the contributing Gaussians (forward.cu:862, 969)
+    size_t total;
+};
+F3dgIntegLayout f3dg_integ_layout(int P, int W, int H, long long cap);
+
 int f3dg_set_hip_error(hipError_t e, const char* where);
 #define F3DG_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return f3dg_set_hip_error(_e, #expr); } while (0)
 
@@ -96,3 +107,10 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float* background, int bg_per_view, float* out_color, float* final_T,
                        unsigned* n_contrib, int save_aux);
+
+int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
+                               float* out_color_integrated);
+int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+                          const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
+                          const float* background, float* out_color, float* out_alpha_integrated,
+                          float* out_color_integrated);

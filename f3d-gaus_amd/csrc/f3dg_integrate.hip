@@ -1,0 +1,448 @@
+// f3dg_integrate.hip -- Gaussians -> points integration (GaussianRasterizer_GOF.integrate) for gfx950.
+//
+// Replaces FORWARD::preprocess_points / createWithKeys / FORWARD::integrate of the reference
+// (RAST/cuda_rasterizer/forward.cu:722-766, 801-1197; rasterizer_impl.cu:113-144, 530-792). The reference runs ONE
+// kernel per tile whose threads keep 7 KB of private arrays each (1024 contributor ids, 256 projected points with
+// their alphas / transmittances) and sweep the tile's depth-sorted point list in chunks of 256 points per pixel. The
+// results only depend on per-pixel and per-point quantities, so the work is reorganised MI355X-first without changing
+// a single value:
+//
+//   pass 1  (one workgroup per tile, one pixel per lane)  the first loop of integrateCUDA: five rays per pixel
+//           (centre + 4 corners), colour / alpha / maximal depth of the pixel, and the pixel's list of contributing
+//           Gaussians -- written to a global [pixel][1024] u16 table instead of a private array. The culled per-16-lane
+//           entry lists and the conservative K pre-test of the compositing kernel are reused (boxes widened by the half
+//           pixel of the corner rays); both only remove (ray, Gaussian) pairs the reference `continue`s on.
+//   points  (one LANE PER POINT, no sort)  preprocessPointsCUDA fused with the second loop of integrateCUDA: the point
+//           finds its pixel, walks that pixel's contributor list and accumulates its alpha. Loop interchange
+//           (points outside, Gaussians inside) is exact because every point's recurrence is independent. The tile's
+//           depth-sorted point list of the reference is only needed for one thing, see below.
+//   epilogue  the reference stores `total_projected` in the distortion channel. It equals the number of points in the
+//           pixel, EXCEPT when some pixel of the tile holds more than 256 points: the block then sweeps again, and
+//           every thread that had already finished re-collects the LAST point of the tile's sorted list if it lies in
+//           its pixel (point_counter_last = point_counter - 1, forward.cu:1099). That is reproduced arithmetically:
+//           total = n + (S - s) * [last tile point in this pixel], s = max(1, ceil(n / 256)), S = max over the tile;
+//           the last point of the stable (tile, depth) sort is the maximum of (depth bits, index), kept by atomicMax.
+//
+// Arithmetic: the reference's float32 / float64 operation order, no contraction (-ffp-contract=off); only expf differs
+// (device libm vs glibc), as in the compositing kernel.
+#include "f3dg_common.h"
+
+namespace {
+
+#define F3DG_ROUND (F3DG_BLOCK - 1)            // staged entries per round; LDS slot F3DG_ROUND is the sentinel
+#define F3DG_MAX_CONTRIB 1024                  // MAX_NUM_CONTRIBUTORS * 4, auxiliary.h:26 / forward.cu:862
+#define F3DG_MAX_PROJECTED 256                 // auxiliary.h:34
+
+struct Pass1State {
+    float Ts[5];
+    float C0, C1, C2, C6, C7;
+    unsigned last_contributor, nloc;
+};
+
+// One (ray, Gaussian) evaluation of forward.cu:903-962. Returns true when the ray "used" the Gaussian.
+template <bool FILTER, int K>
+__device__ __forceinline__ bool ray_entry(Pass1State& st, float rx, float ry, const float4& q0, const float4& q1,
+                                          const float4& q2, const float4& q3)
+{
+    const float n0 = q0.x * rx + q0.y * ry + q0.z;
+    const float n1 = q0.y * rx + q0.w * ry + q1.x;
+    const float n2 = q0.z * rx + q1.x * ry + q1.y;
+    const float AA = rx * n0 + ry * n1 + n2;
+    const float bhalf = q1.z * rx + q1.w * ry + q2.x;
+    if (FILTER) {
+        // Conservative pre-test (f3dg_preprocess.hip pretest_constant): certainly alpha < 1/255. This loop divides
+        // BB / AA in float32 (the compositing loop in float64); the extra relative error 2^-24 of b^2/a is inside the
+        // 5e-7 margin of K (3.2e-7 used by the product roundings and K's own narrowing).
+        if (bhalf * bhalf < q2.w * AA)
+            return false;
+    }
+    const float BB = 2 * bhalf;
+    const float CC = q2.y;
+    const float t = -BB / (2 * AA);
+    if (t <= F3DG_NEAR_PLANE)
+        return false;
+    const double min_value = -(BB / AA) * (BB / 4.) + CC;
+    float power = (float)(-0.5f * min_value);
+    if (power > 0.0f)
+        power = 0.0f;
+    const float alpha = fminf(0.99f, q2.z * expf(power));
+    if (alpha < 1.0f / 255.0f)
+        return false;
+    const float test_T = st.Ts[K] * (1 - alpha);
+    if (test_T < 0.0001f)
+        return false;                                   // `continue`, NOT done (forward.cu:934-938)
+    if (K == 0) {
+        st.C0 += q3.x * alpha * st.Ts[0];
+        st.C1 += q3.y * alpha * st.Ts[0];
+        st.C2 += q3.z * alpha * st.Ts[0];
+    }
+    if (t > st.C6)
+        st.C6 = t;
+    if (K == 0)
+        st.C7 += alpha * st.Ts[0];
+    st.Ts[K] = test_T;
+    return true;
+}
+
+template <bool FILTER>
+__global__ void __launch_bounds__(F3DG_BLOCK)
+integrate_pass1_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
+                       const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
+                       const F3dgRec* __restrict__ rec, const float4* __restrict__ bbox,
+                       const float* __restrict__ background, float* __restrict__ out_color,
+                       float* __restrict__ final_T, unsigned* __restrict__ n_contrib,
+                       unsigned short* __restrict__ contrib_ids, unsigned* __restrict__ contrib_n)
+{
+    const unsigned tile = blockIdx.x;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    // lane -> pixel as in the compositing kernel: wave = 8x8 quadrant, 16-lane group = 4x4 block
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned grp = lane >> 4, gi = lane & 15u;
+    const unsigned blk_x = (wave & 1u) * 2u + (grp & 1u), blk_y = (wave >> 1) * 2u + (grp >> 1);
+    const unsigned lx = blk_x * 4u + (gi & 3u), ly = blk_y * 4u + (gi >> 2);
+    const unsigned pix_x = tile_x * F3DG_TILE + lx, pix_y = tile_y * F3DG_TILE + ly;
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    // the five rays of forward.cu:864-866, 905: offsets (0,0) (-.5,-.5) (.5,-.5) (-.5,.5) (.5,.5)
+    const float rx0 = (float)((pixf_x + 0.0f - W / 2.) / focal_x), ry0 = (float)((pixf_y + 0.0f - H / 2.) / focal_y);
+    const float rxm = (float)((pixf_x + -0.5f - W / 2.) / focal_x), rym = (float)((pixf_y + -0.5f - H / 2.) / focal_y);
+    const float rxp = (float)((pixf_x + 0.5f - W / 2.) / focal_x), ryp = (float)((pixf_y + 0.5f - H / 2.) / focal_y);
+
+    uint2 range = ranges[tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const int rounds = (int)((range.y - range.x + F3DG_ROUND - 1) / F3DG_ROUND);
+    int toDo = (int)(range.y - range.x);
+
+    __shared__ float4 sq0[F3DG_BLOCK];            // v0 v1 v2 v3
+    __shared__ float4 sq1[F3DG_BLOCK];            // v4 v5 v6 v7
+    __shared__ float4 sq2[F3DG_BLOCK];            // v8 v9 opac K
+    __shared__ float4 sq3[F3DG_BLOCK];            // r g b, and (FILTER) the 16-bit block mask in place of the depth
+    __shared__ __align__(16) unsigned char grp_list[FILTER ? F3DG_BLOCK / 64 : 1][FILTER ? 4 : 1][FILTER ? F3DG_BLOCK : 1];
+    if (threadIdx.x == F3DG_ROUND) {
+        // sentinel (see f3dg_render.hip): fails the pre-test, pads the culled lists; .x/.y of sq3 hold the vote counters
+        sq0[F3DG_ROUND] = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
+        sq1[F3DG_ROUND] = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+        sq2[F3DG_ROUND] = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());
+        sq3[F3DG_ROUND] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    int* done_cnt = reinterpret_cast<int*>(&sq3[F3DG_ROUND]);
+    __syncthreads();
+
+    const float tile_px0 = (float)(tile_x * F3DG_TILE), tile_py0 = (float)(tile_y * F3DG_TILE);
+
+    bool done = !inside;
+    Pass1State st;
+#pragma unroll
+    for (int k = 0; k < 5; k++) st.Ts[k] = 1.0f;
+    st.C0 = st.C1 = st.C2 = st.C6 = st.C7 = 0;
+    st.last_contributor = 0; st.nloc = 0;
+    unsigned short* my_ids = contrib_ids + pix_id * F3DG_MAX_CONTRIB;
+
+    for (int i = 0; i < rounds; i++, toDo -= F3DG_ROUND) {
+        {
+            const unsigned long long dl = __ballot(done);
+            if (lane == 0)
+                atomicAdd(&done_cnt[i & 1], __popcll(dl));
+        }
+        __syncthreads();
+        const int num_done = done_cnt[i & 1];
+        if (threadIdx.x == 0)
+            done_cnt[(i + 1) & 1] = 0;
+        if (num_done == F3DG_BLOCK)
+            break;
+
+        const unsigned progress = (unsigned)i * F3DG_ROUND + threadIdx.x;
+        if (threadIdx.x < F3DG_ROUND && range.x + progress < range.y) {
+            const unsigned id = point_list[range.x + progress];
+            const float4* src = reinterpret_cast<const float4*>(rec + id);
+            const float4 a = src[0], b = src[1], c = src[2];
+            float4 d = src[3];
+            sq0[threadIdx.x] = a;
+            sq1[threadIdx.x] = b;
+            sq2[threadIdx.x] = c;
+            if (FILTER) {
+                const float4 bx = bbox[id];                       // pixel-index coordinates of the alpha >= 1/255 region
+                unsigned mx = 0, my = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {                     // corner rays reach half a pixel beyond the block
+                    if (bx.x <= tile_px0 + (float)(4 * q + 3) + 0.5f && bx.y >= tile_px0 + (float)(4 * q) - 0.5f) mx |= 1u << q;
+                    if (bx.z <= tile_py0 + (float)(4 * q + 3) + 0.5f && bx.w >= tile_py0 + (float)(4 * q) - 0.5f) my |= 1u << q;
+                }
+                const unsigned m = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 4 : 0u) | ((my & 4u) ? mx << 8 : 0u) |
+                                   ((my & 8u) ? mx << 12 : 0u);
+                d.w = __uint_as_float(m);
+            }
+            sq3[threadIdx.x] = d;
+        } else if (FILTER && threadIdx.x < F3DG_ROUND) {
+            sq3[threadIdx.x].w = 0.0f;
+        }
+        __syncthreads();
+
+        const int n = min(F3DG_ROUND, toDo);
+        int count = n;
+        if (FILTER) {
+            {
+                uint4* fill = reinterpret_cast<uint4*>(&grp_list[wave][0][0]);
+                const unsigned ss = 0x01010101u * F3DG_ROUND;
+                fill[lane] = make_uint4(ss, ss, ss, ss);
+            }
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            const unsigned qx2 = (wave & 1u) * 2u, qy2 = (wave >> 1) * 2u;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int c = 0; c < F3DG_BLOCK / 64; c++) {
+                const unsigned e = c * 64 + lane;
+                const unsigned m = __float_as_uint(sq3[e].w);
+                const bool b0 = (m >> ((qy2 + 0u) * 4u + qx2 + 0u)) & 1u, b1 = (m >> ((qy2 + 0u) * 4u + qx2 + 1u)) & 1u;
+                const bool b2 = (m >> ((qy2 + 1u) * 4u + qx2 + 0u)) & 1u, b3 = (m >> ((qy2 + 1u) * 4u + qx2 + 1u)) & 1u;
+                const unsigned long long l0 = __ballot(b0), l1 = __ballot(b1), l2 = __ballot(b2), l3 = __ballot(b3);
+                if (b0) grp_list[wave][0][c0 + __popcll(l0 & lt)] = (unsigned char)e;
+                if (b1) grp_list[wave][1][c1 + __popcll(l1 & lt)] = (unsigned char)e;
+                if (b2) grp_list[wave][2][c2 + __popcll(l2 & lt)] = (unsigned char)e;
+                if (b3) grp_list[wave][3][c3 + __popcll(l3 & lt)] = (unsigned char)e;
+                c0 += __popcll(l0); c1 += __popcll(l1); c2 += __popcll(l2); c3 += __popcll(l3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            count = max(max(c0, c1), max(c2, c3));
+        }
+        const unsigned char* my_list = FILTER ? grp_list[wave][grp] : nullptr;
+        const unsigned round_base = (unsigned)i * F3DG_ROUND;
+
+        for (int kk = 0; !done && kk < count; kk++) {
+            const int j = FILTER ? (int)my_list[kk] : kk;
+            const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
+            bool used = false;
+            used |= ray_entry<FILTER, 0>(st, rx0, ry0, q0, q1, q2, q3);
+            used |= ray_entry<FILTER, 1>(st, rxm, rym, q0, q1, q2, q3);
+            used |= ray_entry<FILTER, 2>(st, rxp, rym, q0, q1, q2, q3);
+            used |= ray_entry<FILTER, 3>(st, rxm, ryp, q0, q1, q2, q3);
+            used |= ray_entry<FILTER, 4>(st, rxp, ryp, q0, q1, q2, q3);
+            if (used) {
+                const unsigned contributor = round_base + (unsigned)j + 1u;
+                st.last_contributor = contributor;
+                my_ids[st.nloc] = (unsigned short)contributor;     // (u_int16_t) cast of forward.cu:969
+                st.nloc += 1;
+                if (st.nloc >= F3DG_MAX_CONTRIB)
+                    done = true;                                    // "Maximal contributors are met", forward.cu:972-976
+            }
+        }
+    }
+
+    if (inside) {                                                  // forward.cu:984-996
+        final_T[pix_id] = st.Ts[0];
+        n_contrib[pix_id] = st.last_contributor;
+        contrib_n[pix_id] = st.nloc;
+        out_color[0 * HW + pix_id] = st.C0 + st.Ts[0] * background[0];
+        out_color[1 * HW + pix_id] = st.C1 + st.Ts[0] * background[1];
+        out_color[2 * HW + pix_id] = st.C2 + st.Ts[0] * background[2];
+        out_color[3 * HW + pix_id] = 0.0f;                         // the caller's zero fill, rasterize_points.cu:273
+        out_color[4 * HW + pix_id] = 0.0f;
+        out_color[5 * HW + pix_id] = 0.0f;
+        out_color[6 * HW + pix_id] = st.C6;
+        out_color[7 * HW + pix_id] = st.C7;
+    }
+}
+
+// preprocessPointsCUDA (forward.cu:722-766): view-space depth and image position of one point; false = not integrated
+__device__ __forceinline__ bool project_point(const float* __restrict__ points3D, unsigned idx, const float* view, int W, int H,
+                                              float focal_x, float focal_y, float& ix, float& iy, float& depth)
+{
+    const float px = points3D[3 * (size_t)idx], py = points3D[3 * (size_t)idx + 1], pz = points3D[3 * (size_t)idx + 2];
+    const float vx = view[0] * px + view[4] * py + view[8] * pz + view[12];
+    const float vy = view[1] * px + view[5] * py + view[9] * pz + view[13];
+    const float vz = view[2] * px + view[6] * py + view[10] * pz + view[14];
+    if (vz <= 0.2f)                                                // in_frustum, auxiliary.h:193
+        return false;
+    ix = (float)(focal_x * vx / (vz + 0.0000001f) + W / 2.);
+    iy = (float)(focal_y * vy / (vz + 0.0000001f) + H / 2.);
+    if (ix < 0 || ix >= W || iy < 0 || iy >= H)
+        return false;
+    depth = vz;
+    return true;
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+integrate_points_kernel(int PN, const float* __restrict__ points3D, const float* __restrict__ viewmatrix, int W, int H,
+                        int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
+                        const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
+                        const F3dgRec* __restrict__ rec, const unsigned short* __restrict__ contrib_ids,
+                        const unsigned* __restrict__ contrib_n, const unsigned* __restrict__ n_contrib,
+                        const float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
+                        float* __restrict__ out_color_integrated, unsigned* __restrict__ pix_points,
+                        unsigned long long* __restrict__ tile_last)
+{
+    const unsigned idx = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    if (idx >= (unsigned)PN)
+        return;
+    float ix, iy, depth;
+    const bool ok = !hdr->overflow && project_point(points3D, idx, viewmatrix, W, H, focal_x, focal_y, ix, iy, depth);
+    if (!ok) {                                                      // the caller's fills, rasterize_points.cu:275-276
+        out_alpha_integrated[idx] = 1.0f;
+        out_color_integrated[3 * (size_t)idx] = 0.0f;
+        out_color_integrated[3 * (size_t)idx + 1] = 0.0f;
+        out_color_integrated[3 * (size_t)idx + 2] = 0.0f;
+        return;
+    }
+    // the pixel whose thread collects this point: x in [pix, pix + 1) (forward.cu:1063-1064, evaluated in double on
+    // exactly representable bounds) = truncation; its tile is the createWithKeys tile (rasterizer_impl.cu:135-136)
+    const unsigned pix_x = (unsigned)(int)ix, pix_y = (unsigned)(int)iy;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const unsigned tile = (pix_y / F3DG_TILE) * (unsigned)tiles_x + pix_x / F3DG_TILE;
+
+    const float rx = (float)((ix - W / 2.) / focal_x);
+    const float ry = (float)((iy - H / 2.) / focal_y);
+    const unsigned range_x = ranges[tile].x;
+    const unsigned nloc = contrib_n[pix_id];
+    const unsigned last_contributor = n_contrib[pix_id];
+    const unsigned short* ids = contrib_ids + pix_id * F3DG_MAX_CONTRIB;
+
+    float point_alpha = 0.f, point_T = 1.f;
+    // second loop of integrateCUDA (forward.cu:1111-1176) for this point. num_iterated only ever matches the next
+    // stored id when that id is larger (the u16 ids wrap beyond 65535 entries exactly as in the reference).
+    unsigned num_iterated = 0;
+    for (unsigned ptr = 0; ptr < nloc; ptr++) {
+        const unsigned target = ids[ptr];
+        if (target <= num_iterated || target > last_contributor)
+            break;
+        num_iterated = target;
+        const unsigned g = point_list[range_x + target - 1u];
+        const float4* src = reinterpret_cast<const float4*>(rec + g);
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+        const float n0 = q0.x * rx + q0.y * ry + q0.z;
+        const float n1 = q0.y * rx + q0.w * ry + q1.x;
+        const float n2 = q0.z * rx + q1.x * ry + q1.y;
+        const float AA = rx * n0 + ry * n1 + n2;
+        const float BB = 2 * (q1.z * rx + q1.w * ry + q2.x);
+        const float CC = q2.y;
+        float t = -BB / (2 * AA);
+        if (t > depth)
+            t = depth;
+        const float power = -0.5f * (AA * t * t + BB * t + CC);
+        const float alpha = fminf(0.99f, q2.z * expf(power));
+        if (alpha < 1.0f / 255.0f)
+            continue;
+        const float test_T = point_T * (1 - alpha);
+        point_alpha += alpha * point_T;
+        point_T = test_T;
+    }
+    out_alpha_integrated[idx] = point_alpha;
+    out_color_integrated[3 * (size_t)idx] = out_color[0 * HW + pix_id];         // C + T * bg of the pixel (forward.cu:1186)
+    out_color_integrated[3 * (size_t)idx + 1] = out_color[1 * HW + pix_id];
+    out_color_integrated[3 * (size_t)idx + 2] = out_color[2 * HW + pix_id];
+
+    atomicAdd(&pix_points[pix_id], 1u);
+    atomicMax(&tile_last[tile], ((unsigned long long)__float_as_uint(depth) << 32) | idx);
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+integrate_epilogue_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, const float* __restrict__ points3D,
+                          const float* __restrict__ viewmatrix, const unsigned* __restrict__ pix_points,
+                          const unsigned long long* __restrict__ tile_last, float* __restrict__ out_color)
+{
+    const unsigned tile = blockIdx.x;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned pix_x = tile_x * F3DG_TILE + (threadIdx.x & 15u), pix_y = tile_y * F3DG_TILE + (threadIdx.x >> 4);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const unsigned n = inside ? pix_points[pix_id] : 0u;
+    const unsigned sweeps = n == 0 ? 1u : (n + F3DG_MAX_PROJECTED - 1) / F3DG_MAX_PROJECTED;
+
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0) s_max = 1u;
+    __syncthreads();
+    atomicMax(&s_max, sweeps);
+    __syncthreads();
+    const unsigned S = s_max;
+
+    unsigned extra = 0;
+    const unsigned long long last = tile_last[tile];
+    if (inside && S > sweeps && last != 0ull) {
+        float ix, iy, depth;
+        if (project_point(points3D, (unsigned)(last & 0xffffffffull), viewmatrix, W, H, focal_x, focal_y, ix, iy, depth) &&
+            (unsigned)(int)ix == pix_x && (unsigned)(int)iy == pix_y)
+            extra = S - sweeps;
+    }
+    if (inside)
+        out_color[(size_t)F3DG_DISTORTION_OFFSET * H * W + pix_id] = (float)(int)(n + extra);
+}
+
+__global__ void integrate_fill_kernel(size_t HW, size_t PN, float* __restrict__ out_color,
+                                      float* __restrict__ out_alpha_integrated, float* __restrict__ out_color_integrated)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 9 * HW; i += stride) out_color[i] = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < PN; i += stride) out_alpha_integrated[i] = 1.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * PN; i += stride) out_color_integrated[i] = 0.0f;
+}
+
+} // namespace
+
+F3dgIntegLayout f3dg_integ_layout(int P, int W, int H, long long cap)
+{
+    F3dgIntegLayout I;
+    const F3dgLayout L = f3dg_layout(P, W, H, 1, cap);
+    const size_t HW = (size_t)W * H;
+    const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
+    size_t off = (L.total + 255) & ~(size_t)255;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    I.pix_points = take(HW * sizeof(unsigned));                       // pix_points and tile_last are cleared together
+    I.tile_last = take(T * sizeof(unsigned long long));
+    I.clear_bytes = off - I.pix_points;
+    I.contrib_n = take(HW * sizeof(unsigned));
+    I.contrib_ids = take(HW * F3DG_MAX_CONTRIB * sizeof(unsigned short));
+    I.total = off;
+    return I;
+}
+
+int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
+                               float* out_color_integrated)
+{
+    hipLaunchKernelGGL(integrate_fill_kernel, dim3(1024), dim3(256), 0, s, (size_t)W * H, (size_t)PN, out_color,
+                       out_alpha_integrated, out_color_integrated);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+                          const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
+                          const float* background, float* out_color, float* out_alpha_integrated,
+                          float* out_color_integrated)
+{
+    (void)P;
+    const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    const int T = tiles_x * tiles_y;
+    const F3dgHeader* hdr = reinterpret_cast<const F3dgHeader*>(ws + L.header);
+    const uint2* ranges = reinterpret_cast<const uint2*>(ws + L.ranges);
+    const unsigned* point_list = reinterpret_cast<const unsigned*>(ws + L.vals[0]);
+    const F3dgRec* rec = reinterpret_cast<const F3dgRec*>(ws + L.rec);
+    float* final_T = reinterpret_cast<float*>(ws + L.final_T);
+    unsigned* n_contrib = reinterpret_cast<unsigned*>(ws + L.n_contrib);
+    unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
+    unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
+    unsigned* pix_points = reinterpret_cast<unsigned*>(ws + I.pix_points);
+    unsigned long long* tile_last = reinterpret_cast<unsigned long long*>(ws + I.tile_last);
+
+    F3DG_HIP_CHECK(hipMemsetAsync(ws + I.pix_points, 0, I.clear_bytes, s));
+    if (g_f3dg_render_pretest && g_f3dg_render_cull)
+        hipLaunchKernelGGL((integrate_pass1_kernel<true>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+                           hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
+                           out_color, final_T, n_contrib, contrib_ids, contrib_n);
+    else
+        hipLaunchKernelGGL((integrate_pass1_kernel<false>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+                           hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
+                           out_color, final_T, n_contrib, contrib_ids, contrib_n);
+    F3DG_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(integrate_points_kernel, dim3((PN + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, PN,
+                       points3D, viewmatrix, W, H, tiles_x, focal_x, focal_y, hdr, ranges, point_list, rec, contrib_ids,
+                       contrib_n, n_contrib, out_color, out_alpha_integrated, out_color_integrated, pix_points, tile_last);
+    F3DG_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(integrate_epilogue_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+                       points3D, viewmatrix, pix_points, tile_last, out_color);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}

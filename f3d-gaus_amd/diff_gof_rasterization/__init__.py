@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import _lib
 
 __all__ = ["GaussianRasterizationSettings_GOF", "GaussianRasterizer_GOF", "rasterize_gaussians", "rasterize_views",
-           "Workspace"]
+           "integrate_gaussians_to_points", "Workspace"]
 
 
 class GaussianRasterizationSettings_GOF(NamedTuple):
@@ -209,6 +209,73 @@ class _RasterizeGaussians(torch.autograd.Function):
         return rasterize_backward(ctx, grad_out_color)
 
 
+_INTEG_WS = {}      # device index -> (key, capacity, buffer) reused by integrate calls
+
+
+def integrate_gaussians_to_points(points3D, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                  view2gaussian_precomp, raster_settings):
+    """``_C.integrate_gaussians_to_points`` (RAST/rasterize_points.cu:233-343) through ``f3dg_integrate``.
+    Returns (color [9,H,W], alpha_integrated [PN], color_integrated [PN,3], radii [P], num_rendered)."""
+    L = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("f3dgaus_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
+    if means3D.ndim != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")     # rasterize_points.cu:260-262
+    if points3D.ndim != 2 or points3D.size(1) != 3:
+        raise RuntimeError("points3D must have dimensions (num_points, 3)")    # rasterize_points.cu:263-265
+    rs = raster_settings
+    with torch.no_grad():
+        P, PN = means3D.size(0), points3D.size(0)
+        H, W = int(rs.image_height), int(rs.image_width)
+        points3D = points3D.to(device=device, dtype=torch.float32).contiguous()
+        means3D_ = _dev_f32(means3D, device)
+        sh = _dev_f32(sh, device)
+        colors_precomp = _dev_f32(colors_precomp, device)
+        opacities_ = _dev_f32(opacities, device)
+        scales = _dev_f32(scales, device)
+        rotations = _dev_f32(rotations, device)
+        cov3Ds_precomp = _dev_f32(cov3Ds_precomp, device)
+        view2gaussian_precomp = _dev_f32(view2gaussian_precomp, device)
+        vm = _dev_f32(rs.viewmatrix, device)
+        pm = _dev_f32(rs.projmatrix, device)
+        cp = _dev_f32(rs.campos, device)
+        bgt = _dev_f32(rs.bg, device)
+        M = 0 if sh is None else (sh.size(1) if sh.ndim == 3 else sh.numel() // (3 * max(P, 1)))
+
+        color = torch.empty((9, H, W), dtype=torch.float32, device=device)
+        radii = torch.zeros((P,), dtype=torch.int32, device=device)
+        alpha_integrated = torch.empty((PN,), dtype=torch.float32, device=device)
+        color_integrated = torch.empty((PN, 3), dtype=torch.float32, device=device)
+
+        cap = _initial_capacity(P, W, H, 1)
+        key = (P, W, H)
+        while True:
+            cached = _INTEG_WS.get(device.index)
+            if cached is None or cached[0] != key or cached[1] < cap:
+                nbytes = L.f3dg_integrate_workspace_bytes(P, W, H, cap)
+                if nbytes == 0:
+                    raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_integrate_workspace_bytes")
+                cached = (key, cap, torch.empty(int(nbytes), dtype=torch.uint8, device=device))
+                _INTEG_WS[device.index] = cached
+            buf = cached[2]
+            needed = C.c_longlong(0)
+            rc = L.f3dg_integrate(
+                _stream(), C.c_void_p(buf.data_ptr()), buf.numel(), cached[1], PN, P, int(rs.sh_degree), int(M),
+                _lib.ptr(bgt), W, H, _lib.ptr(points3D) if PN else None, _lib.ptr(means3D_), _lib.ptr(sh),
+                _lib.ptr(colors_precomp), _lib.ptr(opacities_), _lib.ptr(scales), float(rs.scale_modifier),
+                _lib.ptr(rotations), _lib.ptr(cov3Ds_precomp), _lib.ptr(view2gaussian_precomp), _lib.ptr(vm),
+                _lib.ptr(pm), _lib.ptr(cp), float(rs.tanfovx), float(rs.tanfovy), float(rs.kernel_size), None,
+                int(bool(rs.prefiltered)), _lib.ptr(color), _lib.ptr(radii), _lib.ptr(alpha_integrated) if PN else None,
+                _lib.ptr(color_integrated) if PN else None, C.byref(needed))
+            if rc == _lib.ERR_OVERFLOW:
+                cap = int(needed.value * 1.25) + 1024
+                continue
+            _lib.check(rc, "f3dg_integrate")
+            _CAP_HINT[(P, W, H, 1)] = max(int(rc * 1.5) + 1024, 1 << 14)
+            return color, alpha_integrated, color_integrated, radii, int(rc)
+
+
 class GaussianRasterizer_GOF(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
@@ -257,6 +324,19 @@ class GaussianRasterizer_GOF(nn.Module):
 
     def integrate(self, points3D, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
                   rotations=None, cov3D_precomp=None, view2gaussian_precomp=None):
-        # SURVEY section 8(f) rank 1 ("next"): mesh-extraction path, not part of the round-1 hot path.
-        raise NotImplementedError("GaussianRasterizer_GOF.integrate (mesh extraction) is outside the accelerated "
-                                  "hot path in this build; see DESIGN.md 'out of scope / next'")
+        """Integrate the Gaussians' opacity along the rays to ``points3D`` (rast_py:241-307 ->
+        ``_C.integrate_gaussians_to_points``, rasterize_points.cu:233-343). Not differentiable, as in the reference.
+        Returns (color [9,H,W], alpha_integrated [PN], color_integrated [PN,3], radii [P])."""
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        color, alpha_integrated, color_integrated, radii, _ = integrate_gaussians_to_points(
+            points3D, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view2gaussian_precomp,
+            raster_settings)
+        return color, alpha_integrated, color_integrated, radii

@@ -71,7 +71,7 @@ def depth_to_normal(world_view_transform, image_width, image_height, FoVx, FoVy,
 
 
 def _render_one(get, bs, world_view_transform, full_proj_transform, camera_center, bg_color, cfg, kernel_size,
-                scaling_modifier, override_color):
+                scaling_modifier, override_color, points3D=None):
     xyz = get("xyz")
     device = xyz.device
     # zero tensor whose gradient receives the screen-space mean gradients (reference :932-936)
@@ -104,7 +104,15 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
     scales = get("scaling")
     rotations = get("rotation")
 
-    if override_color is None:
+    extra = {}
+    if points3D is not None:        # render_predicted_more_v2_gof_in (:1070-1228): integrate instead of render
+        shs = torch.cat([get("features_dc"), get("features_rest")], dim=1).contiguous() if override_color is None else None
+        colors_precomp = None if override_color is None else get("rgbs")
+        rendered_image, alpha_integrated, color_integrated, radii = rasterizer.integrate(
+            points3D=points3D, means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+            opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None, view2gaussian_precomp=None)
+        extra = {"alpha_integrated": alpha_integrated, "color_integrated": color_integrated}
+    elif override_color is None:
         shs = torch.cat([get("features_dc"), get("features_rest")], dim=1).contiguous()
         rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None,
                                            opacities=opacity, scales=scales, rotations=rotations,
@@ -117,15 +125,17 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
 
     wv = world_view_transform.reshape(1, 4, 4)
     nw, dn = _epilogue(rendered_image.detach().unsqueeze(0), wv, image_width, image_height, FovX, FovY)
-    return {"render": rendered_image[:3, :, :],
-            "rendered_normal": nw[0],
-            "rendered_depth": rendered_image[6:7, :, :],
-            "depth_normal": dn[0],
-            "rendered_alpha": rendered_image[7:8, :, :],
-            "distortion_map": rendered_image[8:9, :, :],
-            "viewspace_points": screenspace_points,
-            "visibility_filter": radii > 0,
-            "radii": radii}
+    res = {"render": rendered_image[:3, :, :],
+           "rendered_normal": nw[0],
+           "rendered_depth": rendered_image[6:7, :, :],
+           "depth_normal": dn[0],
+           "rendered_alpha": rendered_image[7:8, :, :],
+           "distortion_map": rendered_image[8:9, :, :],
+           "viewspace_points": screenspace_points,
+           "visibility_filter": radii > 0,
+           "radii": radii}
+    res.update(extra)
+    return res
 
 
 def render_predicted_more_v2_gof(pc: dict, bs, world_view_transform, full_proj_transform, camera_center,
@@ -135,6 +145,17 @@ def render_predicted_more_v2_gof(pc: dict, bs, world_view_transform, full_proj_t
     Matrices may carry leading singleton dims ([1,1,4,4], [1,1,3], [1,3]) exactly as visualize.py passes them."""
     return _render_one(lambda k: pc[k][bs], bs, world_view_transform, full_proj_transform, camera_center, bg_color,
                        cfg, kernel_size, scaling_modifier, override_color)
+
+
+def render_predicted_more_v2_gof_in(points3D, pc: dict, bs, world_view_transform, full_proj_transform, camera_center,
+                                    bg_color: torch.Tensor, cfg, kernel_size=0.0, scaling_modifier=1.0,
+                                    override_color=None, subpixel_offset=None):
+    """``render_predicted_more_v2_gof_in`` (:1070-1228): ``GaussianRasterizer_GOF.integrate`` of ``points3D`` [PN,3]
+    against image ``bs`` of ``pc``; the returned dict additionally holds ``alpha_integrated`` [PN] and
+    ``color_integrated`` [PN,3]. (``rendered_normal`` is all zero and ``distortion_map`` counts the points per pixel:
+    that is what the reference's integrate kernel leaves in those channels.)"""
+    return _render_one(lambda k: pc[k][bs], bs, world_view_transform, full_proj_transform, camera_center, bg_color,
+                       cfg, kernel_size, scaling_modifier, override_color, points3D=points3D)
 
 
 def render_predicted_more_v3_gof(pc, bs, world_view_transform, full_proj_transform, camera_center,

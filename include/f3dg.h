@@ -63,6 +63,9 @@ extern "C" {
 
 #define F3DG_TILE 16             /* BLOCK_X = BLOCK_Y = 16, RAST/cuda_rasterizer/config.h:16-17 */
 #define F3DG_OUT_CHANNELS 9      /* RGB, normal xyz, median depth, alpha, distortion: auxiliary.h:21-24 */
+#define F3DG_DEPTH_OFFSET 6      /* auxiliary.h:21 */
+#define F3DG_ALPHA_OFFSET 7      /* auxiliary.h:22 */
+#define F3DG_DISTORTION_OFFSET 8 /* auxiliary.h:23 */
 
 /* Library / build identification: "f3dg-hip gfx950 <version>" */
 const char* f3dg_version(void);
@@ -128,6 +131,28 @@ int f3dg_backward(void* stream, void* workspace, size_t workspace_bytes, long lo
                   float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                   float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                   float* dL_dview2gaussian, unsigned flags /* F3DG_FLAG_BG_PER_VIEW as in the forward */);
+
+/* Gaussians -> points integration: Rasterizer::integrate (rasterizer.h:92-123, rasterizer_impl.cu:530-792) as bound by
+ * IntegrateGaussiansToPointsCUDA (rasterize_points.cu:233-343, `_C.integrate_gaussians_to_points`). One view.
+ *   points3D [PN,3]; the Gaussian arguments as in f3dg_forward; subpixel_offset [H,W,2] is accepted and ignored (the
+ *   reference only loads it into an unused variable, forward.cu:838).
+ *   out_color [9,H,W]: 0..2 colour + T * background of the centre ray, 3..5 zero, 6 maximal ray depth, 7 alpha,
+ *       8 the number of points that fell into the pixel (forward.cu:984-996, 1194-1196)
+ *   out_alpha_integrated [PN] (1 for points outside the frustum / image), out_color_integrated [PN,3] (0 for those)
+ * The library writes every output element itself (the reference relies on the caller's torch.full fills). P == 0 or
+ * PN == 0: out_color = 0, alpha = 1, colour = 0, returns 0 (rasterize_points.cu:300).
+ * BLOCKING like f3dg_forward; returns num_rendered >= 0 or a negative error; on F3DG_ERR_OVERFLOW *h_needed (if not
+ * NULL) receives the required instance capacity. The workspace must hold f3dg_integrate_workspace_bytes(). */
+size_t f3dg_integrate_workspace_bytes(int P, int W, int H, long long max_rendered);
+long long f3dg_integrate(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                         int PN, int P, int D, int M, const float* background, int W, int H,
+                         const float* points3D, const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, float scale_modifier,
+                         const float* rotations, const float* cov3D_precomp, const float* view2gaussian_precomp,
+                         const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset,
+                         int prefiltered, float* out_color, int* radii, float* out_alpha_integrated,
+                         float* out_color_integrated, long long* h_needed);
 
 /* present[i] = (view-space z of means3D[i] > 0.2), auxiliary.h:177-202. present is uint8 [P]. */
 int f3dg_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,

@@ -41,6 +41,10 @@ def lib():
         L.gof_oracle_num_rendered.argtypes = [vp]
         L.gof_oracle_higher_msb.restype = C.c_uint32
         L.gof_oracle_higher_msb.argtypes = [C.c_uint32]
+        L.gof_oracle_integrate.restype = C.c_int
+        L.gof_oracle_integrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp,
+                                           fp, fp, C.c_float, fp, fp, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float,
+                                           fp, ip, fp, fp, ip]
         L.gof_oracle_backward.restype = None
         L.gof_oracle_backward.argtypes = [vp] + [fp] * 17
         _LIB = L
@@ -103,6 +107,40 @@ class Oracle:
         self.scale_modifier, self.kernel_size, self.tanfovx, self.tanfovy = scale_modifier, kernel_size, tanfovx, tanfovy
         self.out_color, self.radii = out, radii
         return out, radii, R
+
+    def integrate(self, *, points3D, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H, bg,
+                  shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                  view2gaussian_precomp=None, sh_degree=0, scale_modifier=1.0, kernel_size=0.0):
+        """``Rasterizer::integrate`` (rasterizer_impl.cu:530-792) with the output initialisation of
+        ``IntegrateGaussiansToPointsCUDA`` (rasterize_points.cu:273-276). Returns
+        (out_color[9,H,W], alpha_integrated[PN], color_integrated[PN,3], radii[P], num_rendered, num_integrated)."""
+        means3D = _f32(means3D).reshape(-1, 3)
+        points3D = _f32(points3D).reshape(-1, 3)
+        P, PN = means3D.shape[0], points3D.shape[0]
+        shs = _f32(shs)
+        M = 0 if shs is None else shs.reshape(P, -1, 3).shape[1]
+        a = dict(means3D=means3D, shs=shs, colors_precomp=_f32(colors_precomp), opacities=_f32(opacities),
+                 scales=_f32(scales), rotations=_f32(rotations), cov3D_precomp=_f32(cov3D_precomp),
+                 view2gaussian_precomp=_f32(view2gaussian_precomp), viewmatrix=_f32(viewmatrix).reshape(16),
+                 projmatrix=_f32(projmatrix).reshape(16), campos=_f32(campos).reshape(3), bg=_f32(bg).reshape(3),
+                 points3D=points3D)
+        out = np.zeros((9, H, W), np.float32)
+        radii = np.zeros((P,), np.int32)
+        alpha_i = np.ones((PN,), np.float32)
+        color_i = np.zeros((PN, 3), np.float32)
+        ni = C.c_int(0)
+        R = 0
+        if P != 0 and PN != 0:          # rasterize_points.cu:300
+            R = self._L.gof_oracle_integrate(
+                self._ctx, PN, P, int(sh_degree), M, _ptr(a["bg"]), int(W), int(H), _ptr(points3D), _ptr(a["means3D"]),
+                _ptr(a["shs"]), _ptr(a["colors_precomp"]), _ptr(a["opacities"]), _ptr(a["scales"]),
+                C.c_float(scale_modifier), _ptr(a["rotations"]), _ptr(a["cov3D_precomp"]),
+                _ptr(a["view2gaussian_precomp"]), _ptr(a["viewmatrix"]), _ptr(a["projmatrix"]), _ptr(a["campos"]),
+                C.c_float(tanfovx), C.c_float(tanfovy), C.c_float(kernel_size), _ptr(out), _ptr(radii), _ptr(alpha_i),
+                _ptr(color_i), C.byref(ni))
+        self.args = a
+        self.P, self.W, self.H, self.M, self.D, self.R = P, W, H, M, int(sh_degree), R
+        return out, alpha_i, color_i, radii, R, int(ni.value)
 
     def backward(self, dL_dpix):
         """Gradients of the last forward w.r.t. its inputs given dL/d(out_color) [9,H,W]. Returns a dict with the

@@ -21,6 +21,7 @@
  *                                          computeView2Gaussian, preprocessCUDA, renderCUDA
  *   RAST/cuda_rasterizer/rasterizer_impl.cu getHigherMsb, duplicateWithKeys, identifyTileRanges,
  *                                          Rasterizer::forward / backward orchestration
+ *                                          preprocessPointsCUDA, integrateCUDA; createWithKeys, Rasterizer::integrate
  *   RAST/cuda_rasterizer/backward.cu       renderCUDA (bwd), computeView2Gaussian_backward,
  *                                          computeColorFromSH (bwd), preprocessCUDA (bwd)
  *
@@ -568,12 +569,11 @@ static void render_pixel(const gof_ctx* c, uint32_t px, uint32_t py, const uint3
  * view2gaussian_precomp, if given, is [P,10] and is consumed by the compositing stage exactly as the
  * reference's render does (forward.cu:402 reads it 16-strided into a dead variable; render reads it
  * 10-strided, rasterizer_impl.cu:378). Returns num_rendered. */
-int gof_oracle_forward(gof_ctx* c, int P, int D, int M, const float* background, int width, int height,
+static int geometry_and_binning(gof_ctx* c, int P, int D, int M, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                        const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
-                       const float* cam_pos, float tan_fovx, float tan_fovy, float kernel_size,
-                       float* out_color, int* radii)
+                       const float* cam_pos, float tan_fovx, float tan_fovy, float kernel_size, int* radii)
 {
     ctx_free_buffers(c);
     c->P = P; c->W = width; c->H = height; c->D = D; c->M = M;
@@ -652,6 +652,20 @@ int gof_oracle_forward(gof_ctx* c, int P, int D, int M, const float* background,
 
     c->colors_used = colors_precomp != NULL ? colors_precomp : c->rgb;
     c->v2g_used = view2gaussian_precomp != NULL ? view2gaussian_precomp : c->v2g;
+    return R;
+}
+
+int gof_oracle_forward(gof_ctx* c, int P, int D, int M, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* cam_pos, float tan_fovx, float tan_fovy, float kernel_size,
+                       float* out_color, int* radii)
+{
+    const int R = geometry_and_binning(c, P, D, M, width, height, means3D, shs, colors_precomp, opacities, scales,
+                                       scale_modifier, rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix,
+                                       projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, radii);
+    const int ntiles = c->gx * c->gy;
 
     /* renderCUDA: tile-parallel on the host cores */
     #pragma omp parallel for schedule(dynamic, 1)
@@ -665,6 +679,321 @@ int gof_oracle_forward(gof_ctx* c, int P, int D, int M, const float* background,
                     render_pixel(c, px, py, c->point_list + r0, (int)(r1 - r0), background, out_color);
             }
     }
+    return R;
+}
+
+/* ========================================================================================== */
+/*                       INTEGRATE (Gaussians -> points), SURVEY.md 8f-1                      */
+/* ========================================================================================== */
+/* Literal restatement of Rasterizer::integrate (rasterizer_impl.cu:530-792): preprocessPointsCUDA
+ * (forward.cu:722-766), createWithKeys (rasterizer_impl.cu:113-144) and integrateCUDA (forward.cu:801-1197),
+ * INCLUDING the per-thread arrays, the 256-point sweeps and the block-wide votes of the CUDA kernel: the 256
+ * threads of a tile are simulated one after the other between two votes. */
+#define MAX_NUM_CONTRIBUTORS 256   /* auxiliary.h:26 */
+#define MAX_NUM_PROJECTED 256      /* auxiliary.h:34 */
+#define BLOCK_SIZE (BLOCK_X * BLOCK_Y)
+
+typedef struct {
+    int inside;
+    uint32_t px, py;
+    float corner_Ts[5];
+    float C[8];
+    uint32_t last_contributor;
+    uint32_t n_contrib_local;
+    uint16_t contributed_ids[MAX_NUM_CONTRIBUTORS * 4];
+    /* point phase */
+    uint32_t point_counter_last;
+    int point_done;
+    int total_projected;
+} integ_thread;
+
+/* first loop of integrateCUDA (forward.cu:871-980) for one thread */
+static void integrate_pass1(const gof_ctx* c, integ_thread* th, const uint32_t* list, int count)
+{
+    const int W = c->W, H = c->H;
+    const float pixf_x = (float)th->px + 0.5f, pixf_y = (float)th->py + 0.5f;
+    static const float offset_xs[5] = { 0.0f, -0.5f, 0.5f, -0.5f, 0.5f };
+    static const float offset_ys[5] = { 0.0f, -0.5f, -0.5f, 0.5f, 0.5f };
+    uint32_t contributor = 0;
+    int done = !th->inside;
+
+    for (int j = 0; !done && j < count; j++) {
+        contributor++;
+        const uint32_t id = list[j];
+        const float con_o_w = c->conic_opacity[4 * (size_t)id + 3];
+        const float* v = c->v2g_used + (size_t)id * 10;
+
+        int used = 0;
+        for (int k = 0; k < 5; ++k) {
+            const float rx = (float)((pixf_x + offset_xs[k] - W / 2.) / c->focal_x);
+            const float ry = (float)((pixf_y + offset_ys[k] - H / 2.) / c->focal_y);
+            const float normal[3] = {
+                v[0] * rx + v[1] * ry + v[2],
+                v[1] * rx + v[3] * ry + v[4],
+                v[2] * rx + v[4] * ry + v[5]
+            };
+            float AA = rx * normal[0] + ry * normal[1] + normal[2];
+            float BB = 2 * (v[6] * rx + v[7] * ry + v[8]);
+            float CC = v[9];
+
+            float t = -BB / (2 * AA);
+            if (t <= NEAR_PLANE)
+                continue;
+
+            double min_value = -(BB / AA) * (BB / 4.) + CC;     /* float quotient, then double */
+            float power = (float)(-0.5f * min_value);
+            if (power > 0.0f)
+                power = 0.0f;
+
+            float alpha = fminf(0.99f, con_o_w * expf(power));
+            if (alpha < 1.0f / 255.0f)
+                continue;
+            float test_T = th->corner_Ts[k] * (1 - alpha);
+            if (test_T < 0.0001f)
+                continue;               /* NOT done: forward.cu:934-938 */
+
+            if (k == 0)
+                for (int ch = 0; ch < 3; ch++)
+                    th->C[ch] += c->colors_used[(size_t)id * 3 + ch] * alpha * th->corner_Ts[k];
+            if (t > th->C[6])
+                th->C[6] = t;           /* maximal depth */
+            if (k == 0)
+                th->C[7] += alpha * th->corner_Ts[k];
+            th->corner_Ts[k] = test_T;
+            used = 1;
+        }
+
+        if (used) {
+            th->last_contributor = contributor;
+            th->contributed_ids[th->n_contrib_local] = (uint16_t)contributor;
+            th->n_contrib_local += 1;
+            if (th->n_contrib_local >= MAX_NUM_CONTRIBUTORS * 4) {
+                done = 1;               /* "Maximal contributors are met" */
+                break;
+            }
+        }
+    }
+}
+
+/* points state (rasterizer_impl.cu:47-57) */
+typedef struct { float* depths; float* points2D; uint32_t* tiles_touched; uint32_t* point_list; uint32_t* ranges; int num_integrated; } point_state;
+
+/* Returns num_rendered. out_color [9,H,W] must be zero-filled by the caller exactly as rasterize_points.cu:273 does
+ * (channels 3..5 are never written); out_alpha_integrated [PN] pre-filled with 1, out_color_integrated [PN,3] with 0
+ * (rasterize_points.cu:275-276). */
+int gof_oracle_integrate(gof_ctx* c, int PN, int P, int D, int M, const float* background, int width, int height,
+                         const float* points3D, const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                         const float* cov3D_precomp, const float* view2gaussian_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                         float kernel_size, float* out_color, int* radii, float* out_alpha_integrated,
+                         float* out_color_integrated, int* num_integrated_out)
+{
+    const int R = geometry_and_binning(c, P, D, M, width, height, means3D, shs, colors_precomp, opacities, scales,
+                                       scale_modifier, rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix,
+                                       projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, radii);
+    const int W = width, H = height;
+    const int ntiles = c->gx * c->gy;
+    const size_t HW = (size_t)H * W;
+
+    /* preprocessPointsCUDA, forward.cu:722-766 */
+    point_state ps;
+    size_t PNn = PN > 0 ? (size_t)PN : 1;
+    ps.depths = calloc(PNn, 4); ps.points2D = calloc(PNn * 2, 4); ps.tiles_touched = calloc(PNn, 4);
+    for (int idx = 0; idx < PN; idx++) {
+        ps.tiles_touched[idx] = 0;
+        vec3 p_orig = { points3D[3 * idx], points3D[3 * idx + 1], points3D[3 * idx + 2] };
+        vec3 p_view = transformPoint4x3(p_orig, viewmatrix);
+        if (p_view.z <= 0.2f)
+            continue;
+        const float ix = (float)(c->focal_x * p_view.x / (p_view.z + 0.0000001f) + W / 2.);
+        const float iy = (float)(c->focal_y * p_view.y / (p_view.z + 0.0000001f) + H / 2.);
+        if (ix < 0 || ix >= W || iy < 0 || iy >= H)
+            continue;
+        ps.depths[idx] = p_view.z;
+        ps.points2D[2 * (size_t)idx] = ix; ps.points2D[2 * (size_t)idx + 1] = iy;
+        ps.tiles_touched[idx] = 1;
+    }
+    /* InclusiveSum + createWithKeys (rasterizer_impl.cu:113-144) + SortPairs + identifyTileRanges */
+    int NI = 0;
+    for (int idx = 0; idx < PN; idx++) NI += (int)ps.tiles_touched[idx];
+    ps.num_integrated = NI;
+    kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (NI > 0 ? (size_t)NI : 1));
+    {
+        uint32_t off = 0;
+        for (int idx = 0; idx < PN; idx++)
+            if (ps.tiles_touched[idx] > 0) {
+                const float pxf = ps.points2D[2 * (size_t)idx], pyf = ps.points2D[2 * (size_t)idx + 1];
+                int x = imin(c->gx - 1, imax(0, (int)(pxf / BLOCK_X)));
+                int y = imin(c->gy - 1, imax(0, (int)(pyf / BLOCK_Y)));
+                uint64_t key = (uint64_t)(y * c->gx + x);
+                key <<= 32;
+                uint32_t dbits; memcpy(&dbits, &ps.depths[idx], 4);
+                key |= dbits;
+                kv[off].key = key; kv[off].val = (uint32_t)idx; kv[off].seq = off;
+                off++;
+            }
+    }
+    int bit = (int)getHigherMsb((uint32_t)ntiles);
+    int end_bit = 32 + bit;
+    g_sort_mask = end_bit >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << end_bit) - 1);
+    if (NI > 1) qsort(kv, (size_t)NI, sizeof(kv_t), kv_cmp);
+    ps.point_list = (uint32_t*)malloc(4 * (NI > 0 ? (size_t)NI : 1));
+    ps.ranges = (uint32_t*)calloc((size_t)ntiles * 2, 4);
+    for (int i = 0; i < NI; i++) ps.point_list[i] = kv[i].val;
+    for (int idx = 0; idx < NI; idx++) {
+        uint32_t currtile = (uint32_t)(kv[idx].key >> 32);
+        if (idx == 0)
+            ps.ranges[2 * currtile] = 0;
+        else {
+            uint32_t prevtile = (uint32_t)(kv[idx - 1].key >> 32);
+            if (currtile != prevtile) {
+                ps.ranges[2 * prevtile + 1] = (uint32_t)idx;
+                ps.ranges[2 * currtile] = (uint32_t)idx;
+            }
+        }
+        if (idx == NI - 1)
+            ps.ranges[2 * currtile + 1] = (uint32_t)NI;
+    }
+    free(kv);
+    if (num_integrated_out) *num_integrated_out = NI;
+
+    /* integrateCUDA, one tile = one block of 256 simulated threads */
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int tx = tile % c->gx, ty = tile / c->gx;
+        const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
+        const uint32_t* list = c->point_list + r0;
+        const int count = (int)(r1 - r0);
+        const uint32_t p0 = ps.ranges[2 * tile], p1 = ps.ranges[2 * tile + 1];
+        const int pcount = (int)(p1 - p0);
+        integ_thread* th = (integ_thread*)calloc(BLOCK_SIZE, sizeof(integ_thread));
+
+        for (int t = 0; t < BLOCK_SIZE; t++) {
+            integ_thread* h = &th[t];
+            h->px = (uint32_t)(tx * BLOCK_X + t % BLOCK_X); h->py = (uint32_t)(ty * BLOCK_Y + t / BLOCK_X);
+            h->inside = h->px < (uint32_t)W && h->py < (uint32_t)H;
+            for (int k = 0; k < 5; k++) h->corner_Ts[k] = 1.0f;
+            integrate_pass1(c, h, list, count);
+            if (h->inside) {                                  /* forward.cu:984-996 */
+                const uint32_t pix_id = (uint32_t)W * h->py + h->px;
+                c->final_T[pix_id] = h->corner_Ts[0];
+                c->n_contrib[pix_id] = h->last_contributor;
+                for (int ch = 0; ch < 3; ch++)
+                    out_color[ch * HW + pix_id] = h->C[ch] + h->corner_Ts[0] * background[ch];
+                out_color[DEPTH_OFFSET * HW + pix_id] = h->C[6];
+                out_color[ALPHA_OFFSET * HW + pix_id] = h->C[7];
+            }
+            h->point_counter_last = 0;
+            h->point_done = !h->inside;
+            h->total_projected = 0;
+        }
+
+        /* forward.cu:1011-1189 */
+        while (1) {
+            int num_done = 0;
+            for (int t = 0; t < BLOCK_SIZE; t++) num_done += th[t].point_done;
+            if (num_done == BLOCK_SIZE)
+                break;
+
+            for (int t = 0; t < BLOCK_SIZE; t++) {
+                integ_thread* h = &th[t];
+                const float pixf_x = (float)h->px + 0.5f, pixf_y = (float)h->py + 0.5f;
+                int projected_ids[MAX_NUM_PROJECTED];
+                float projected_xy[MAX_NUM_PROJECTED][2];
+                float projected_depth[MAX_NUM_PROJECTED];
+                int num_projected = 0;
+                int excced_max_projected = 0;
+                int done = 0;
+                uint32_t point_counter = 0;
+
+                /* the block-wide "all done" vote inside the rounds loop (forward.cu:1034-1037) can only stop the loop
+                 * once every thread has stopped iterating, so it changes no thread's state */
+                for (int j = 0; !done && j < pcount; j++) {
+                    point_counter++;
+                    if (point_counter <= h->point_counter_last)
+                        continue;
+                    const uint32_t pid = ps.point_list[p0 + j];
+                    const float qx = ps.points2D[2 * (size_t)pid], qy = ps.points2D[2 * (size_t)pid + 1];
+                    const float depth = ps.depths[pid];
+                    if ((qx >= (pixf_x - 0.5)) && (qx < (pixf_x + 0.5)) && (qy >= (pixf_y - 0.5)) && (qy < (pixf_y + 0.5))) {
+                        if (num_projected >= MAX_NUM_PROJECTED) {
+                            done = 1;
+                            excced_max_projected = 1;
+                            break;
+                        }
+                        projected_ids[num_projected] = (int)pid;
+                        projected_xy[num_projected][0] = qx; projected_xy[num_projected][1] = qy;
+                        projected_depth[num_projected] = depth;
+                        num_projected += 1;
+                    }
+                }
+                h->point_counter_last = point_counter - 1;
+                h->point_done = !excced_max_projected;
+                h->total_projected += num_projected;
+
+                float point_alphas[MAX_NUM_PROJECTED];
+                float point_Ts[MAX_NUM_PROJECTED];
+                for (int i = 0; i < MAX_NUM_PROJECTED; i++) { point_alphas[i] = 0.f; point_Ts[i] = 0.f; }
+                for (int i = 0; i < num_projected; i++) point_Ts[i] = 1.f;
+
+                uint32_t num_iterated = 0;
+                int second_done = !h->inside;
+                uint16_t num_contributed_second = 0;
+                for (int j = 0; !second_done && j < count; j++) {
+                    num_iterated++;
+                    if (num_iterated > h->last_contributor) {
+                        second_done = 1;
+                        continue;
+                    }
+                    if (num_iterated != (uint32_t)h->contributed_ids[num_contributed_second])
+                        continue;
+                    else
+                        num_contributed_second += 1;
+
+                    const uint32_t id = list[j];
+                    const float con_o_w = c->conic_opacity[4 * (size_t)id + 3];
+                    const float* v = c->v2g_used + (size_t)id * 10;
+                    for (int k = 0; k < num_projected; k++) {
+                        const float rx = (float)((projected_xy[k][0] - W / 2.) / c->focal_x);
+                        const float ry = (float)((projected_xy[k][1] - H / 2.) / c->focal_y);
+                        const float ray_depth = projected_depth[k];
+                        const float normal[3] = {
+                            v[0] * rx + v[1] * ry + v[2],
+                            v[1] * rx + v[3] * ry + v[4],
+                            v[2] * rx + v[4] * ry + v[5]
+                        };
+                        float AA = rx * normal[0] + ry * normal[1] + normal[2];
+                        float BB = 2 * (v[6] * rx + v[7] * ry + v[8]);
+                        float CC = v[9];
+                        float t = -BB / (2 * AA);
+                        if (t > ray_depth)
+                            t = ray_depth;
+                        float power = -0.5f * (AA * t * t + BB * t + CC);
+                        float alpha = fminf(0.99f, con_o_w * expf(power));
+                        if (alpha < 1.0f / 255.0f)
+                            continue;
+                        float test_T = point_Ts[k] * (1 - alpha);
+                        point_alphas[k] += alpha * point_Ts[k];
+                        point_Ts[k] = test_T;
+                    }
+                }
+
+                if (h->inside)
+                    for (int k = 0; k < num_projected; k++) {
+                        out_alpha_integrated[projected_ids[k]] = point_alphas[k];
+                        for (int ch = 0; ch < 3; ch++)
+                            out_color_integrated[3 * (size_t)projected_ids[k] + ch] = h->C[ch] + h->corner_Ts[0] * background[ch];
+                    }
+            }
+        }
+
+        for (int t = 0; t < BLOCK_SIZE; t++)
+            if (th[t].inside)
+                out_color[DISTORTION_OFFSET * HW + (size_t)W * th[t].py + th[t].px] = (float)th[t].total_projected;
+        free(th);
+    }
+    free(ps.depths); free(ps.points2D); free(ps.tiles_touched); free(ps.point_list); free(ps.ranges);
     return R;
 }
 
