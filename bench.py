@@ -162,6 +162,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    copy_gbs = measured_copy_bandwidth(device) if rank == 0 else None
+
     if rank == 0:
         T = ((RES + 15) // 16) ** 2
         launches = max(int(ncalls.value), 1)
@@ -186,6 +188,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "render_fwd_kernel<SAVE_AUX=false, PRETEST, CULL, QUEUE>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(P, V, RES, args.views_per_call),
+                         "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
+                         "valu": measured_valu(P, V, RES, args.views_per_call),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": render_ms_per_launch,
                          "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
                                                "compositing": stage_ms[2] / args.steps}},
@@ -196,6 +200,38 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_copy_bandwidth(device, nbytes=1 << 30, reps=5):
+    """GB/s (read + write) of a plain device-to-device copy of 1 GiB on this box: the practical HBM ceiling next to the
+    8 TB/s nominal peak the roofline fraction is quoted against."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    a.zero_()
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def measured_valu(P, V, RES, views_per_call):
+    """Vector-ALU figures of the compositing kernel from the committed SQ counter passes (profiles/r01_final/traffic.json,
+    same configuration only): busy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x kernel cycles), lanes = active lanes per VALU
+    instruction / 64. The kernel is VALU-bound (SURVEY 8d asks for this next to the HBM fraction)."""
+    path = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
+    try:
+        t = json.load(open(path))
+        c = t["config"]
+        if (c["gaussians"], c["views"], c["resolution"], c["views_per_call"]) == (P, V, RES, views_per_call):
+            return t.get("valu")
+    except Exception:
+        pass
+    return None
 
 
 def measured_traffic(P, V, RES, views_per_call):

@@ -271,7 +271,7 @@ radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ va
 //     L2 / Infinity-Cache resident), chunk by chunk with running per-digit cursors.
 // The LDS path first ORs (key ^ first key) over the segment: only the depth bits that actually vary inside the tile are
 // sorted, in ceil(bits/9) passes of <= 9 bits (three passes for the 25 varying bits of depths in [6.7, 8.7], not four).
-#define F3DG_TILE_SORT_CAP F3DG_SORT_CHUNK
+#define F3DG_TILE_SORT_CAP (F3DG_SORT_CHUNK - 64)      // 4032: keeps the workgroup under 32 KB of LDS = 5 per CU
 
 // stable in-wave ranking of one digit per lane; returns the lane's rank among equal digits seen so far by this wave
 __device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 lane_lt, int digit_bits = 8)
@@ -323,7 +323,8 @@ group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restr
     if (i < nseg) ranges[i] = gcount[i] ? make_uint2(gcum[i] - gcount[i], gcum[i]) : make_uint2(0u, 0u);
 }
 
-__global__ void __launch_bounds__(F3DG_BLOCK)
+template <bool LONG>
+__global__ void __launch_bounds__(F3DG_BLOCK, LONG ? 2 : 4)
 tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
                  const F3dgHeader* __restrict__ hdr,
                  const u64* __restrict__ keys_src, const u32* __restrict__ vals_src,     // tile-grouped buffer
@@ -331,11 +332,15 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
                  u64* __restrict__ keys_tmp, u32* __restrict__ vals_tmp)                 // scratch for long segments
 {
     __shared__ u32 cnt[F3DG_BLOCK / 64][512];          // per-wave digit counters (up to 9-bit digits in the LDS path)
-    __shared__ u32 cursor[256];
     __shared__ u32 wtot[F3DG_BLOCK / 64];
     __shared__ u32 skip_flag;
-    __shared__ u32 sdepth[2][F3DG_TILE_SORT_CAP];
-    __shared__ u32 sval[2][F3DG_TILE_SORT_CAP];
+    // LDS path: the keys live in REGISTERS between the passes (16 per thread, in (wave, row, lane) = segment order);
+    // one LDS buffer is only the exchange medium of a pass (scatter to the ranked slot, barrier, read the own rows back).
+    // The payload is the 12-bit position inside the segment (the Gaussian ids are gathered once, at the end). 32 KB of
+    // LDS per workgroup instead of 72 KB: 5 workgroups per CU instead of 2.
+    __shared__ u32 sdepth[F3DG_TILE_SORT_CAP];
+    __shared__ unsigned short sidx[F3DG_TILE_SORT_CAP];
+    u32* cursor = sdepth;                               // long-segment path only (it does not use sdepth / sidx)
     if (hdr->overflow) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 lane_lt = ((u64)1 << lane) - 1;
@@ -344,30 +349,29 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
         const uint2 range = ranges[seg];
         const u32 n = range.y - range.x;
         if (n == 0) continue;
+        if ((n > F3DG_TILE_SORT_CAP) != LONG) continue;      // two instantiations: the LDS path keeps 5 workgroups per CU
         const u32 src0 = gstart[seg];
         __syncthreads();
 
-        if (n <= F3DG_TILE_SORT_CAP) {
+        if (!LONG) {
             // ---------------- LDS-resident path
             const u64 first = keys_src[src0];
             const u64 hi = first & 0xFFFFFFFF00000000ull;               // (view, tile) bits: constant over the segment
+            const u32 wave_base = (u32)wave * (64 * F3DG_SORT_ITEMS);
+            u32 dk[F3DG_SORT_ITEMS];                                    // depth bits
+            u32 di[F3DG_SORT_ITEMS];                                    // position in the segment (low 16) | rank << 16
             u32 diff = 0;
-            {
-                // all of this thread's global loads are issued before the first one is consumed (the segment is short:
-                // a dependent load per loop trip would serialise ~10 memory latencies per workgroup)
-                u32 kd[F3DG_SORT_ITEMS], vv[F3DG_SORT_ITEMS];
+            // all of this thread's global loads are issued before the first one is consumed
 #pragma unroll
-                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                    const u32 i = threadIdx.x + (u32)r * F3DG_BLOCK;
-                    kd[r] = i < n ? (u32)keys_src[src0 + i] : (u32)first;
-                    vv[r] = i < n ? vals_src[src0 + i] : 0u;
-                }
+            for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
+                const u32 i = wave_base + (u32)r * 64 + lane;
+                dk[r] = i < n ? (u32)keys_src[src0 + i] : 0xFFFFFFFFu;
+                di[r] = i;
+            }
 #pragma unroll
-                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                    const u32 i = threadIdx.x + (u32)r * F3DG_BLOCK;
-                    if (i < n) { sdepth[0][i] = kd[r]; sval[0][i] = vv[r]; }
-                    diff |= kd[r] ^ (u32)first;
-                }
+            for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
+                const u32 i = wave_base + (u32)r * 64 + lane;
+                if (i < n) diff |= dk[r] ^ (u32)first;
             }
             // number of depth bits that actually vary inside this tile -> as few, as narrow (<= 9 bit) passes as possible
 #pragma unroll
@@ -379,23 +383,18 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
             const int npass = (vbits + 8) / 9;
             const int dbits = npass ? (vbits + npass - 1) / npass : 0;   // <= 9
             const u32 dmask = (1u << dbits) - 1u;
-            int cur = 0;
-            const u32 wave_base = (u32)wave * (64 * F3DG_SORT_ITEMS);
             for (int pass = 0; pass < npass; pass++) {
                 const int shift = dbits * pass;
                 __syncthreads();
                 cnt[0][threadIdx.x] = 0; cnt[0][threadIdx.x + 256] = 0; cnt[1][threadIdx.x] = 0; cnt[1][threadIdx.x + 256] = 0;
                 cnt[2][threadIdx.x] = 0; cnt[2][threadIdx.x + 256] = 0; cnt[3][threadIdx.x] = 0; cnt[3][threadIdx.x + 256] = 0;
                 __syncthreads();
-                u32 dk[F3DG_SORT_ITEMS], rank[F3DG_SORT_ITEMS];
 #pragma unroll
                 for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                    const u32 i = wave_base + (u32)r * 64 + lane;
-                    rank[r] = 0; dk[r] = 0;
                     if (wave_base + (u32)r * 64 < n) {           // wave-uniform
-                        const bool valid = i < n;
-                        dk[r] = valid ? sdepth[cur][i] : 0xFFFFFFFFu;
-                        rank[r] = wave_rank((dk[r] >> shift) & dmask, valid, cnt[wave], lane_lt, dbits);
+                        const bool valid = wave_base + (u32)r * 64 + lane < n;
+                        const u32 rk = wave_rank((dk[r] >> shift) & dmask, valid, cnt[wave], lane_lt, dbits);
+                        di[r] = (di[r] & 0xFFFFu) | (rk << 16);
                     }
                 }
                 __syncthreads();
@@ -425,20 +424,25 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
                 for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
                     const u32 i = wave_base + (u32)r * 64 + lane;
                     if (i < n) {
-                        const u32 pos = cnt[wave][(dk[r] >> shift) & dmask] + rank[r];
-                        sdepth[cur ^ 1][pos] = dk[r];
-                        sval[cur ^ 1][pos] = sval[cur][i];
+                        const u32 pos = cnt[wave][(dk[r] >> shift) & dmask] + (di[r] >> 16);
+                        sdepth[pos] = dk[r];
+                        sidx[pos] = (unsigned short)(di[r] & 0xFFFFu);
                     }
                 }
-                cur ^= 1;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
+                    const u32 i = wave_base + (u32)r * 64 + lane;
+                    if (i < n) { dk[r] = sdepth[i]; di[r] = sidx[i]; }
+                }
             }
-            __syncthreads();
+            // registers hold the sorted segment in (wave, row, lane) order: coalesced stores, ids gathered from the source
 #pragma unroll
             for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                const u32 i = threadIdx.x + (u32)r * F3DG_BLOCK;
+                const u32 i = wave_base + (u32)r * 64 + lane;
                 if (i < n) {
-                    vals_dst[range.x + i] = sval[cur][i];
-                    keys_dst[range.x + i] = hi | sdepth[cur][i];
+                    vals_dst[range.x + i] = vals_src[src0 + (di[r] & 0xFFFFu)];
+                    keys_dst[range.x + i] = hi | dk[r];
                 }
             }
             continue;
@@ -624,7 +628,10 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
     hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges);
 
     // 5. level 2: per-(view, tile) stable sort by the depth bits: gather the group from half 1, write it sorted to half 0
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(nseg < 65535u * 16u ? nseg : 65535u * 16u), dim3(F3DG_BLOCK), 0, s, ranges, gstart,
+    hipLaunchKernelGGL((tile_sort_kernel<false>), dim3(nseg < 65535u * 16u ? nseg : 65535u * 16u), dim3(F3DG_BLOCK), 0, s, ranges, gstart,
+                       nseg, hdr, keys[1], vals[1], keys[0], vals[0], keys[2], vals[2]);
+    // segments above the LDS capacity (rare: > 4032 Gaussians in one tile of one view): a few workgroups stride over all
+    hipLaunchKernelGGL((tile_sort_kernel<true>), dim3(nseg < 1024u ? nseg : 1024u), dim3(F3DG_BLOCK), 0, s, ranges, gstart,
                        nseg, hdr, keys[1], vals[1], keys[0], vals[0], keys[2], vals[2]);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
