@@ -19,6 +19,14 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
+# Per-file extras. -fno-slp-vectorize: the SLP vectorizer pairs the float32 multiplies / adds of the per-pixel quadric into
+# v_pk_mul_f32 / v_pk_add_f32; on gfx950 those issue at half rate, so nothing is gained and the v_mov shuffles that feed them
+# are pure overhead (measured on the compositing kernel: DESIGN.md section 5). Results are bit-identical either way.
+EXTRA_FLAGS = {name: os.environ.get("F3DG_EXTRA_" + name.split(".")[0].upper(), default).split()
+               for name, default in (("f3dg_render.hip", "-fno-slp-vectorize"), ("f3dg_backward.hip", "-fno-slp-vectorize"),
+                                     ("f3dg_integrate.hip", "-fno-slp-vectorize"), ("f3dg_preprocess.hip", "-fno-slp-vectorize"))}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -39,7 +47,7 @@ def build(force=False, verbose=False):
     def compile_one(pair):
         src, obj = pair
         if force or _stale(obj, [src] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
