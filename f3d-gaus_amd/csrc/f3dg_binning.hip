@@ -262,16 +262,14 @@ radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ va
 }
 
 // ------------------------------------------------------------------------------------------------ per-tile depth sort
-// Level 2 of the two-level sort. After the global passes have grouped the instances by (view, tile) -- stably, so each
-// segment is in ascending Gaussian-id order -- one workgroup per segment sorts it by the 32 depth bits with four
-// stable 8-bit LSD passes.
-//   * segments of up to 4096 instances (the normal case: ~2.4k at 200k Gaussians / 256^2) are sorted ENTIRELY IN LDS:
-//     12 B read + 4 B written per instance of global traffic instead of four more 24-B trips through HBM;
-//   * longer segments fall back to ping-pong passes over their own slice of the two global halves (just written, so
-//     L2 / Infinity-Cache resident), chunk by chunk with running per-digit cursors.
-// The LDS path first ORs (key ^ first key) over the segment: only the depth bits that actually vary inside the tile are
-// sorted, in ceil(bits/9) passes of <= 9 bits (three passes for the 25 varying bits of depths in [6.7, 8.7], not four).
-#define F3DG_TILE_SORT_CAP (F3DG_SORT_CHUNK - 64)      // 4032: keeps the workgroup under 32 KB of LDS = 5 per CU
+// Level 2 of the two-level sort. After the global pass(es) have grouped the instances by (view, tile) -- stably, so each
+// segment is in ascending Gaussian-id order -- one workgroup per segment sorts it by its depth bits, in three tiers:
+//   * n <= 4032  (C2: ~2.5 k entries per tile)   tile_sort_lds_kernel<256, 16>, 32 KB of LDS, 4 workgroups per CU
+//   * n <= 16320 (C5: 8-9 k entries per tile)     tile_sort_lds_kernel<512, 32>, 112 KB of LDS, one 8-wave workgroup per CU
+//   * longer                                        tile_sort_long_kernel: 8-bit LSD passes through a global scratch slice
+// The LDS tiers first OR (key ^ first key) over the segment: only the depth bits that actually vary inside the tile are
+// sorted, in ceil(bits/9) passes of <= 9 bits (three passes for the 24 varying bits of depths in [6.7, 8.7], not four);
+// 12 B read + 12 B written per instance of global traffic.
 
 // stable in-wave ranking of one digit per lane; returns the lane's rank among equal digits seen so far by this wave
 __device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 lane_lt, int digit_bits = 8)
@@ -323,24 +321,26 @@ group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restr
     if (i < nseg) ranges[i] = gcount[i] ? make_uint2(gcum[i] - gcount[i], gcum[i]) : make_uint2(0u, 0u);
 }
 
-template <bool LONG>
-__global__ void __launch_bounds__(F3DG_BLOCK, LONG ? 2 : 4)
-tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
-                 const F3dgHeader* __restrict__ hdr,
-                 const u64* __restrict__ keys_src, const u32* __restrict__ vals_src,     // tile-grouped buffer
-                 u64* __restrict__ keys_dst, u32* __restrict__ vals_dst,                 // final buffer (half 0)
-                 u64* __restrict__ keys_tmp, u32* __restrict__ vals_tmp)                 // scratch for long segments
+// LDS-resident per-(view, tile) sort for segments of lo < n <= THREADS * ITEMS - 64 entries. The keys live in REGISTERS
+// between the passes (ITEMS per thread, in (wave, row, lane) = segment order); one LDS buffer is only the exchange medium of
+// a pass (scatter to the ranked slot, barrier, read the own rows back). The payload is the position inside the segment
+// (u16; the Gaussian ids are gathered once, at the end). Two instantiations:
+//   <256, 16>: n <= 4032, 32 KB of LDS -> 4 workgroups per CU (the C2 regime: ~2.5 k entries per tile)
+//   <512, 32>: n <= 16320, 112 KB of LDS -> 1 workgroup of 8 waves per CU (the C5 regime: 8-9 k entries per tile)
+template <int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1)
+tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
+                     const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */,
+                     const u64* __restrict__ keys_src, const u32* __restrict__ vals_src,     // tile-grouped buffer
+                     u64* __restrict__ keys_dst, u32* __restrict__ vals_dst)                 // final buffer (half 0)
 {
-    __shared__ u32 cnt[F3DG_BLOCK / 64][512];          // per-wave digit counters (up to 9-bit digits in the LDS path)
-    __shared__ u32 wtot[F3DG_BLOCK / 64];
-    __shared__ u32 skip_flag;
-    // LDS path: the keys live in REGISTERS between the passes (16 per thread, in (wave, row, lane) = segment order);
-    // one LDS buffer is only the exchange medium of a pass (scatter to the ranked slot, barrier, read the own rows back).
-    // The payload is the 12-bit position inside the segment (the Gaussian ids are gathered once, at the end). 32 KB of
-    // LDS per workgroup instead of 72 KB: 5 workgroups per CU instead of 2.
-    __shared__ u32 sdepth[F3DG_TILE_SORT_CAP];
-    __shared__ unsigned short sidx[F3DG_TILE_SORT_CAP];
-    u32* cursor = sdepth;                               // long-segment path only (it does not use sdepth / sidx)
+    constexpr int WAVES = THREADS / 64;
+    constexpr u32 CAP = (u32)THREADS * ITEMS - 64u;
+    constexpr int DPT = 512 / THREADS;                  // digits of the 512-entry counter table owned by one thread
+    __shared__ u32 cnt[WAVES][512];                     // per-wave digit counters (up to 9-bit digits)
+    __shared__ u32 wtot[WAVES];
+    __shared__ u32 sdepth[CAP];
+    __shared__ unsigned short sidx[CAP];
     if (hdr->overflow) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 lane_lt = ((u64)1 << lane) - 1;
@@ -348,105 +348,142 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstar
     for (u32 seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
         const uint2 range = ranges[seg];
         const u32 n = range.y - range.x;
-        if (n == 0) continue;
-        if ((n > F3DG_TILE_SORT_CAP) != LONG) continue;      // two instantiations: the LDS path keeps 5 workgroups per CU
+        if (n <= n_lo || n > CAP) continue;
         const u32 src0 = gstart[seg];
         __syncthreads();
 
-        if (!LONG) {
-            // ---------------- LDS-resident path
-            const u64 first = keys_src[src0];
-            const u64 hi = first & 0xFFFFFFFF00000000ull;               // (view, tile) bits: constant over the segment
-            const u32 wave_base = (u32)wave * (64 * F3DG_SORT_ITEMS);
-            u32 dk[F3DG_SORT_ITEMS];                                    // depth bits
-            u32 di[F3DG_SORT_ITEMS];                                    // position in the segment (low 16) | rank << 16
-            u32 diff = 0;
-            // all of this thread's global loads are issued before the first one is consumed
+        const u64 first = keys_src[src0];
+        const u64 hi = first & 0xFFFFFFFF00000000ull;               // (view, tile) bits: constant over the segment
+        const u32 wave_base = (u32)wave * (64 * ITEMS);
+        u32 dk[ITEMS];                                              // depth bits
+        u32 di[ITEMS];                                              // position in the segment (low 16) | rank << 16
+        u32 diff = 0;
+        // all of this thread's global loads are issued before the first one is consumed
 #pragma unroll
-            for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                const u32 i = wave_base + (u32)r * 64 + lane;
-                dk[r] = i < n ? (u32)keys_src[src0 + i] : 0xFFFFFFFFu;
-                di[r] = i;
-            }
+        for (int r = 0; r < ITEMS; r++) {
+            const u32 i = wave_base + (u32)r * 64 + lane;
+            dk[r] = i < n ? (u32)keys_src[src0 + i] : 0xFFFFFFFFu;
+            di[r] = i;
+        }
 #pragma unroll
-            for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                const u32 i = wave_base + (u32)r * 64 + lane;
-                if (i < n) diff |= dk[r] ^ (u32)first;
-            }
-            // number of depth bits that actually vary inside this tile -> as few, as narrow (<= 9 bit) passes as possible
+        for (int r = 0; r < ITEMS; r++) {
+            const u32 i = wave_base + (u32)r * 64 + lane;
+            if (i < n) diff |= dk[r] ^ (u32)first;
+        }
+        // number of depth bits that actually vary inside this tile -> as few, as narrow (<= 9 bit) passes as possible
 #pragma unroll
-            for (int m = 32; m > 0; m >>= 1) diff |= __shfl_xor(diff, m, 64);
-            if (lane == 0) wtot[wave] = diff;
+        for (int m = 32; m > 0; m >>= 1) diff |= __shfl_xor(diff, m, 64);
+        if (lane == 0) wtot[wave] = diff;
+        __syncthreads();
+        diff = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) diff |= wtot[w];
+        const int vbits = diff ? 32 - __builtin_clz(diff) : 0;
+        const int npass = (vbits + 8) / 9;
+        const int dbits = npass ? (vbits + npass - 1) / npass : 0;   // <= 9
+        const u32 dmask = (1u << dbits) - 1u;
+        for (int pass = 0; pass < npass; pass++) {
+            const int shift = dbits * pass;
             __syncthreads();
-            diff = wtot[0] | wtot[1] | wtot[2] | wtot[3];
-            const int vbits = diff ? 32 - __builtin_clz(diff) : 0;
-            const int npass = (vbits + 8) / 9;
-            const int dbits = npass ? (vbits + npass - 1) / npass : 0;   // <= 9
-            const u32 dmask = (1u << dbits) - 1u;
-            for (int pass = 0; pass < npass; pass++) {
-                const int shift = dbits * pass;
-                __syncthreads();
-                cnt[0][threadIdx.x] = 0; cnt[0][threadIdx.x + 256] = 0; cnt[1][threadIdx.x] = 0; cnt[1][threadIdx.x + 256] = 0;
-                cnt[2][threadIdx.x] = 0; cnt[2][threadIdx.x + 256] = 0; cnt[3][threadIdx.x] = 0; cnt[3][threadIdx.x + 256] = 0;
-                __syncthreads();
 #pragma unroll
-                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                    if (wave_base + (u32)r * 64 < n) {           // wave-uniform
-                        const bool valid = wave_base + (u32)r * 64 + lane < n;
-                        const u32 rk = wave_rank((dk[r] >> shift) & dmask, valid, cnt[wave], lane_lt, dbits);
-                        di[r] = (di[r] & 0xFFFFu) | (rk << 16);
-                    }
-                }
-                __syncthreads();
-                {
-                    // thread t owns digits 2t and 2t+1: chunk-wide exclusive scan over the (up to) 512 digits
-                    const u32 d0 = 2u * threadIdx.x, d1 = d0 + 1u;
-                    const u32 a0 = cnt[0][d0], a1 = cnt[1][d0], a2 = cnt[2][d0], a3 = cnt[3][d0];
-                    const u32 b0 = cnt[0][d1], b1 = cnt[1][d1], b2 = cnt[2][d1], b3 = cnt[3][d1];
-                    const u32 t0 = a0 + a1 + a2 + a3, t1 = b0 + b1 + b2 + b3;
-                    u32 x = t0 + t1;
+            for (int w = 0; w < WAVES; w++)
 #pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const u32 y = __shfl_up(x, off, 64);
-                        if (lane >= off) x += y;
-                    }
-                    __syncthreads();
-                    if (lane == 63) wtot[wave] = x;
-                    __syncthreads();
-                    u32 e0 = x - (t0 + t1);
-                    for (int w = 0; w < wave; w++) e0 += wtot[w];
-                    const u32 e1 = e0 + t0;
-                    cnt[0][d0] = e0; cnt[1][d0] = e0 + a0; cnt[2][d0] = e0 + a0 + a1; cnt[3][d0] = e0 + a0 + a1 + a2;
-                    cnt[0][d1] = e1; cnt[1][d1] = e1 + b0; cnt[2][d1] = e1 + b0 + b1; cnt[3][d1] = e1 + b0 + b1 + b2;
-                }
-                __syncthreads();
+                for (int q = 0; q < DPT; q++) cnt[w][threadIdx.x + q * THREADS] = 0;
+            __syncthreads();
 #pragma unroll
-                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                    const u32 i = wave_base + (u32)r * 64 + lane;
-                    if (i < n) {
-                        const u32 pos = cnt[wave][(dk[r] >> shift) & dmask] + (di[r] >> 16);
-                        sdepth[pos] = dk[r];
-                        sidx[pos] = (unsigned short)(di[r] & 0xFFFFu);
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
-                    const u32 i = wave_base + (u32)r * 64 + lane;
-                    if (i < n) { dk[r] = sdepth[i]; di[r] = sidx[i]; }
+            for (int r = 0; r < ITEMS; r++) {
+                if (wave_base + (u32)r * 64 < n) {           // wave-uniform
+                    const bool valid = wave_base + (u32)r * 64 + lane < n;
+                    const u32 rk = wave_rank((dk[r] >> shift) & dmask, valid, cnt[wave], lane_lt, dbits);
+                    di[r] = (di[r] & 0xFFFFu) | (rk << 16);
                 }
             }
-            // registers hold the sorted segment in (wave, row, lane) order: coalesced stores, ids gathered from the source
+            __syncthreads();
+            {
+                // thread t owns the DPT consecutive digits DPT*t ..: chunk-wide exclusive scan over the (up to) 512 digits
+                u32 tot[DPT], x = 0;
 #pragma unroll
-            for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
+                for (int q = 0; q < DPT; q++) {
+                    tot[q] = 0;
+#pragma unroll
+                    for (int w = 0; w < WAVES; w++) tot[q] += cnt[w][DPT * threadIdx.x + q];
+                    x += tot[q];
+                }
+                const u32 mine = x;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const u32 y = __shfl_up(x, off, 64);
+                    if (lane >= off) x += y;
+                }
+                __syncthreads();
+                if (lane == 63) wtot[wave] = x;
+                __syncthreads();
+                u32 e = x - mine;
+                for (int w = 0; w < wave; w++) e += wtot[w];
+#pragma unroll
+                for (int q = 0; q < DPT; q++) {
+                    u32 run = e;
+#pragma unroll
+                    for (int w = 0; w < WAVES; w++) {
+                        const u32 c = cnt[w][DPT * threadIdx.x + q];
+                        cnt[w][DPT * threadIdx.x + q] = run;
+                        run += c;
+                    }
+                    e += tot[q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
                 const u32 i = wave_base + (u32)r * 64 + lane;
                 if (i < n) {
-                    vals_dst[range.x + i] = vals_src[src0 + (di[r] & 0xFFFFu)];
-                    keys_dst[range.x + i] = hi | dk[r];
+                    const u32 pos = cnt[wave][(dk[r] >> shift) & dmask] + (di[r] >> 16);
+                    sdepth[pos] = dk[r];
+                    sidx[pos] = (unsigned short)(di[r] & 0xFFFFu);
                 }
             }
-            continue;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                const u32 i = wave_base + (u32)r * 64 + lane;
+                if (i < n) { dk[r] = sdepth[i]; di[r] = sidx[i]; }
+            }
         }
+        // registers hold the sorted segment in (wave, row, lane) order: coalesced stores, ids gathered from the source
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const u32 i = wave_base + (u32)r * 64 + lane;
+            if (i < n) {
+                vals_dst[range.x + i] = vals_src[src0 + (di[r] & 0xFFFFu)];
+                keys_dst[range.x + i] = hi | dk[r];
+            }
+        }
+    }
+}
+
+// Segments above the LDS capacities: 8-bit LSD passes through global memory (a scratch slice <-> the final slice, both
+// L2 / Infinity-Cache resident), chunk by chunk with running per-digit cursors; one workgroup per segment.
+__global__ void __launch_bounds__(F3DG_BLOCK, 2)
+tile_sort_long_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
+                      const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */,
+                      const u64* __restrict__ keys_src, const u32* __restrict__ vals_src,
+                      u64* __restrict__ keys_dst, u32* __restrict__ vals_dst,
+                      u64* __restrict__ keys_tmp, u32* __restrict__ vals_tmp)
+{
+    __shared__ u32 cnt[F3DG_BLOCK / 64][256];
+    __shared__ u32 cursor[256];
+    __shared__ u32 wtot[F3DG_BLOCK / 64];
+    __shared__ u32 skip_flag;
+    if (hdr->overflow) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 lane_lt = ((u64)1 << lane) - 1;
+
+    for (u32 seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+        const uint2 range = ranges[seg];
+        const u32 n = range.y - range.x;
+        if (n <= n_lo) continue;
+        const u32 src0 = gstart[seg];
+        __syncthreads();
 
         // ---------------- long segment: copy to the scratch slice, then ping-pong scratch <-> final slice
         for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
@@ -628,11 +665,14 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
     hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges);
 
     // 5. level 2: per-(view, tile) stable sort by the depth bits: gather the group from half 1, write it sorted to half 0
-    hipLaunchKernelGGL((tile_sort_kernel<false>), dim3(nseg < 65535u * 16u ? nseg : 65535u * 16u), dim3(F3DG_BLOCK), 0, s, ranges, gstart,
-                       nseg, hdr, keys[1], vals[1], keys[0], vals[0], keys[2], vals[2]);
-    // segments above the LDS capacity (rare: > 4032 Gaussians in one tile of one view): a few workgroups stride over all
-    hipLaunchKernelGGL((tile_sort_kernel<true>), dim3(nseg < 1024u ? nseg : 1024u), dim3(F3DG_BLOCK), 0, s, ranges, gstart,
-                       nseg, hdr, keys[1], vals[1], keys[0], vals[0], keys[2], vals[2]);
+    //    three tiers by segment length (each kernel skips the segments of the others): <= 4032, <= 16320, longer
+    const u32 sort_grid = nseg < 65535u * 16u ? nseg : 65535u * 16u;
+    hipLaunchKernelGGL((tile_sort_lds_kernel<256, 16>), dim3(sort_grid), dim3(256), 0, s, ranges, gstart, nseg, hdr, 0u,
+                       keys[1], vals[1], keys[0], vals[0]);
+    hipLaunchKernelGGL((tile_sort_lds_kernel<512, 32>), dim3(sort_grid), dim3(512), 0, s, ranges, gstart, nseg, hdr,
+                       (u32)(256 * 16 - 64), keys[1], vals[1], keys[0], vals[0]);
+    hipLaunchKernelGGL(tile_sort_long_kernel, dim3(nseg < 4096u ? nseg : 4096u), dim3(F3DG_BLOCK), 0, s, ranges, gstart, nseg, hdr,
+                       (u32)(512 * 32 - 64), keys[1], vals[1], keys[0], vals[0], keys[2], vals[2]);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

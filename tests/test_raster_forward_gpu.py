@@ -19,7 +19,8 @@ SCENES = {
     "F5_odd_size": dict(P=4000, res=(100, 72), s0=0.04, view="oblique"),
     "F6_small_splats": dict(P=30000, res=(128, 128), s0=0.01, view="oblique"),
     "F8_sh0": dict(P=1500, res=(64, 64), s0=0.05, view="oblique", sh_degree=0),
-    "F9_long_tile_lists": dict(P=30000, res=(128, 128), s0=0.05, view="oblique"),      # lists > 4096: global-memory tile sort path
+    "F9_long_tile_lists": dict(P=30000, res=(128, 128), s0=0.05, view="oblique"),      # lists of 4k..16k: 512-thread LDS tile sort
+    "F10_huge_tile_lists": dict(P=50000, res=(32, 32), s0=0.05, view="canonical"),     # lists > 16320: global-memory tile sort path
 }
 
 
