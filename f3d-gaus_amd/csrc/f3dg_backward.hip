@@ -36,8 +36,51 @@ __device__ __forceinline__ double wave_sum_f64(float v)
     return d;
 }
 
+
+// Wave64 sums on the VALU with DPP (no LDS traffic): inclusive row scans (row_shr 1, 2, 4, 8 with zero fill), then the
+// row totals are folded across the four rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3). The total
+// ends up in lane 63. The backward kernel is LDS-pipe-bound with ds_bpermute butterflies or LDS atomics (measured:
+// SQ_ACTIVE_INST_LDS ~ the kernel time), while its VALU is mostly idle.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+#define F3DG_DPP_ROW_SHR(n) (0x110 + (n))
+#define F3DG_DPP_ROW_BCAST15 0x142
+#define F3DG_DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ float wave_total_lane63(float v)
+{
+    v += dpp_f32<F3DG_DPP_ROW_SHR(1), 0xF>(v);
+    v += dpp_f32<F3DG_DPP_ROW_SHR(2), 0xF>(v);
+    v += dpp_f32<F3DG_DPP_ROW_SHR(4), 0xF>(v);
+    v += dpp_f32<F3DG_DPP_ROW_SHR(8), 0xF>(v);
+    v += dpp_f32<F3DG_DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_f32<F3DG_DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_total_lane63_f64(float f)
+{
+    double v = (double)f;
+    v += dpp_f64<F3DG_DPP_ROW_SHR(1), 0xF>(v);
+    v += dpp_f64<F3DG_DPP_ROW_SHR(2), 0xF>(v);
+    v += dpp_f64<F3DG_DPP_ROW_SHR(4), 0xF>(v);
+    v += dpp_f64<F3DG_DPP_ROW_SHR(8), 0xF>(v);
+    v += dpp_f64<F3DG_DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_f64<F3DG_DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+
 __global__ void __launch_bounds__(F3DG_BLOCK)
-render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
                   const float2* __restrict__ means2D, const float4* __restrict__ conic,
@@ -252,6 +295,296 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                          s_v6 = wave_sum_f64(g_v6), s_v7 = wave_sum_f64(g_v7), s_v8 = wave_sum_f64(g_v8),
                          s_v9 = wave_sum_f64(g_v9);
             if (lane0) {
+                const unsigned id = staged_id[j];
+                const size_t gi = vP + id;
+                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 0], g_col0);
+                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 1], g_col1);
+                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 2], g_col2);
+                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 0], g_mx);
+                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 1], g_my);
+                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 2], g_mz);
+                unsafeAtomicAdd(&dL_dopacity[id], g_op);
+                double* a = dL_dv2g_acc + gi * 10;
+                unsafeAtomicAdd(a + 0, s_v0); unsafeAtomicAdd(a + 1, s_v1);
+                unsafeAtomicAdd(a + 2, s_v2); unsafeAtomicAdd(a + 3, s_v3);
+                unsafeAtomicAdd(a + 4, s_v4); unsafeAtomicAdd(a + 5, s_v5);
+                unsafeAtomicAdd(a + 6, s_v6); unsafeAtomicAdd(a + 7, s_v7);
+                unsafeAtomicAdd(a + 8, s_v8); unsafeAtomicAdd(a + 9, s_v9);
+            }
+        }
+    }
+}
+
+
+// ---- culled + DPP-reduced variant (the default) -------------------------------------------------------------------
+// Same arithmetic per contributing (pixel, Gaussian) pair as render_bwd_lockstep_kernel above, but
+//   * a wave owns an 8x8 pixel quadrant (not a 16x4 strip) and walks only the staged entries whose conservative
+//     alpha >= 1/255 box (written by the forward's preprocess) touches its quadrant -- every skipped pair is one the
+//     reference `continue`s on (backward.cu:773-777), so no per-pixel state changes;
+//   * the 17 partials are not butterflied over all 64 lanes (102 cross-lane exchanges + 60 float64 adds per
+//     (wave, Gaussian), although only a handful of lanes contribute): the contributing lanes add them into 17 per-wave
+//     LDS accumulators (ds_add_f32 / ds_add_f64), then lanes 0..16 each swap one accumulator out and issue ONE global
+//     atomic in parallel. float64 accumulation of dL/dview2gaussian is kept.
+// The position of an entry from the front of the list is computed from its staged slot, so skipped entries need no counter.
+__global__ void __launch_bounds__(F3DG_BLOCK)
+render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                  const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                  const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                  const float4* __restrict__ bbox,
+                  const float2* __restrict__ means2D, const float4* __restrict__ conic,
+                  const float* __restrict__ background, int bg_per_view,
+                  const float* __restrict__ final_T, const unsigned* __restrict__ n_contrib,
+                  const float* __restrict__ dL_dpixels,
+                  float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
+                  double* __restrict__ dL_dv2g_acc)
+{
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned slot = blockIdx.x >> 3;
+    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
+    const unsigned tile = slot % (unsigned)T;
+    if (view >= (unsigned)V)
+        return;
+
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+    const unsigned pix_x = tile_x * F3DG_TILE + lx, pix_y = tile_y * F3DG_TILE + ly;
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+
+    __shared__ float4 sq0[F3DG_BLOCK], sq1[F3DG_BLOCK], sq2[F3DG_BLOCK], sq3[F3DG_BLOCK];
+    __shared__ float4 staged_conic[F3DG_BLOCK];
+    __shared__ float2 staged_xy[F3DG_BLOCK];
+    __shared__ unsigned staged_id[F3DG_BLOCK];
+    __shared__ unsigned char quad_mask[F3DG_BLOCK];
+    __shared__ unsigned char wave_list[F3DG_BLOCK / 64][F3DG_BLOCK];
+    __shared__ int block_last_s;
+    if (threadIdx.x == 0) block_last_s = 0;
+
+    const size_t vP = (size_t)view * P;
+    const float4* vbox = bbox + vP;
+    const float* fT = final_T + (size_t)view * 4 * HW;
+    const unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+    const float* dpix = dL_dpixels + (size_t)view * F3DG_OUT_CHANNELS * HW;
+    const float* bg = background + (bg_per_view ? 3 * view : 0);
+    const float tile_px0 = (float)(tile_x * F3DG_TILE), tile_py0 = (float)(tile_y * F3DG_TILE);
+
+    const float T_final = inside ? fT[pix_id] : 0;
+    float Tr = T_final;
+    const float final_D = inside ? fT[pix_id + HW] : 0;
+    const float final_A = 1 - T_final;
+    const float dL_dreg = inside ? dpix[8 * HW + pix_id] : 0;
+
+    const int last_contributor = inside ? (int)nc[pix_id] : 0;
+    const int max_contributor = inside ? (int)nc[pix_id + HW] : 0;
+    float accum_rec0 = 0, accum_rec1 = 0, accum_rec2 = 0;
+    float dpx0 = 0, dpx1 = 0, dpx2 = 0, dn0 = 0, dn1 = 0, dn2 = 0, dL_dmax_depth = 0;
+    if (inside) {
+        dpx0 = dpix[pix_id]; dpx1 = dpix[HW + pix_id]; dpx2 = dpix[2 * HW + pix_id];
+        dn0 = dpix[3 * HW + pix_id]; dn1 = dpix[4 * HW + pix_id]; dn2 = dpix[5 * HW + pix_id];
+        dL_dmax_depth = dpix[6 * HW + pix_id];
+    }
+    float last_alpha = 0;
+    float last_c0 = 0, last_c1 = 0, last_c2 = 0;
+    float last_n0 = 0, last_n1 = 0, last_n2 = 0;
+    float acc_n0 = 0, acc_n1 = 0, acc_n2 = 0;
+    const float ddelx_dx = (float)(0.5 * W);
+    const float ddely_dy = (float)(0.5 * H);
+    const float bg_dot_dpixel = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
+    // Entries at or behind a pixel's last contributor are skipped by the reference one by one (backward.cu:745-746); the
+    // tile starts at the deepest last contributor of its 256 pixels instead of staging the whole list from the back
+    // (with opaque scenes the forward stops after a small part of an 8 k-entry list, and so does this).
+    const int wave_last = (int)__builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, last_contributor));
+    __syncthreads();
+    if (lane == 0) atomicMax(&block_last_s, wave_last);
+    __syncthreads();
+    const int block_last = min(block_last_s, (int)(range.y - range.x));      // entries [0, block_last) can contribute
+    const int rounds = (block_last + F3DG_BLOCK - 1) / F3DG_BLOCK;
+    int toDo = block_last;
+
+    for (int i = 0; i < rounds; i++, toDo -= F3DG_BLOCK) {
+        __syncthreads();
+        const int progress = i * F3DG_BLOCK + (int)threadIdx.x;
+        if (progress < block_last) {
+            const unsigned id = point_list[range.x + (unsigned)(block_last - 1 - progress)];       // back to front
+            const float4* src = reinterpret_cast<const float4*>(rec + vP + id);
+            sq0[threadIdx.x] = src[0];
+            sq1[threadIdx.x] = src[1];
+            sq2[threadIdx.x] = src[2];
+            sq3[threadIdx.x] = src[3];
+            staged_conic[threadIdx.x] = conic[vP + id];
+            staged_xy[threadIdx.x] = means2D[vP + id];
+            staged_id[threadIdx.x] = id;
+            const float4 bx = vbox[id];
+            const unsigned mx = (bx.x <= tile_px0 + 7.0f && bx.y >= tile_px0 ? 1u : 0u) |
+                                (bx.x <= tile_px0 + 15.0f && bx.y >= tile_px0 + 8.0f ? 2u : 0u);
+            const unsigned my = (bx.z <= tile_py0 + 7.0f && bx.w >= tile_py0 ? 1u : 0u) |
+                                (bx.z <= tile_py0 + 15.0f && bx.w >= tile_py0 + 8.0f ? 2u : 0u);
+            quad_mask[threadIdx.x] = (unsigned char)(((mx & 1u) && (my & 1u) ? 1u : 0u) | ((mx & 2u) && (my & 1u) ? 2u : 0u) |
+                                                     ((mx & 1u) && (my & 2u) ? 4u : 0u) | ((mx & 2u) && (my & 2u) ? 8u : 0u));
+        } else {
+            quad_mask[threadIdx.x] = 0;
+        }
+        __syncthreads();
+
+        // entries of this round are front positions [first_front - n + 1, first_front]; nothing to do while the whole
+        // round lies behind every pixel's last contributor
+        const int first_front = block_last - 1 - i * F3DG_BLOCK;
+        const int n = min(F3DG_BLOCK, toDo);
+        if (first_front - n + 1 >= wave_last)
+            continue;
+        int count = 0;
+#pragma unroll
+        for (int c = 0; c < F3DG_BLOCK / 64; c++) {
+            const unsigned e = c * 64 + lane;
+            const bool bit = (quad_mask[e] >> wave) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            if (bit) wave_list[wave][count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)e;
+            count += __popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        for (int kk = 0; kk < count; kk++) {
+            const int j = (int)wave_list[wave][kk];
+            const int contributor = first_front - j;                       // 0-based position from the front
+            bool active = inside && contributor < last_contributor;
+
+            const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j];
+            const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+            const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+            const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+            const float aaf = ray_x * n0 + ray_y * n1 + n2;
+            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+            // the forward's conservative pre-test (f3dg_render.hip): a true test proves alpha < 1/255, i.e. `continue`
+            if (bhalf * bhalf < q2.w * aaf) active = false;
+            if (__ballot(active) == 0)
+                continue;
+
+            const double AA = aaf;
+            const double BB = 2 * bhalf;
+            const float CC = q2.y;
+            float t = 0, G = 0, alpha = 0;
+            if (active) {
+                t = (float)(-BB / (2 * AA));
+                if (t <= F3DG_NEAR_PLANE) active = false;
+                const double min_value = -(BB / AA) * (BB / 4.) + CC;
+                float power = (float)(-0.5f * min_value);
+                if (power > 0.0f) power = 0.0f;
+                G = expf(power);
+                alpha = fminf(0.99f, q2.z * G);
+                if (alpha < 1.0f / 255.0f) active = false;
+            }
+            if (__ballot(active) == 0)
+                continue;
+
+            float g_col0 = 0, g_col1 = 0, g_col2 = 0, g_mx = 0, g_my = 0, g_mz = 0, g_op = 0;
+            float g_v0 = 0, g_v1 = 0, g_v2 = 0, g_v3 = 0, g_v4 = 0, g_v5 = 0, g_v6 = 0, g_v7 = 0, g_v8 = 0, g_v9 = 0;
+            if (active) {
+                const float4 q3 = sq3[j];
+                const float4 con = staged_conic[j];
+                const float2 xy = staged_xy[j];
+                const float d_x = (float)(xy.x - (pixf_x - 0.5)), d_y = (float)(xy.y - (pixf_y - 0.5));
+
+                const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
+                const float dmax_t_dd = (float)((F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t * t));
+                const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
+                const float nn0 = -n0 / length, nn1 = -n1 / length, nn2 = -n2 / length;
+
+                Tr = Tr / (1.f - alpha);
+                const float dchannel_dcolor = alpha * Tr;
+
+                float dL_dalpha = 0.0f;
+                const float c0 = q3.x, c1 = q3.y, c2 = q3.z;
+                accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0; last_c0 = c0;
+                dL_dalpha += (c0 - accum_rec0) * dpx0;
+                g_col0 = dchannel_dcolor * dpx0;
+                accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1; last_c1 = c1;
+                dL_dalpha += (c1 - accum_rec1) * dpx1;
+                g_col1 = dchannel_dcolor * dpx1;
+                accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2; last_c2 = c2;
+                dL_dalpha += (c2 - accum_rec2) * dpx2;
+                g_col2 = dchannel_dcolor * dpx2;
+
+                float dL_dmax_t = 0.0f;
+                dL_dmax_t += 2.0f * (Tr * alpha) * (mapped_max_t * final_A - final_D) * dL_dreg * dmax_t_dd;
+                dL_dalpha += 0.f - 0.f;
+
+                acc_n0 = last_alpha * last_n0 + (1.f - last_alpha) * acc_n0; last_n0 = nn0;
+                dL_dalpha += (nn0 - acc_n0) * dn0;
+                const float dnn0 = alpha * Tr * dn0;
+                acc_n1 = last_alpha * last_n1 + (1.f - last_alpha) * acc_n1; last_n1 = nn1;
+                dL_dalpha += (nn1 - acc_n1) * dn1;
+                const float dnn1 = alpha * Tr * dn1;
+                acc_n2 = last_alpha * last_n2 + (1.f - last_alpha) * acc_n2; last_n2 = nn2;
+                dL_dalpha += (nn2 - acc_n2) * dn2;
+                const float dnn2 = alpha * Tr * dn2;
+
+                float dL_dlength = (dnn0 * n0 + dnn1 * n1 + dnn2 * n2);
+                dL_dlength *= 1.f / (length * length);
+                float dLn0 = (-dnn0 + dL_dlength * n0) / length;
+                float dLn1 = (-dnn1 + dL_dlength * n1) / length;
+                float dLn2 = (-dnn2 + dL_dlength * n2) / length;
+
+                float dL_dt = dL_dmax_t;
+                if (contributor == max_contributor - 1)
+                    dL_dt += dL_dmax_depth;
+
+                dL_dalpha *= Tr;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+                const float dL_dG = con.w * dL_dalpha;
+                const float gdx = G * d_x;
+                const float gdy = G * d_y;
+                const float dG_ddelx = -gdx * con.x - gdy * con.y;
+                const float dG_ddely = -gdy * con.z - gdx * con.y;
+                g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                g_my = dL_dG * dG_ddely * ddely_dy;
+                g_mz = fabsf(dL_dG * dG_ddelx * ddelx_dx) + fabsf(dL_dG * dG_ddely * ddely_dy);
+                g_op = G * dL_dalpha;
+
+                const float dL_dpower = dL_dG * G;
+                const float dL_dmin_value = dL_dpower * -0.5f;
+                double dL_dA = dL_dmin_value * (BB / AA) * (BB / AA) / 4.f;
+                double dL_dB = dL_dmin_value * -BB / (2 * AA);
+                const double dL_dC = dL_dmin_value * 1.0f;
+                dL_dA += dL_dt * BB / (2 * AA * AA);
+                dL_dB += dL_dt * -1.f / (2 * AA);
+                dLn0 += dL_dA * ray_x;
+                dLn1 += dL_dA * ray_y;
+                dLn2 += dL_dA;
+
+                g_v0 = dLn0 * ray_x;
+                g_v1 = dLn0 * ray_y + dLn1 * ray_x;
+                g_v2 = dLn0 + dLn2 * ray_x;
+                g_v3 = dLn1 * ray_y;
+                g_v4 = dLn1 + dLn2 * ray_y;
+                g_v5 = dLn2;
+                g_v6 = (float)(dL_dB * 2 * ray_x);
+                g_v7 = (float)(dL_dB * 2 * ray_y);
+                g_v8 = (float)(dL_dB * 2);
+                g_v9 = (float)dL_dC;
+            }
+
+            // sum the 17 partials over the wave's 64 pixels on the VALU (DPP), lane 63 updates memory
+            g_col0 = wave_total_lane63(g_col0); g_col1 = wave_total_lane63(g_col1); g_col2 = wave_total_lane63(g_col2);
+            g_mx = wave_total_lane63(g_mx); g_my = wave_total_lane63(g_my); g_mz = wave_total_lane63(g_mz);
+            g_op = wave_total_lane63(g_op);
+            const double s_v0 = wave_total_lane63_f64(g_v0), s_v1 = wave_total_lane63_f64(g_v1),
+                         s_v2 = wave_total_lane63_f64(g_v2), s_v3 = wave_total_lane63_f64(g_v3),
+                         s_v4 = wave_total_lane63_f64(g_v4), s_v5 = wave_total_lane63_f64(g_v5),
+                         s_v6 = wave_total_lane63_f64(g_v6), s_v7 = wave_total_lane63_f64(g_v7),
+                         s_v8 = wave_total_lane63_f64(g_v8), s_v9 = wave_total_lane63_f64(g_v9);
+            if (lane == 63) {
                 const unsigned id = staged_id[j];
                 const size_t gi = vP + id;
                 unsafeAtomicAdd(&dL_dcolors[gi * 3 + 0], g_col0);
@@ -588,13 +921,23 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     F3DG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * 10 * (size_t)n_views * P, s));
 
     const unsigned groups = (unsigned)((n_views + 7) / 8);
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(groups * 8u * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
-                       tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
-                       reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
-                       reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
-                       background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
-                       reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
-                       acc);
+    if (g_f3dg_render_cull)
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(groups * 8u * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
+                           tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
+                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
+                           reinterpret_cast<const float4*>(ws + L.bbox),
+                           reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
+                           background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
+                           reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
+                           acc);
+    else     // option render_cull = 0: the lock-step kernel (every lane visits every entry, wave butterflies), kept for A/B
+        hipLaunchKernelGGL(render_bwd_lockstep_kernel, dim3(groups * 8u * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
+                           tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
+                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
+                           reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
+                           background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
+                           reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
+                           acc);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK, n_views), dim3(F3DG_BLOCK), 0, s, P,
                        D, M, means3D, radii_used, shs, reinterpret_cast<const unsigned char*>(ws + L.clamped), scales,
                        rotations, viewmatrix, cam_pos, acc, dL_dview2gaussian, dL_dcolor, dL_dmean3D, dL_dsh, dL_dscale,
