@@ -114,11 +114,19 @@ scan_apply_kernel(const u32* in, u32* out /* may alias in */, u64 n, const u32* 
 }
 
 // ------------------------------------------------------------------------------------------------ keys
+// The unsorted and the tile-grouped instance buffers are three streams (structure of arrays), not u64 keys:
+//   depth [cap] u32 : the IEEE bits of the view-space depth (only read again by the per-tile sort)
+//   grp   [cap] G   : (view << tile_bits) | tile -- the only thing the histogram / group-bounds kernels read. G is u16
+//                     whenever V << tile_bits fits (C2: 120 views x 256 tiles), so those kernels move 2 B instead of 8 B
+//   val   [cap] u32 : Gaussian id
+// depth and grp share the 8-byte-per-instance region that held the u64 keys. Only the FINAL, depth-sorted buffer (half 0)
+// keeps u64 keys ((grp << 32) | depth), which is what the debug export and the tests read.
+template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 duplicate_keys_kernel(int P, int tile_bits, int grid_x, int grid_y, const float2* __restrict__ means2D,
                       const float* __restrict__ depths, const u32* __restrict__ offsets,
                       const int* __restrict__ radii, const F3dgHeader* __restrict__ hdr,
-                      u64* __restrict__ keys, u32* __restrict__ vals)
+                      u32* __restrict__ kdepth, G* __restrict__ kgrp, u32* __restrict__ vals)
 {
     if (hdr->overflow) return;
     const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
@@ -134,13 +142,11 @@ duplicate_keys_kernel(int P, int tile_bits, int grid_x, int grid_y, const float2
         const int rmaxx = min(grid_x, max(0, (int)((p.x + radius + F3DG_TILE - 1) / F3DG_TILE)));
         const int rmaxy = min(grid_y, max(0, (int)((p.y + radius + F3DG_TILE - 1) / F3DG_TILE)));
         const u32 depth_bits = __float_as_uint(depths[idx]);
-        const u64 view_base = (u64)v << tile_bits;
+        const u32 view_base = (u32)v << tile_bits;
         for (int y = rminy; y < rmaxy; y++)
             for (int x = rminx; x < rmaxx; x++) {
-                u64 key = view_base | (u64)(y * grid_x + x);
-                key <<= 32;
-                key |= depth_bits;
-                keys[off] = key;
+                kdepth[off] = depth_bits;
+                kgrp[off] = (G)(view_base | (u32)(y * grid_x + x));
                 vals[off] = (u32)g;
                 off++;
             }
@@ -148,8 +154,9 @@ duplicate_keys_kernel(int P, int tile_bits, int grid_x, int grid_y, const float2
 }
 
 // ------------------------------------------------------------------------------------------------ sort
+template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
-radix_hist_kernel(const u64* __restrict__ keys, const F3dgHeader* __restrict__ hdr, int shift, u32 nblocks,
+radix_hist_kernel(const G* __restrict__ kgrp, const F3dgHeader* __restrict__ hdr, int shift, u32 nblocks,
                   u32* __restrict__ hist /* [256][nblocks] */)
 {
     __shared__ u32 h[256];
@@ -161,16 +168,18 @@ radix_hist_kernel(const u64* __restrict__ keys, const F3dgHeader* __restrict__ h
 #pragma unroll
         for (int i = 0; i < F3DG_SORT_ITEMS; i++) {
             const u64 k = base + (u64)i * F3DG_BLOCK + threadIdx.x;
-            if (k < n) atomicAdd(&h[(u32)(keys[k] >> shift) & 255u], 1u);
+            if (k < n) atomicAdd(&h[((u32)kgrp[k] >> shift) & 255u], 1u);
         }
         __syncthreads();
     }
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
-radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in, u64* __restrict__ keys_out,
-                     u32* __restrict__ vals_out, const F3dgHeader* __restrict__ hdr, int shift, u32 nblocks,
+radix_scatter_kernel(const u32* __restrict__ kdepth_in, const G* __restrict__ kgrp_in, const u32* __restrict__ vals_in,
+                     u32* __restrict__ kdepth_out, G* __restrict__ kgrp_out, u32* __restrict__ vals_out,
+                     const F3dgHeader* __restrict__ hdr, int shift, u32 nblocks,
                      const u32* __restrict__ offsets /* exclusive scan of hist, [256][nblocks] */)
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out: consecutive LDS slots of one digit
@@ -180,7 +189,8 @@ radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ va
     __shared__ u32 lbase[256];          // first LDS slot of each digit inside the chunk
     __shared__ u32 gdelta[256];         // global position of a digit's first element minus lbase
     __shared__ u32 wtot[F3DG_BLOCK / 64];
-    __shared__ u64 skey[F3DG_SORT_CHUNK];
+    __shared__ u32 sdep[F3DG_SORT_CHUNK];
+    __shared__ G sgrp[F3DG_SORT_CHUNK];
     __shared__ u32 sval[F3DG_SORT_CHUNK];
     const u32 n = hdr->overflow ? 0u : hdr->num_rendered;
     const u64 block_base = (u64)blockIdx.x * F3DG_SORT_CHUNK;
@@ -192,17 +202,24 @@ radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ va
     __syncthreads();
 
     const u64 wave_base = block_base + (u64)wave * (64 * F3DG_SORT_ITEMS);
-    u64 key[F3DG_SORT_ITEMS];
+    u32 dep[F3DG_SORT_ITEMS];
+    u32 grp[F3DG_SORT_ITEMS];
     u32 val[F3DG_SORT_ITEMS];
     u32 rank[F3DG_SORT_ITEMS];
     const u64 lane_lt = ((u64)1 << lane) - 1;
 #pragma unroll
+    for (int r = 0; r < F3DG_SORT_ITEMS; r++) {          // all loads first
+        const u64 i = wave_base + (u64)r * 64 + lane;
+        const bool valid = i < n;
+        dep[r] = valid ? kdepth_in[i] : 0u;
+        grp[r] = valid ? (u32)kgrp_in[i] : 0u;
+        val[r] = valid ? vals_in[i] : 0u;
+    }
+#pragma unroll
     for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
         const u64 i = wave_base + (u64)r * 64 + lane;
         const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : ~(u64)0;
-        val[r] = valid ? vals_in[i] : 0u;
-        const u32 d = (u32)(key[r] >> shift) & 255u;
+        const u32 d = (grp[r] >> shift) & 255u;
         u64 same = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -245,18 +262,20 @@ radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ va
     for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
         const u64 i = wave_base + (u64)r * 64 + lane;
         if (i < n) {
-            const u32 d = (u32)(key[r] >> shift) & 255u;
+            const u32 d = (grp[r] >> shift) & 255u;
             const u32 slot = cnt[wave][d] + rank[r];
-            skey[slot] = key[r];
+            sdep[slot] = dep[r];
+            sgrp[slot] = (G)grp[r];
             sval[slot] = val[r];
         }
     }
     __syncthreads();
     for (u32 slot = threadIdx.x; slot < in_block; slot += F3DG_BLOCK) {
-        const u64 k = skey[slot];
-        const u32 d = (u32)(k >> shift) & 255u;
+        const G k = sgrp[slot];
+        const u32 d = ((u32)k >> shift) & 255u;
         const u32 pos = gdelta[d] + slot;
-        keys_out[pos] = k;
+        kdepth_out[pos] = sdep[slot];
+        kgrp_out[pos] = k;
         vals_out[pos] = sval[slot];
     }
 }
@@ -292,17 +311,18 @@ __device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 l
 }
 
 // (view, tile) groups of the tile-sorted buffer: first / one-past-last index of every group, indexed view * T + tile
+template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
-group_bounds_kernel(const u64* __restrict__ keys, const F3dgHeader* __restrict__ hdr, int tile_bits, int T,
+group_bounds_kernel(const G* __restrict__ kgrp, const F3dgHeader* __restrict__ hdr, int tile_bits, int T,
                     u32* __restrict__ gstart, u32* __restrict__ gend)
 {
     const u32 L = hdr->overflow ? 0u : hdr->num_rendered;
     const u32 tmask = (1u << tile_bits) - 1u;
     for (u64 idx = (u64)blockIdx.x * F3DG_BLOCK + threadIdx.x; idx < L; idx += (u64)gridDim.x * F3DG_BLOCK) {
-        const u32 cur = (u32)(keys[idx] >> 32);
+        const u32 cur = (u32)kgrp[idx];
         const u32 seg = (cur >> tile_bits) * (u32)T + (cur & tmask);
-        if (idx == 0 || (u32)(keys[idx - 1] >> 32) != cur) gstart[seg] = (u32)idx;
-        if (idx == L - 1 || (u32)(keys[idx + 1] >> 32) != cur) gend[seg] = (u32)idx + 1u;
+        if (idx == 0 || (u32)kgrp[idx - 1] != cur) gstart[seg] = (u32)idx;
+        if (idx == L - 1 || (u32)kgrp[idx + 1] != cur) gend[seg] = (u32)idx + 1u;
     }
 }
 
@@ -330,8 +350,8 @@ group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restr
 template <int THREADS, int ITEMS>
 __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1)
 tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
-                     const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */,
-                     const u64* __restrict__ keys_src, const u32* __restrict__ vals_src,     // tile-grouped buffer
+                     const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */, int tile_bits, int T,
+                     const u32* __restrict__ kdepth_src, const u32* __restrict__ vals_src,   // tile-grouped streams
                      u64* __restrict__ keys_dst, u32* __restrict__ vals_dst)                 // final buffer (half 0)
 {
     constexpr int WAVES = THREADS / 64;
@@ -352,8 +372,8 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
         const u32 src0 = gstart[seg];
         __syncthreads();
 
-        const u64 first = keys_src[src0];
-        const u64 hi = first & 0xFFFFFFFF00000000ull;               // (view, tile) bits: constant over the segment
+        const u32 first = kdepth_src[src0];
+        const u64 hi = (u64)(((seg / (u32)T) << tile_bits) | (seg % (u32)T)) << 32;   // (view, tile) bits of the final key
         const u32 wave_base = (u32)wave * (64 * ITEMS);
         u32 dk[ITEMS];                                              // depth bits
         u32 di[ITEMS];                                              // position in the segment (low 16) | rank << 16
@@ -362,13 +382,13 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
             const u32 i = wave_base + (u32)r * 64 + lane;
-            dk[r] = i < n ? (u32)keys_src[src0 + i] : 0xFFFFFFFFu;
+            dk[r] = i < n ? kdepth_src[src0 + i] : 0xFFFFFFFFu;
             di[r] = i;
         }
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
             const u32 i = wave_base + (u32)r * 64 + lane;
-            if (i < n) diff |= dk[r] ^ (u32)first;
+            if (i < n) diff |= dk[r] ^ first;
         }
         // number of depth bits that actually vary inside this tile -> as few, as narrow (<= 9 bit) passes as possible
 #pragma unroll
@@ -465,8 +485,8 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
 // L2 / Infinity-Cache resident), chunk by chunk with running per-digit cursors; one workgroup per segment.
 __global__ void __launch_bounds__(F3DG_BLOCK, 2)
 tile_sort_long_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
-                      const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */,
-                      const u64* __restrict__ keys_src, const u32* __restrict__ vals_src,
+                      const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */, int tile_bits, int T,
+                      const u32* __restrict__ kdepth_src, const u32* __restrict__ vals_src,
                       u64* __restrict__ keys_dst, u32* __restrict__ vals_dst,
                       u64* __restrict__ keys_tmp, u32* __restrict__ vals_tmp)
 {
@@ -486,8 +506,9 @@ tile_sort_long_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ 
         __syncthreads();
 
         // ---------------- long segment: copy to the scratch slice, then ping-pong scratch <-> final slice
+        const u64 hi = (u64)(((seg / (u32)T) << tile_bits) | (seg % (u32)T)) << 32;
         for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
-            keys_tmp[range.x + i] = keys_src[src0 + i];
+            keys_tmp[range.x + i] = hi | kdepth_src[src0 + i];
             vals_tmp[range.x + i] = vals_src[src0 + i];
         }
         __threadfence_block();
@@ -614,6 +635,58 @@ int f3dg_sort_passes(int V, int T)
     return bits == 0 ? 0 : (bits + 7) / 8;
 }
 
+template <typename G>
+static int binning_tail(hipStream_t s, int V, int P, int grid_x, int grid_y, int T, int tile_bits, const F3dgLayout& L, char* ws,
+                        const int* radii, F3dgHeader* hdr, u32* offsets, u32* scan_tmp, u64** keys, u32** vals, u32* hist,
+                        uint2* ranges, u32* gstart, u32* gend, u32* gcount, u32 nseg)
+{
+    int rc = F3DG_OK;
+    const size_t hdr_capacity = (L.keys[1] - L.keys[0]) / 8;      // >= the instance capacity (256-byte aligned carving)
+    // 2. keys/values, generated in (view, Gaussian) order, into the half from which the tile pass(es) end in half 1
+    const int passes = f3dg_sort_passes(V, T);
+    int src = (passes & 1) ? 0 : 1;
+    // stream views of a half: depth = first 4 bytes/entry of the key region, grp = the 4 bytes/entry behind all depths
+    const size_t cap = (size_t)hdr_capacity;
+    auto kdepth = [&](int h) { return reinterpret_cast<u32*>(keys[h]); };
+    auto kgrp = [&](int h) { return reinterpret_cast<G*>(reinterpret_cast<u32*>(keys[h]) + cap); };
+    hipLaunchKernelGGL((duplicate_keys_kernel<G>), dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V), dim3(F3DG_BLOCK), 0, s, P, tile_bits,
+                       grid_x, grid_y, reinterpret_cast<const float2*>(ws + L.means2D),
+                       reinterpret_cast<const float*>(ws + L.depths), offsets, radii, hdr, kdepth(src), kgrp(src), vals[src]);
+
+    // 3. level 1: stable LSD radix pass(es) over the TILE bits only, 8 bits per pass (one pass up to 256 tiles)
+    const u32 nb = L.sort_blocks;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL((radix_hist_kernel<G>), dim3(nb), dim3(F3DG_BLOCK), 0, s, kgrp(src), hdr, shift, nb, hist);
+        rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * nb, scan_tmp, L.scan_tmp_elems, 1, nullptr);
+        if (rc != F3DG_OK) return rc;
+        hipLaunchKernelGGL((radix_scatter_kernel<G>), dim3(nb), dim3(F3DG_BLOCK), 0, s, kdepth(src), kgrp(src), vals[src],
+                           kdepth(src ^ 1), kgrp(src ^ 1), vals[src ^ 1], hdr, shift, nb, hist);
+        src ^= 1;
+    }
+    // tile-grouped instances are now in half 1 (src == 1); every (tile, view) group is contiguous, in Gaussian-id order
+
+    // 4. (view, tile) group bounds -> final ranges by a scan over the groups in (view, tile) order
+    F3DG_HIP_CHECK(hipMemsetAsync(gstart, 0, sizeof(u32) * 2 * (size_t)nseg, s));      // gstart[nseg] + gend[nseg], adjacent
+    hipLaunchKernelGGL((group_bounds_kernel<G>), dim3(2048), dim3(F3DG_BLOCK), 0, s, kgrp(1), hdr, tile_bits, T, gstart, gend);
+    hipLaunchKernelGGL(group_counts_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gstart, gend, gcount);
+    rc = f3dg_launch_scan_inclusive(s, gcount, hist /* reuse as gcum */, nseg, scan_tmp, L.scan_tmp_elems, 0, nullptr);
+    if (rc != F3DG_OK) return rc;
+    hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges);
+
+    // 5. level 2: per-(view, tile) stable sort by the depth bits: gather the group from half 1, write it sorted to half 0
+    //    three tiers by segment length (each kernel skips the segments of the others): <= 4032, <= 16320, longer
+    const u32 sort_grid = nseg < 65535u * 16u ? nseg : 65535u * 16u;
+    hipLaunchKernelGGL((tile_sort_lds_kernel<256, 16>), dim3(sort_grid), dim3(256), 0, s, ranges, gstart, nseg, hdr, 0u,
+                       tile_bits, T, kdepth(1), vals[1], keys[0], vals[0]);
+    hipLaunchKernelGGL((tile_sort_lds_kernel<512, 32>), dim3(sort_grid), dim3(512), 0, s, ranges, gstart, nseg, hdr,
+                       (u32)(256 * 16 - 64), tile_bits, T, kdepth(1), vals[1], keys[0], vals[0]);
+    hipLaunchKernelGGL(tile_sort_long_kernel, dim3(nseg < 4096u ? nseg : 4096u), dim3(F3DG_BLOCK), 0, s, ranges, gstart, nseg, hdr,
+                       (u32)(512 * 32 - 64), tile_bits, T, kdepth(1), vals[1], keys[0], vals[0], keys[2], vals[2]);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
 int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
@@ -636,43 +709,14 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
     int rc = f3dg_launch_scan_inclusive(s, tiles, offsets, (unsigned long long)V * P, scan_tmp, L.scan_tmp_elems, 0, hdr);
     if (rc != F3DG_OK) return rc;
 
-    // 2. keys/values, generated in (view, Gaussian) order, into the half from which the tile pass(es) end in half 1
-    const int passes = f3dg_sort_passes(V, T);
-    int src = (passes & 1) ? 0 : 1;
-    hipLaunchKernelGGL(duplicate_keys_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V), dim3(F3DG_BLOCK), 0, s, P, tile_bits,
-                       grid_x, grid_y, reinterpret_cast<const float2*>(ws + L.means2D),
-                       reinterpret_cast<const float*>(ws + L.depths), offsets, radii, hdr, keys[src], vals[src]);
-
-    // 3. level 1: stable LSD radix pass(es) over the TILE bits only, 8 bits per pass (one pass up to 256 tiles)
-    const u32 nb = L.sort_blocks;
-    for (int p = 0; p < passes; p++) {
-        const int shift = 32 + 8 * p;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(F3DG_BLOCK), 0, s, keys[src], hdr, shift, nb, hist);
-        rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * nb, scan_tmp, L.scan_tmp_elems, 1, nullptr);
-        if (rc != F3DG_OK) return rc;
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(F3DG_BLOCK), 0, s, keys[src], vals[src], keys[src ^ 1],
-                           vals[src ^ 1], hdr, shift, nb, hist);
-        src ^= 1;
-    }
-    // tile-grouped instances are now in half 1 (src == 1); every (tile, view) group is contiguous, in Gaussian-id order
-
-    // 4. (view, tile) group bounds -> final ranges by a scan over the groups in (view, tile) order
-    F3DG_HIP_CHECK(hipMemsetAsync(gstart, 0, sizeof(u32) * 2 * (size_t)nseg, s));      // gstart[nseg] + gend[nseg], adjacent
-    hipLaunchKernelGGL(group_bounds_kernel, dim3(2048), dim3(F3DG_BLOCK), 0, s, keys[1], hdr, tile_bits, T, gstart, gend);
-    hipLaunchKernelGGL(group_counts_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gstart, gend, gcount);
-    rc = f3dg_launch_scan_inclusive(s, gcount, hist /* reuse as gcum */, nseg, scan_tmp, L.scan_tmp_elems, 0, nullptr);
+    // 2.-5. with the group stream type that fits (view << tile_bits | tile)
+    const bool small = !g_f3dg_sort_wide_groups &&
+                       (((unsigned long long)(V > 0 ? V - 1 : 0) << tile_bits) | ((1ull << tile_bits) - 1ull)) <= 0xFFFFull;
+    rc = small ? binning_tail<unsigned short>(s, V, P, grid_x, grid_y, T, tile_bits, L, ws, radii, hdr, offsets, scan_tmp, keys, vals,
+                                              hist, ranges, gstart, gend, gcount, nseg)
+               : binning_tail<u32>(s, V, P, grid_x, grid_y, T, tile_bits, L, ws, radii, hdr, offsets, scan_tmp, keys, vals, hist,
+                                   ranges, gstart, gend, gcount, nseg);
     if (rc != F3DG_OK) return rc;
-    hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges);
-
-    // 5. level 2: per-(view, tile) stable sort by the depth bits: gather the group from half 1, write it sorted to half 0
-    //    three tiers by segment length (each kernel skips the segments of the others): <= 4032, <= 16320, longer
-    const u32 sort_grid = nseg < 65535u * 16u ? nseg : 65535u * 16u;
-    hipLaunchKernelGGL((tile_sort_lds_kernel<256, 16>), dim3(sort_grid), dim3(256), 0, s, ranges, gstart, nseg, hdr, 0u,
-                       keys[1], vals[1], keys[0], vals[0]);
-    hipLaunchKernelGGL((tile_sort_lds_kernel<512, 32>), dim3(sort_grid), dim3(512), 0, s, ranges, gstart, nseg, hdr,
-                       (u32)(256 * 16 - 64), keys[1], vals[1], keys[0], vals[0]);
-    hipLaunchKernelGGL(tile_sort_long_kernel, dim3(nseg < 4096u ? nseg : 4096u), dim3(F3DG_BLOCK), 0, s, ranges, gstart, nseg, hdr,
-                       (u32)(512 * 32 - 64), keys[1], vals[1], keys[0], vals[0], keys[2], vals[2]);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

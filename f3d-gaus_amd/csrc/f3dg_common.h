@@ -101,6 +101,7 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
 
 extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test enabled; 0: plain path (A/B, tests)
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
+extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,

@@ -189,7 +189,8 @@ int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* r
  * results are bit-identical with it on or off (asserted by the tests). "render_cull" (default 1): every 16x4 pixel strip
  * of a tile walks only the staged Gaussians whose conservative alpha >= 1/255 box touches it; also bit-identical.
  * "render_queue" (default 1): two-phase compositing loop (cheap test for 64 entries, then per-pixel queues of the passing
- * ones); also bit-identical. Returns F3DG_ERR_BAD_ARG for unknown names. */
+ * ones); also bit-identical. "sort_wide_groups" (default 0): forces the 32-bit (view, tile) stream of the binning stage, which
+ * is otherwise only used when views << tile_bits exceeds 16 bits (tests). Returns F3DG_ERR_BAD_ARG for unknown names. */
 int f3dg_set_option(const char* name, int value);
 
 /* Optional per-stage timing of the forward path with HIP events recorded on the caller's stream (this is what

@@ -90,6 +90,27 @@ def test_forward_batched_views_equal_single_views(gpu_device):
     assert total == h["num_rendered"]
 
 
+def test_wide_group_stream_is_identical(gpu_device):
+    """The binning stage carries (view << tile_bits | tile) as u16 when it fits, else u32: both must give the same lists
+    (the u32 path is otherwise only reached with more than 65,536 (view, tile) groups)."""
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    res = []
+    try:
+        for wide in (0, 1):
+            L.f3dg_set_option(b"sort_wide_groups", wide)
+            for name in ("F5_odd_size", "F9_long_tile_lists", "F10_huge_tile_lists"):
+                res.append((wide, name, run_hip(make_scene(**SCENES[name]), gpu_device)))
+            res.append((wide, "multi", run_hip(make_scene(P=8000, res=(128, 128), s0=0.03, view=[0, 1, 3, 5, 6, 2, 4, 7, 8]), gpu_device)))
+    finally:
+        L.f3dg_set_option(b"sort_wide_groups", 0)
+    half = len(res) // 2
+    for (w0, n0, a), (w1, n1, b) in zip(res[:half], res[half:]):
+        assert n0 == n1 and w0 != w1
+        for k in ("point_list", "keys_sorted", "ranges", "out_color"):
+            assert np.array_equal(a[k], b[k]), (n0, k)
+
+
 def test_empty_and_all_culled(gpu_device):
     import f3dgaus_amd as f3d
     scene = make_scene(P=100, res=(64, 64))
