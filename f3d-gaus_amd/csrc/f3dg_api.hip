@@ -202,7 +202,7 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_PREPROCESS, s);
-    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, radii_used);
+    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, radii_used, save_aux);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_BINNING, s);
     return F3DG_OK;

@@ -7,7 +7,8 @@
 //   cub::DeviceRadixSort::SortPairs    :358-363  -> radix_hist_kernel + scan + radix_scatter_kernel (8 bits/pass)
 //   cudaMemset(ranges) + identifyTileRanges :365, :149-171 -> group_bounds / group_counts / scan / group_ranges kernels
 //
-// Keys are ((view << tile_bits) | tile) << 32 | float_bits(depth). Instances are GENERATED in (view, Gaussian) order,
+// Sort keys are ((view << tile_bits) | tile) << 32 | float_bits(depth), carried as separate streams until the final
+// buffer (see duplicate_keys_kernel). Instances are GENERATED in (view, Gaussian) order,
 // so only the tile bits need a global sort: after the stable tile-digit pass(es) every (tile, view) group is contiguous
 // and internally in ascending Gaussian-id order; group bounds + a scan over the V*T groups in (view, tile) order give
 // each group its final place, and the per-group depth sort (tile_sort_kernel) reads the group where the tile pass left
@@ -159,20 +160,31 @@ __global__ void __launch_bounds__(F3DG_BLOCK)
 radix_hist_kernel(const G* __restrict__ kgrp, const F3dgHeader* __restrict__ hdr, int shift, u32 nblocks,
                   u32* __restrict__ hist /* [256][nblocks] */)
 {
-    __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
+    // per-wave counters (4x fewer same-address LDS conflicts), 8 consecutive entries per 16/32-byte load
+    __shared__ u32 h[F3DG_BLOCK / 64][256];
+#pragma unroll
+    for (int w = 0; w < F3DG_BLOCK / 64; w++) h[w][threadIdx.x] = 0;
     __syncthreads();
     const u32 n = hdr->overflow ? 0u : hdr->num_rendered;
     const u64 base = (u64)blockIdx.x * F3DG_SORT_CHUNK;
+    u32* hw = h[threadIdx.x >> 6];
     if (base < n) {
+        typedef G __attribute__((ext_vector_type(8))) G8;
 #pragma unroll
-        for (int i = 0; i < F3DG_SORT_ITEMS; i++) {
-            const u64 k = base + (u64)i * F3DG_BLOCK + threadIdx.x;
-            if (k < n) atomicAdd(&h[((u32)kgrp[k] >> shift) & 255u], 1u);
+        for (int i = 0; i < F3DG_SORT_ITEMS / 8; i++) {
+            const u64 k = base + ((u64)i * F3DG_BLOCK + threadIdx.x) * 8u;
+            if (k + 8 <= n) {
+                const G8 w = *reinterpret_cast<const G8*>(kgrp + k);
+#pragma unroll
+                for (int q = 0; q < 8; q++) atomicAdd(&hw[((u32)w[q] >> shift) & 255u], 1u);
+            } else {
+                for (int q = 0; q < 8; q++)
+                    if (k + q < n) atomicAdd(&hw[((u32)kgrp[k + q] >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
     }
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
 }
 
 template <typename G>
@@ -316,13 +328,34 @@ __global__ void __launch_bounds__(F3DG_BLOCK)
 group_bounds_kernel(const G* __restrict__ kgrp, const F3dgHeader* __restrict__ hdr, int tile_bits, int T,
                     u32* __restrict__ gstart, u32* __restrict__ gend)
 {
+    // every thread looks at 8 consecutive entries (one or two 16-byte loads) plus the entry on either side
     const u32 L = hdr->overflow ? 0u : hdr->num_rendered;
     const u32 tmask = (1u << tile_bits) - 1u;
-    for (u64 idx = (u64)blockIdx.x * F3DG_BLOCK + threadIdx.x; idx < L; idx += (u64)gridDim.x * F3DG_BLOCK) {
-        const u32 cur = (u32)kgrp[idx];
-        const u32 seg = (cur >> tile_bits) * (u32)T + (cur & tmask);
-        if (idx == 0 || (u32)kgrp[idx - 1] != cur) gstart[seg] = (u32)idx;
-        if (idx == L - 1 || (u32)kgrp[idx + 1] != cur) gend[seg] = (u32)idx + 1u;
+    for (u64 base = ((u64)blockIdx.x * F3DG_BLOCK + threadIdx.x) * 8u; base < L; base += (u64)gridDim.x * F3DG_BLOCK * 8u) {
+        G v[8];
+        if (base + 8 <= L) {
+            typedef G __attribute__((ext_vector_type(8))) G8;
+            const G8 w = *reinterpret_cast<const G8*>(kgrp + base);          // base is a multiple of 8: aligned
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = w[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = base + i < L ? kgrp[base + i] : (G)0;
+        }
+        u32 prev = base > 0 ? (u32)kgrp[base - 1] : 0u;
+        const u32 next = base + 8 < L ? (u32)kgrp[base + 8] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u64 idx = base + i;
+            if (idx < L) {
+                const u32 cur = (u32)v[i];
+                const u32 nxt = i < 7 ? (u32)v[i + 1] : next;
+                const u32 seg = (cur >> tile_bits) * (u32)T + (cur & tmask);
+                if (idx == 0 || prev != cur) gstart[seg] = (u32)idx;
+                if (idx == L - 1 || nxt != cur) gend[seg] = (u32)idx + 1u;
+                prev = cur;
+            }
+        }
     }
 }
 
@@ -352,7 +385,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1)
 tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
                      const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */, int tile_bits, int T,
                      const u32* __restrict__ kdepth_src, const u32* __restrict__ vals_src,   // tile-grouped streams
-                     u64* __restrict__ keys_dst, u32* __restrict__ vals_dst)                 // final buffer (half 0)
+                     u64* __restrict__ keys_dst /* may be null: the sorted keys are only kept for inspection */,
+                     u32* __restrict__ vals_dst)                                             // final buffer (half 0)
 {
     constexpr int WAVES = THREADS / 64;
     constexpr u32 CAP = (u32)THREADS * ITEMS - 64u;
@@ -475,7 +509,7 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
             const u32 i = wave_base + (u32)r * 64 + lane;
             if (i < n) {
                 vals_dst[range.x + i] = vals_src[src0 + (di[r] & 0xFFFFu)];
-                keys_dst[range.x + i] = hi | dk[r];
+                if (keys_dst) keys_dst[range.x + i] = hi | dk[r];
             }
         }
     }
@@ -638,7 +672,7 @@ int f3dg_sort_passes(int V, int T)
 template <typename G>
 static int binning_tail(hipStream_t s, int V, int P, int grid_x, int grid_y, int T, int tile_bits, const F3dgLayout& L, char* ws,
                         const int* radii, F3dgHeader* hdr, u32* offsets, u32* scan_tmp, u64** keys, u32** vals, u32* hist,
-                        uint2* ranges, u32* gstart, u32* gend, u32* gcount, u32 nseg)
+                        uint2* ranges, u32* gstart, u32* gend, u32* gcount, u32 nseg, int keep_keys)
 {
     int rc = F3DG_OK;
     const size_t hdr_capacity = (L.keys[1] - L.keys[0]) / 8;      // >= the instance capacity (256-byte aligned carving)
@@ -678,16 +712,18 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int grid_y, int
     //    three tiers by segment length (each kernel skips the segments of the others): <= 4032, <= 16320, longer
     const u32 sort_grid = nseg < 65535u * 16u ? nseg : 65535u * 16u;
     hipLaunchKernelGGL((tile_sort_lds_kernel<256, 16>), dim3(sort_grid), dim3(256), 0, s, ranges, gstart, nseg, hdr, 0u,
-                       tile_bits, T, kdepth(1), vals[1], keys[0], vals[0]);
-    hipLaunchKernelGGL((tile_sort_lds_kernel<512, 32>), dim3(sort_grid), dim3(512), 0, s, ranges, gstart, nseg, hdr,
-                       (u32)(256 * 16 - 64), tile_bits, T, kdepth(1), vals[1], keys[0], vals[0]);
-    hipLaunchKernelGGL(tile_sort_long_kernel, dim3(nseg < 4096u ? nseg : 4096u), dim3(F3DG_BLOCK), 0, s, ranges, gstart, nseg, hdr,
+                       tile_bits, T, kdepth(1), vals[1], keep_keys ? keys[0] : nullptr, vals[0]);
+    const u32 mid_grid = nseg < 2048u ? nseg : 2048u;       // these two stride over all segments and skip most of them
+    hipLaunchKernelGGL((tile_sort_lds_kernel<512, 32>), dim3(mid_grid), dim3(512), 0, s, ranges, gstart, nseg, hdr,
+                       (u32)(256 * 16 - 64), tile_bits, T, kdepth(1), vals[1], keep_keys ? keys[0] : nullptr, vals[0]);
+    hipLaunchKernelGGL(tile_sort_long_kernel, dim3(mid_grid), dim3(F3DG_BLOCK), 0, s, ranges, gstart, nseg, hdr,
                        (u32)(512 * 32 - 64), tile_bits, T, kdepth(1), vals[1], keys[0], vals[0], keys[2], vals[2]);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
 
-int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii)
+int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii,
+                        int keep_keys)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = grid_x * grid_y;
@@ -713,9 +749,9 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
     const bool small = !g_f3dg_sort_wide_groups &&
                        (((unsigned long long)(V > 0 ? V - 1 : 0) << tile_bits) | ((1ull << tile_bits) - 1ull)) <= 0xFFFFull;
     rc = small ? binning_tail<unsigned short>(s, V, P, grid_x, grid_y, T, tile_bits, L, ws, radii, hdr, offsets, scan_tmp, keys, vals,
-                                              hist, ranges, gstart, gend, gcount, nseg)
+                                              hist, ranges, gstart, gend, gcount, nseg, keep_keys)
                : binning_tail<u32>(s, V, P, grid_x, grid_y, T, tile_bits, L, ws, radii, hdr, offsets, scan_tmp, keys, vals, hist,
-                                   ranges, gstart, gend, gcount, nseg);
+                                   ranges, gstart, gend, gcount, nseg, keep_keys);
     if (rc != F3DG_OK) return rc;
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

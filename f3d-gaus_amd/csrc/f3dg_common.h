@@ -97,7 +97,9 @@ int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out,
                                unsigned* tmp, unsigned tmp_elems, int exclusive,
                                F3dgHeader* hdr_total /* if not null: write total + overflow */);
 
-int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii);
+// keep_keys: also write the final u64 sort keys (only the debug export reads them; the inference path skips 8 B/instance)
+int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii,
+                        int keep_keys);
 
 extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test enabled; 0: plain path (A/B, tests)
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box

@@ -205,7 +205,7 @@ int f3dg_profile_collect(double* h_stage_ms, int* h_calls);
  * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the
  * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
  *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], depth), means2D [V*P*2], conic [V*P*4] (SAVE_AUX),
- *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped; SAVE_AUX), keys_sorted [cap] u64,
+ *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped; SAVE_AUX), keys_sorted [cap] u64 (SAVE_AUX),
  *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX). */
 int f3dg_debug_export(void* stream, const void* workspace, int P, int W, int H, int n_views,
                       long long max_rendered, float* rec, float* means2D, float* conic, unsigned* tiles,
