@@ -1,9 +1,32 @@
 """CPU model of the compositing kernel at wave granularity (C2 recipe, 48 random tiles of one view): trips of phase 1 (longest\nof the four 16-lane group lists) and phase 2 (largest per-lane pass count per 64-entry window) per tile-list entry, and\nthe lane utilisation of both. Needs the oracle (test infrastructure); not used by the product path."""
 import sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from helpers import make_scene, run_oracle
-exec(open('/tmp/bbox_exp.py').read().split("def analyze")[0])
+
+
+def bbox_px(v2g, thr, W, H, fx, fy):
+    v = v2g.astype(np.float64); C = v[:,9]
+    k = -2.0*thr.astype(np.float64) + 4e-6*np.abs(C) + 1e-3
+    cK = C - k
+    B0,B1,B2 = v[:,6],v[:,7],v[:,8]
+    m00 = cK*v[:,0]-B0*B0; m01 = cK*v[:,1]-B0*B1; m02 = cK*v[:,2]-B0*B2
+    m11 = cK*v[:,3]-B1*B1; m12 = cK*v[:,4]-B1*B2; m22 = cK*v[:,5]-B2*B2
+    D00 = m11*m22-m12*m12; D11 = m00*m22-m02*m02; D22 = m00*m11-m01*m01
+    D02 = m01*m12-m02*m11; D12 = m01*m02-m00*m12
+    with np.errstate(all="ignore"):
+        cx = D02/D22; cy = D12/D22
+        hx = np.sqrt(D02*D02-D00*D22)/np.abs(D22); hy = np.sqrt(D12*D12-D11*D22)/np.abs(D22)
+    ok = (cK > 0) & (m00 > 0) & (D22 > 1e-12*np.abs(m00*m11)) & np.isfinite(cx) & np.isfinite(cy) & np.isfinite(hx) & np.isfinite(hy)
+    hx = hx*1.02 + 0.75/fx; hy = hy*1.02 + 0.75/fy
+    x0 = (cx-hx)*fx + W/2 - 0.5; x1 = (cx+hx)*fx + W/2 - 0.5; y0 = (cy-hy)*fy + H/2-0.5; y1 = (cy+hy)*fy+H/2-0.5
+    big = 1e30
+    x0 = np.where(ok, x0, -big); x1 = np.where(ok, x1, big); y0 = np.where(ok, y0, -big); y1 = np.where(ok, y1, big)
+    return np.stack([x0,x1,y0,y1],1), ok
+
+
 sc = make_scene(P=196608, res=(256,256), s0=0.01, view="oblique"); o = run_oracle(sc)
 W=H=256; f32=np.float32
 fx = float(f32(W)/(f32(2.0)*f32(sc["tanfovx"])))
