@@ -1,4 +1,6 @@
-"""CPU model of the compositing kernel at wave granularity (C2 recipe, 48 random tiles of one view): trips of phase 1 (longest\nof the four 16-lane group lists) and phase 2 (largest per-lane pass count per 64-entry window) per tile-list entry, and\nthe lane utilisation of both. Needs the oracle (test infrastructure); not used by the product path."""
+"""CPU model of the compositing kernel at wave granularity (C2 recipe, 48 random tiles of one view): trips of phase 1 (longest
+of the four 16-lane group lists) and phase 2 (largest per-lane pass count per 64-entry window) per tile-list entry, and
+the lane utilisation of both. Needs the oracle (test infrastructure); not used by the product path."""
 import sys
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
