@@ -1,4 +1,4 @@
-"""Committed rasterizer fixtures (tests/golden/raster_*.npz, written by tools/gen_raster_golden.py from the CPU oracle):
+"""Committed rasterizer fixtures (tests/golden/raster_*.npz, written by tests/tools/gen_raster_golden.py from the CPU oracle):
   * CPU: the oracle on this host reproduces them (guards against host libm / compiler differences);
   * GPU: the HIP path reproduces them (forward bit-exact intermediates, 1e-4 renders, 1e-5 compositing gradients)."""
 import glob

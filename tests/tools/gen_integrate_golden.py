@@ -1,5 +1,5 @@
 """Writes a small fixture of the integrate path (inputs + the CPU oracle's outputs) to tests/golden/integrate_*.npz.
-Like tools/gen_raster_golden.py it freezes the ORACLE's results of this container (the reference's integrate is CUDA-only
+Like tests/tools/gen_raster_golden.py it freezes the ORACLE's results of this container (the reference's integrate is CUDA-only
 and cannot run here); the oracle's integrate is cross-checked against an independent float64 numpy evaluation in
 tests/test_oracle_integrate.py."""
 import os
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import make_scene  # noqa: E402

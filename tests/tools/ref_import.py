@@ -3,7 +3,7 @@
 The reference hard-codes device="cuda" and imports packages that are not installed here (omegaconf, prettytable,
 torchvision, the CUDA rasterizer extension); this harness injects empty stand-in MODULE OBJECTS for those names
 into sys.modules (no reference code is copied or re-implemented) and rewrites device='cuda' -> 'cpu' through a
-TorchFunctionMode. Used ONLY by tools/gen_golden.py to produce the committed fixtures under tests/golden/.
+TorchFunctionMode. Used ONLY by tests/tools/gen_golden.py to produce the committed fixtures under tests/golden/.
 """
 import sys
 import types

@@ -3,7 +3,7 @@ of the four 16-lane group lists) and phase 2 (largest per-lane pass count per 64
 the lane utilisation of both. Needs the oracle (test infrastructure); not used by the product path."""
 import sys
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from helpers import make_scene, run_oracle

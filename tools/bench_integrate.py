@@ -10,7 +10,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import f3dgaus_amd as f3d  # noqa: E402
 from f3dgaus_amd import cameras, synthetic  # noqa: E402
 from f3dgaus_amd.diff_gof_rasterization import GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF  # noqa: E402

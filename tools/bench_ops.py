@@ -34,7 +34,6 @@ depth = torch.rand(B, 1, res, res, device=dev) * 2 + 6.667
 ob = rig.orbit(8)
 v2w = ob.view_to_world_transforms[:, 0][torch.arange(B) % 8].to(dev)
 quat = ob.source_cv2wT_quat[:, 0][torch.arange(B) % 8].to(dev)
-rd = torch.from_numpy(__import__("oracle.splat_head", fromlist=["x"]).init_ray_dirs(res, 13.164)).to(dev) if False else None
 pred = f3d.GaussianSplatPredictor_gtunet(cfg).to(dev).eval()
 out = f3d.gaussian_predictor.allocate_gaussians(B, HW, dev)
 t = timeit(lambda: f3d.splat_head(net, depth, pred.ray_dirs, v2w, quat, out=out, n_offset=0))
