@@ -32,7 +32,7 @@ SIGNATURES = {
                            _f, _f, _f, _i, _p, _p, _u, C.POINTER(_ll)]),
     "f3dg_backward": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,
                            _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _u]),
-    "f3dg_integrate_workspace_bytes": (_sz, [_i, _i, _i, _ll]),
+    "f3dg_integrate_workspace_bytes": (_sz, [_i, _i, _i, _i, _ll]),
     # stream, ws, ws_bytes, cap | PN P D M | bg W H | points3D means3D shs colors opac scales | mod | rot cov3D v2g view
     # proj campos | tanx tany ks | subpix | prefiltered | out_color radii alpha_i color_i | h_needed
     "f3dg_integrate": (_ll, [_p, _p, _sz, _ll, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p,

@@ -267,10 +267,10 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
     return rc;
 }
 
-extern "C" size_t f3dg_integrate_workspace_bytes(int P, int W, int H, long long max_rendered)
+extern "C" size_t f3dg_integrate_workspace_bytes(int P, int PN, int W, int H, long long max_rendered)
 {
-    if (P < 0 || W <= 0 || H <= 0 || max_rendered < 0) return 0;
-    return f3dg_integ_layout(P, W, H, max_rendered).total;
+    if (P < 0 || PN < 0 || W <= 0 || H <= 0 || max_rendered < 0) return 0;
+    return f3dg_integ_layout(P, PN, W, H, max_rendered).total;
 }
 
 extern "C" long long f3dg_integrate(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
@@ -291,7 +291,7 @@ extern "C" long long f3dg_integrate(void* stream, void* workspace, size_t worksp
     if (PN > 0 && (!points3D || !out_alpha_integrated || !out_color_integrated)) return F3DG_ERR_BAD_ARG;
     if (max_rendered > 0xFFFFFFF0ll) return F3DG_ERR_BAD_ARG;
     const F3dgLayout L = f3dg_layout(P, W, H, 1, max_rendered);
-    const F3dgIntegLayout I = f3dg_integ_layout(P, W, H, max_rendered);
+    const F3dgIntegLayout I = f3dg_integ_layout(P, PN, W, H, max_rendered);
     if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
     char* ws = static_cast<char*>(workspace);
     F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);

@@ -71,9 +71,13 @@ struct F3dgIntegLayout {
     size_t clear_bytes;
     size_t contrib_n;      // [H*W] u32: entries of the pixel's contributor list
     size_t contrib_ids;    // [H*W][1024] u16: 1-based list positions of the contributing Gaussians (forward.cu:862, 969)
+    size_t pix_start;      // [H*W] u32: exclusive scan of pix_points
+    size_t scan_tmp;       // block sums of that scan
+    size_t pt_pix, pt_rank, perm;   // [PN] u32 each: pixel of a point (~0: not integrated), its rank in the pixel, pixel order
     size_t total;
+    unsigned scan_tmp_elems;
 };
-F3dgIntegLayout f3dg_integ_layout(int P, int W, int H, long long cap);
+F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap);
 
 int f3dg_set_hip_error(hipError_t e, const char* where);
 #define F3DG_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return f3dg_set_hip_error(_e, #expr); } while (0)

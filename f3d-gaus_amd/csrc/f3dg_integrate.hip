@@ -12,8 +12,8 @@
 //           Gaussians -- written to a global [pixel][1024] u16 table instead of a private array. The culled per-16-lane
 //           entry lists and the conservative K pre-test of the compositing kernel are reused (boxes widened by the half
 //           pixel of the corner rays); both only remove (ray, Gaussian) pairs the reference `continue`s on.
-//   points  (one LANE PER POINT, no sort)  preprocessPointsCUDA fused with the second loop of integrateCUDA: the point
-//           finds its pixel, walks that pixel's contributor list and accumulates its alpha. Loop interchange
+//   points  (one LANE PER POINT, visited in pixel order)  preprocessPointsCUDA fused with the second loop of integrateCUDA:
+//           the point finds its pixel, walks that pixel's contributor list and accumulates its alpha. Loop interchange
 //           (points outside, Gaussians inside) is exact because every point's recurrence is independent. The tile's
 //           depth-sorted point list of the reference is only needed for one thing, see below.
 //   epilogue  the reference stores `total_projected` in the distortion channel. It equals the number of points in the
@@ -265,15 +265,20 @@ __device__ __forceinline__ bool project_point(const float* __restrict__ points3D
     return true;
 }
 
+// Points are integrated in PIXEL order, not in the caller's order: the lanes of a wave then share a pixel (or a few), i.e.
+// the same contributor list, the same records and the same trip count, instead of 64 unrelated lists (1 M randomly
+// ordered points: 2.8 ms of divergent L2 reads). The order inside a pixel is irrelevant (every point's recurrence is
+// independent), so this is a counting sort by pixel with atomic ranks:
+//   bin:  project the point, rank = atomicAdd(points of its pixel), keep (pixel, rank); also the per-tile maximum of
+//         (depth bits, index) the epilogue needs
+//   scan: exclusive scan of the per-pixel counts
+//   perm: perm[start[pixel] + rank] = point index
 __global__ void __launch_bounds__(F3DG_BLOCK)
-integrate_points_kernel(int PN, const float* __restrict__ points3D, const float* __restrict__ viewmatrix, int W, int H,
-                        int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
-                        const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
-                        const F3dgRec* __restrict__ rec, const unsigned short* __restrict__ contrib_ids,
-                        const unsigned* __restrict__ contrib_n, const unsigned* __restrict__ n_contrib,
-                        const float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
-                        float* __restrict__ out_color_integrated, unsigned* __restrict__ pix_points,
-                        unsigned long long* __restrict__ tile_last)
+integrate_points_bin_kernel(int PN, const float* __restrict__ points3D, const float* __restrict__ viewmatrix, int W, int H,
+                            int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
+                            float* __restrict__ out_alpha_integrated, float* __restrict__ out_color_integrated,
+                            unsigned* __restrict__ pix_points, unsigned long long* __restrict__ tile_last,
+                            unsigned* __restrict__ pt_pix, unsigned* __restrict__ pt_rank)
 {
     const unsigned idx = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     if (idx >= (unsigned)PN)
@@ -285,12 +290,49 @@ integrate_points_kernel(int PN, const float* __restrict__ points3D, const float*
         out_color_integrated[3 * (size_t)idx] = 0.0f;
         out_color_integrated[3 * (size_t)idx + 1] = 0.0f;
         out_color_integrated[3 * (size_t)idx + 2] = 0.0f;
+        pt_pix[idx] = 0xFFFFFFFFu;
         return;
     }
     // the pixel whose thread collects this point: x in [pix, pix + 1) (forward.cu:1063-1064, evaluated in double on
     // exactly representable bounds) = truncation; its tile is the createWithKeys tile (rasterizer_impl.cu:135-136)
     const unsigned pix_x = (unsigned)(int)ix, pix_y = (unsigned)(int)iy;
+    const unsigned pix_id = (unsigned)W * pix_y + pix_x;
+    const unsigned tile = (pix_y / F3DG_TILE) * (unsigned)tiles_x + pix_x / F3DG_TILE;
+    pt_pix[idx] = pix_id;
+    pt_rank[idx] = atomicAdd(&pix_points[pix_id], 1u);
+    atomicMax(&tile_last[tile], ((unsigned long long)__float_as_uint(depth) << 32) | idx);
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+integrate_points_perm_kernel(int PN, const unsigned* __restrict__ pt_pix, const unsigned* __restrict__ pt_rank,
+                             const unsigned* __restrict__ pix_start, unsigned* __restrict__ perm)
+{
+    const unsigned idx = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    if (idx >= (unsigned)PN)
+        return;
+    const unsigned pix = pt_pix[idx];
+    if (pix != 0xFFFFFFFFu)
+        perm[pix_start[pix] + pt_rank[idx]] = idx;
+}
+
+__global__ void __launch_bounds__(F3DG_BLOCK)
+integrate_points_kernel(int PN, const float* __restrict__ points3D, const float* __restrict__ viewmatrix, int W, int H,
+                        int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
+                        const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
+                        const F3dgRec* __restrict__ rec, const unsigned short* __restrict__ contrib_ids,
+                        const unsigned* __restrict__ contrib_n, const unsigned* __restrict__ n_contrib,
+                        const float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
+                        float* __restrict__ out_color_integrated, const unsigned* __restrict__ pix_points,
+                        const unsigned* __restrict__ pix_start, const unsigned* __restrict__ perm)
+{
+    const unsigned i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const size_t HW = (size_t)H * W;
+    if (hdr->overflow || i >= pix_start[HW - 1] + pix_points[HW - 1])       // number of points inside the image
+        return;
+    const unsigned idx = perm[i];
+    float ix, iy, depth;
+    project_point(points3D, idx, viewmatrix, W, H, focal_x, focal_y, ix, iy, depth);     // true, by construction of perm
+    const unsigned pix_x = (unsigned)(int)ix, pix_y = (unsigned)(int)iy;
     const size_t pix_id = (size_t)W * pix_y + pix_x;
     const unsigned tile = (pix_y / F3DG_TILE) * (unsigned)tiles_x + pix_x / F3DG_TILE;
 
@@ -334,9 +376,6 @@ integrate_points_kernel(int PN, const float* __restrict__ points3D, const float*
     out_color_integrated[3 * (size_t)idx] = out_color[0 * HW + pix_id];         // C + T * bg of the pixel (forward.cu:1186)
     out_color_integrated[3 * (size_t)idx + 1] = out_color[1 * HW + pix_id];
     out_color_integrated[3 * (size_t)idx + 2] = out_color[2 * HW + pix_id];
-
-    atomicAdd(&pix_points[pix_id], 1u);
-    atomicMax(&tile_last[tile], ((unsigned long long)__float_as_uint(depth) << 32) | idx);
 }
 
 __global__ void __launch_bounds__(F3DG_BLOCK)
@@ -382,7 +421,7 @@ __global__ void integrate_fill_kernel(size_t HW, size_t PN, float* __restrict__ 
 
 } // namespace
 
-F3dgIntegLayout f3dg_integ_layout(int P, int W, int H, long long cap)
+F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap)
 {
     F3dgIntegLayout I;
     const F3dgLayout L = f3dg_layout(P, W, H, 1, cap);
@@ -395,6 +434,13 @@ F3dgIntegLayout f3dg_integ_layout(int P, int W, int H, long long cap)
     I.clear_bytes = off - I.pix_points;
     I.contrib_n = take(HW * sizeof(unsigned));
     I.contrib_ids = take(HW * F3DG_MAX_CONTRIB * sizeof(unsigned short));
+    const size_t PNn = (size_t)(PN > 0 ? PN : 1);
+    I.pix_start = take(HW * sizeof(unsigned));
+    I.scan_tmp_elems = (unsigned)((HW + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK + 1);
+    I.scan_tmp = take((size_t)I.scan_tmp_elems * sizeof(unsigned));
+    I.pt_pix = take(PNn * sizeof(unsigned));
+    I.pt_rank = take(PNn * sizeof(unsigned));
+    I.perm = take(PNn * sizeof(unsigned));
     I.total = off;
     return I;
 }
@@ -437,9 +483,21 @@ int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float foca
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);
     F3DG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(integrate_points_kernel, dim3((PN + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, PN,
-                       points3D, viewmatrix, W, H, tiles_x, focal_x, focal_y, hdr, ranges, point_list, rec, contrib_ids,
-                       contrib_n, n_contrib, out_color, out_alpha_integrated, out_color_integrated, pix_points, tile_last);
+    // points: counting sort by pixel (bin, scan, perm), then the integration in pixel order
+    unsigned* pix_start = reinterpret_cast<unsigned*>(ws + I.pix_start);
+    unsigned* pt_pix = reinterpret_cast<unsigned*>(ws + I.pt_pix);
+    unsigned* pt_rank = reinterpret_cast<unsigned*>(ws + I.pt_rank);
+    unsigned* perm = reinterpret_cast<unsigned*>(ws + I.perm);
+    const dim3 pgrid((PN + F3DG_BLOCK - 1) / F3DG_BLOCK);
+    hipLaunchKernelGGL(integrate_points_bin_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
+                       focal_x, focal_y, hdr, out_alpha_integrated, out_color_integrated, pix_points, tile_last, pt_pix, pt_rank);
+    int rc = f3dg_launch_scan_inclusive(s, pix_points, pix_start, (unsigned long long)W * H,
+                                        reinterpret_cast<unsigned*>(ws + I.scan_tmp), I.scan_tmp_elems, 1, nullptr);
+    if (rc != F3DG_OK) return rc;
+    hipLaunchKernelGGL(integrate_points_perm_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, pt_pix, pt_rank, pix_start, perm);
+    hipLaunchKernelGGL(integrate_points_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
+                       focal_x, focal_y, hdr, ranges, point_list, rec, contrib_ids, contrib_n, n_contrib, out_color,
+                       out_alpha_integrated, out_color_integrated, pix_points, pix_start, perm);
     F3DG_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(integrate_epilogue_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                        points3D, viewmatrix, pix_points, tile_last, out_color);

@@ -249,11 +249,11 @@ def integrate_gaussians_to_points(points3D, means3D, sh, colors_precomp, opaciti
         color_integrated = torch.empty((PN, 3), dtype=torch.float32, device=device)
 
         cap = _initial_capacity(P, W, H, 1)
-        key = (P, W, H)
+        key = (P, PN, W, H)
         while True:
             cached = _INTEG_WS.get(device.index)
             if cached is None or cached[0] != key or cached[1] < cap:
-                nbytes = L.f3dg_integrate_workspace_bytes(P, W, H, cap)
+                nbytes = L.f3dg_integrate_workspace_bytes(P, PN, W, H, cap)
                 if nbytes == 0:
                     raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_integrate_workspace_bytes")
                 cached = (key, cap, torch.empty(int(nbytes), dtype=torch.uint8, device=device))

@@ -143,7 +143,7 @@ int f3dg_backward(void* stream, void* workspace, size_t workspace_bytes, long lo
  * PN == 0: out_color = 0, alpha = 1, colour = 0, returns 0 (rasterize_points.cu:300).
  * BLOCKING like f3dg_forward; returns num_rendered >= 0 or a negative error; on F3DG_ERR_OVERFLOW *h_needed (if not
  * NULL) receives the required instance capacity. The workspace must hold f3dg_integrate_workspace_bytes(). */
-size_t f3dg_integrate_workspace_bytes(int P, int W, int H, long long max_rendered);
+size_t f3dg_integrate_workspace_bytes(int P, int PN, int W, int H, long long max_rendered);
 long long f3dg_integrate(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
                          int PN, int P, int D, int M, const float* background, int W, int H,
                          const float* points3D, const float* means3D, const float* shs, const float* colors_precomp,
