@@ -18,6 +18,8 @@ torch.manual_seed(0)
 pred = f3d.GaussianSplatPredictor_gtunet(cfg).to(dev).eval()
 x = torch.rand(B, 4, 256, 256, device=dev)
 mode = os.environ.get("MODE", "fp32")
+if os.environ.get("BENCHMARK"):
+    torch.backends.cudnn.benchmark = True
 if mode == "channels_last":
     pred = pred.to(memory_format=torch.channels_last)
     x = x.contiguous(memory_format=torch.channels_last)
