@@ -187,9 +187,10 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
             const float CC = q2.y;
             float t = 0, G = 0, alpha = 0;
             if (active) {
-                t = (float)(-BB / (2 * AA));
+                const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
+                t = (float)(-0.5 * q);
                 if (t <= F3DG_NEAR_PLANE) active = false;
-                const double min_value = -(BB / AA) * (BB / 4.) + CC;
+                const double min_value = -q * (BB / 4.) + CC;
                 float power = (float)(-0.5f * min_value);
                 if (power > 0.0f) power = 0.0f;
                 G = expf(power);
@@ -474,9 +475,10 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             const float CC = q2.y;
             float t = 0, G = 0, alpha = 0;
             if (active) {
-                t = (float)(-BB / (2 * AA));
+                const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
+                t = (float)(-0.5 * q);
                 if (t <= F3DG_NEAR_PLANE) active = false;
-                const double min_value = -(BB / AA) * (BB / 4.) + CC;
+                const double min_value = -q * (BB / 4.) + CC;
                 float power = (float)(-0.5f * min_value);
                 if (power > 0.0f) power = 0.0f;
                 G = expf(power);

@@ -58,10 +58,11 @@ __device__ __forceinline__ bool ray_entry(Pass1State& st, float rx, float ry, co
     }
     const float BB = 2 * bhalf;
     const float CC = q2.y;
-    const float t = -BB / (2 * AA);
+    const float q = BB / AA;                            // one float32 division: -BB / (2 * AA) == -0.5f * (BB / AA) exactly
+    const float t = -0.5f * q;
     if (t <= F3DG_NEAR_PLANE)
         return false;
-    const double min_value = -(BB / AA) * (BB / 4.) + CC;
+    const double min_value = -q * (BB / 4.) + CC;
     float power = (float)(-0.5f * min_value);
     if (power > 0.0f)
         power = 0.0f;

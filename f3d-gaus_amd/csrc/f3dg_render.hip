@@ -59,11 +59,14 @@ __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor
     const float bbf = 2 * bhalf;
     const double BB = bbf;
 
-    const float t = -bbf / (2.0f * aaf);                  // == (float)(-BB / (2 * AA)), see header
+    // ONE float64 division serves both uses: -BB / (2 * AA) is the correctly rounded quotient BB / AA scaled by -1/2
+    // (exact), so t below has the bits of the reference's (float)(-BB / (2 * AA)).
+    const double q = BB / AA;
+    const float t = (float)(-0.5 * q);
     if (t <= F3DG_NEAR_PLANE)
         return false;
 
-    const double min_value = -(BB / AA) * (BB / 4.) + CC;
+    const double min_value = -q * (BB / 4.) + CC;
     float power = (float)(-0.5f * min_value);
     if (power > 0.0f)
         power = 0.0f;
