@@ -296,7 +296,7 @@ radix_scatter_kernel(const u32* __restrict__ kdepth_in, const G* __restrict__ kg
 // Level 2 of the two-level sort. After the global pass(es) have grouped the instances by (view, tile) -- stably, so each
 // segment is in ascending Gaussian-id order -- one workgroup per segment sorts it by its depth bits, in three tiers:
 //   * n <= 4032  (C2: ~2.5 k entries per tile)   tile_sort_lds_kernel<256, 16>, 32 KB of LDS, 4 workgroups per CU
-//   * n <= 16320 (C5: 8-9 k entries per tile)     tile_sort_lds_kernel<512, 32>, 112 KB of LDS, one 8-wave workgroup per CU
+//   * n <= 16320 (C5: 8-9 k entries per tile)     tile_sort_lds_kernel<1024, 16>, 128 KB of LDS, one 16-wave workgroup per CU
 //   * longer                                        tile_sort_long_kernel: 8-bit LSD passes through a global scratch slice
 // The LDS tiers first OR (key ^ first key) over the segment: only the depth bits that actually vary inside the tile are
 // sorted, in ceil(bits/9) passes of <= 9 bits (three passes for the 24 varying bits of depths in [6.7, 8.7], not four);
@@ -379,9 +379,14 @@ group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restr
 // a pass (scatter to the ranked slot, barrier, read the own rows back). The payload is the position inside the segment
 // (u16; the Gaussian ids are gathered once, at the end). Two instantiations:
 //   <256, 16>: n <= 4032, 32 KB of LDS -> 4 workgroups per CU (the C2 regime: ~2.5 k entries per tile)
-//   <512, 32>: n <= 16320, 112 KB of LDS -> 1 workgroup of 8 waves per CU (the C5 regime: 8-9 k entries per tile)
+//   <1024, 16>: n <= 16320, 128 KB of LDS -> 1 workgroup of 16 waves per CU (the C5 regime: 8-9 k entries per tile;
+//               measured 1.7 -> 0.9 ms against <512, 32>, which kept only 8 waves per CU)
+#ifndef F3DG_MID_THREADS
+#define F3DG_MID_THREADS 1024
+#define F3DG_MID_ITEMS 16
+#endif
 template <int THREADS, int ITEMS>
-__global__ void __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1)
+__global__ void __launch_bounds__(THREADS, THREADS == 256 ? 4 : (THREADS == 512 ? 2 : 4))
 tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
                      const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */, int tile_bits, int T,
                      const u32* __restrict__ kdepth_src, const u32* __restrict__ vals_src,   // tile-grouped streams
@@ -390,7 +395,8 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
 {
     constexpr int WAVES = THREADS / 64;
     constexpr u32 CAP = (u32)THREADS * ITEMS - 64u;
-    constexpr int DPT = 512 / THREADS;                  // digits of the 512-entry counter table owned by one thread
+    constexpr int DPT = THREADS >= 512 ? 1 : 512 / THREADS;   // digits of the 512-entry counter table owned by one thread
+    const bool owner = (u32)threadIdx.x * DPT < 512u;          // with 1024 threads only the first 512 own a digit
     __shared__ u32 cnt[WAVES][512];                     // per-wave digit counters (up to 9-bit digits)
     __shared__ u32 wtot[WAVES];
     __shared__ u32 sdepth[CAP];
@@ -439,10 +445,12 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
         for (int pass = 0; pass < npass; pass++) {
             const int shift = dbits * pass;
             __syncthreads();
+            if (owner) {
 #pragma unroll
-            for (int w = 0; w < WAVES; w++)
+                for (int w = 0; w < WAVES; w++)
 #pragma unroll
-                for (int q = 0; q < DPT; q++) cnt[w][threadIdx.x + q * THREADS] = 0;
+                    for (int q = 0; q < DPT; q++) cnt[w][DPT * threadIdx.x + q] = 0;
+            }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < ITEMS; r++) {
@@ -459,8 +467,10 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
 #pragma unroll
                 for (int q = 0; q < DPT; q++) {
                     tot[q] = 0;
+                    if (owner) {
 #pragma unroll
-                    for (int w = 0; w < WAVES; w++) tot[q] += cnt[w][DPT * threadIdx.x + q];
+                        for (int w = 0; w < WAVES; w++) tot[q] += cnt[w][DPT * threadIdx.x + q];
+                    }
                     x += tot[q];
                 }
                 const u32 mine = x;
@@ -477,11 +487,13 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
 #pragma unroll
                 for (int q = 0; q < DPT; q++) {
                     u32 run = e;
+                    if (owner) {
 #pragma unroll
-                    for (int w = 0; w < WAVES; w++) {
-                        const u32 c = cnt[w][DPT * threadIdx.x + q];
-                        cnt[w][DPT * threadIdx.x + q] = run;
-                        run += c;
+                        for (int w = 0; w < WAVES; w++) {
+                            const u32 c = cnt[w][DPT * threadIdx.x + q];
+                            cnt[w][DPT * threadIdx.x + q] = run;
+                            run += c;
+                        }
                     }
                     e += tot[q];
                 }
@@ -714,7 +726,7 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int grid_y, int
     hipLaunchKernelGGL((tile_sort_lds_kernel<256, 16>), dim3(sort_grid), dim3(256), 0, s, ranges, gstart, nseg, hdr, 0u,
                        tile_bits, T, kdepth(1), vals[1], keep_keys ? keys[0] : nullptr, vals[0]);
     const u32 mid_grid = nseg < 2048u ? nseg : 2048u;       // these two stride over all segments and skip most of them
-    hipLaunchKernelGGL((tile_sort_lds_kernel<512, 32>), dim3(mid_grid), dim3(512), 0, s, ranges, gstart, nseg, hdr,
+    hipLaunchKernelGGL((tile_sort_lds_kernel<F3DG_MID_THREADS, F3DG_MID_ITEMS>), dim3(mid_grid), dim3(F3DG_MID_THREADS), 0, s, ranges, gstart, nseg, hdr,
                        (u32)(256 * 16 - 64), tile_bits, T, kdepth(1), vals[1], keep_keys ? keys[0] : nullptr, vals[0]);
     hipLaunchKernelGGL(tile_sort_long_kernel, dim3(mid_grid), dim3(F3DG_BLOCK), 0, s, ranges, gstart, nseg, hdr,
                        (u32)(512 * 32 - 64), tile_bits, T, kdepth(1), vals[1], keys[0], vals[0], keys[2], vals[2]);
