@@ -295,7 +295,7 @@ radix_scatter_kernel(const u32* __restrict__ kdepth_in, const G* __restrict__ kg
 // ------------------------------------------------------------------------------------------------ per-tile depth sort
 // Level 2 of the two-level sort. After the global pass(es) have grouped the instances by (view, tile) -- stably, so each
 // segment is in ascending Gaussian-id order -- one workgroup per segment sorts it by its depth bits, in three tiers:
-//   * n <= 4032  (C2: ~2.5 k entries per tile)   tile_sort_lds_kernel<256, 16>, 32 KB of LDS, 4 workgroups per CU
+//   * n <= 4032  (C2: ~2.5 k entries per tile)   tile_sort_lds_kernel<512, 8>, 32 KB of LDS, 4 workgroups = 32 waves per CU
 //   * n <= 16320 (C5: 8-9 k entries per tile)     tile_sort_lds_kernel<1024, 16>, 128 KB of LDS, one 16-wave workgroup per CU
 //   * longer                                        tile_sort_long_kernel: 8-bit LSD passes through a global scratch slice
 // The LDS tiers first OR (key ^ first key) over the segment: only the depth bits that actually vary inside the tile are
@@ -303,7 +303,8 @@ radix_scatter_kernel(const u32* __restrict__ kdepth_in, const G* __restrict__ kg
 // 12 B read + 12 B written per instance of global traffic.
 
 // stable in-wave ranking of one digit per lane; returns the lane's rank among equal digits seen so far by this wave
-__device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 lane_lt, int digit_bits = 8)
+template <typename CT>
+__device__ __forceinline__ u32 wave_rank(u32 d, bool valid, CT* wave_cnt, u64 lane_lt, int digit_bits = 8)
 {
     u64 same = __ballot(valid);
 #pragma unroll
@@ -317,7 +318,7 @@ __device__ __forceinline__ u32 wave_rank(u32 d, bool valid, u32* wave_cnt, u64 l
     const u32 below = (u32)__popcll(same & lane_lt);
     const u32 prev = wave_cnt[d];
     __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) wave_cnt[d] = prev + (u32)__popcll(same);
+    if (valid && below == 0) wave_cnt[d] = (CT)(prev + (u32)__popcll(same));
     __builtin_amdgcn_wave_barrier();
     return prev + below;
 }
@@ -378,15 +379,19 @@ group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restr
 // between the passes (ITEMS per thread, in (wave, row, lane) = segment order); one LDS buffer is only the exchange medium of
 // a pass (scatter to the ranked slot, barrier, read the own rows back). The payload is the position inside the segment
 // (u16; the Gaussian ids are gathered once, at the end). Two instantiations:
-//   <256, 16>: n <= 4032, 32 KB of LDS -> 4 workgroups per CU (the C2 regime: ~2.5 k entries per tile)
+//   <512, 8>: n <= 4032, 32 KB of LDS, 64 VGPRs -> 4 workgroups = 32 waves per CU (the C2 regime: ~2.5 k entries per tile)
 //   <1024, 16>: n <= 16320, 128 KB of LDS -> 1 workgroup of 16 waves per CU (the C5 regime: 8-9 k entries per tile;
 //               measured 1.7 -> 0.9 ms against <512, 32>, which kept only 8 waves per CU)
+#ifndef F3DG_SMALL_THREADS
+#define F3DG_SMALL_THREADS 512
+#define F3DG_SMALL_ITEMS 8
+#endif
 #ifndef F3DG_MID_THREADS
 #define F3DG_MID_THREADS 1024
 #define F3DG_MID_ITEMS 16
 #endif
 template <int THREADS, int ITEMS>
-__global__ void __launch_bounds__(THREADS, THREADS == 256 ? 4 : (THREADS == 512 ? 2 : 4))
+__global__ void __launch_bounds__(THREADS, ITEMS == 8 ? 8 : 4)
 tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ gstart, u32 n_segments,
                      const F3dgHeader* __restrict__ hdr, u32 n_lo /* exclusive */, int tile_bits, int T,
                      const u32* __restrict__ kdepth_src, const u32* __restrict__ vals_src,   // tile-grouped streams
@@ -397,7 +402,7 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
     constexpr u32 CAP = (u32)THREADS * ITEMS - 64u;
     constexpr int DPT = THREADS >= 512 ? 1 : 512 / THREADS;   // digits of the 512-entry counter table owned by one thread
     const bool owner = (u32)threadIdx.x * DPT < 512u;          // with 1024 threads only the first 512 own a digit
-    __shared__ u32 cnt[WAVES][512];                     // per-wave digit counters (up to 9-bit digits)
+    __shared__ unsigned short cnt[WAVES][512];          // per-wave digit counters (up to 9-bit digits); values <= CAP < 65536
     __shared__ u32 wtot[WAVES];
     __shared__ u32 sdepth[CAP];
     __shared__ unsigned short sidx[CAP];
@@ -491,7 +496,7 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
 #pragma unroll
                         for (int w = 0; w < WAVES; w++) {
                             const u32 c = cnt[w][DPT * threadIdx.x + q];
-                            cnt[w][DPT * threadIdx.x + q] = run;
+                            cnt[w][DPT * threadIdx.x + q] = (unsigned short)run;
                             run += c;
                         }
                     }
@@ -723,7 +728,7 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int grid_y, int
     // 5. level 2: per-(view, tile) stable sort by the depth bits: gather the group from half 1, write it sorted to half 0
     //    three tiers by segment length (each kernel skips the segments of the others): <= 4032, <= 16320, longer
     const u32 sort_grid = nseg < 65535u * 16u ? nseg : 65535u * 16u;
-    hipLaunchKernelGGL((tile_sort_lds_kernel<256, 16>), dim3(sort_grid), dim3(256), 0, s, ranges, gstart, nseg, hdr, 0u,
+    hipLaunchKernelGGL((tile_sort_lds_kernel<F3DG_SMALL_THREADS, F3DG_SMALL_ITEMS>), dim3(sort_grid), dim3(F3DG_SMALL_THREADS), 0, s, ranges, gstart, nseg, hdr, 0u,
                        tile_bits, T, kdepth(1), vals[1], keep_keys ? keys[0] : nullptr, vals[0]);
     const u32 mid_grid = nseg < 2048u ? nseg : 2048u;       // these two stride over all segments and skip most of them
     hipLaunchKernelGGL((tile_sort_lds_kernel<F3DG_MID_THREADS, F3DG_MID_ITEMS>), dim3(mid_grid), dim3(F3DG_MID_THREADS), 0, s, ranges, gstart, nseg, hdr,
