@@ -79,6 +79,57 @@ __device__ __forceinline__ double wave_total_lane63_f64(float f)
     return v;
 }
 
+// ---- transposed wave reduction of several values at once -------------------------------------------------------------
+// v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / 16-lane rows between two registers, so ONE add
+// halves the lane span of TWO values: after both, every 16-lane row holds the partial sums of a different value and only
+// ceil(n/4) registers are left for the four row-local DPP steps. 17 values: 34 adds instead of 102.
+//   pair32(X, Y): lanes 0..31 = X[i] + X[i+32], lanes 32..63 = Y[i-32] + Y[i]
+//   pair16(P, Q): row 0 = P.row0 + P.row1, row 1 = Q.row0 + Q.row1, row 2 = P.row2 + P.row3, row 3 = Q.row2 + Q.row3
+typedef unsigned __attribute__((ext_vector_type(2))) f3dg_u2;
+__device__ __forceinline__ float pair32(float x, float y)
+{
+    const f3dg_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float pair16(float x, float y)
+{
+    const f3dg_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ double pair32(double x, double y)
+{
+    const unsigned long long a = (unsigned long long)__double_as_longlong(x), b = (unsigned long long)__double_as_longlong(y);
+    const f3dg_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    const f3dg_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x)) +
+           __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+}
+__device__ __forceinline__ double pair16(double x, double y)
+{
+    const unsigned long long a = (unsigned long long)__double_as_longlong(x), b = (unsigned long long)__double_as_longlong(y);
+    const f3dg_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    const f3dg_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x)) +
+           __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+}
+// total of each 16-lane row in its lane 15
+__device__ __forceinline__ float row_total(float v)
+{
+    v += dpp_f32<F3DG_DPP_ROW_SHR(1), 0xF>(v);
+    v += dpp_f32<F3DG_DPP_ROW_SHR(2), 0xF>(v);
+    v += dpp_f32<F3DG_DPP_ROW_SHR(4), 0xF>(v);
+    v += dpp_f32<F3DG_DPP_ROW_SHR(8), 0xF>(v);
+    return v;
+}
+__device__ __forceinline__ double row_total(double v)
+{
+    v += dpp_f64<F3DG_DPP_ROW_SHR(1), 0xF>(v);
+    v += dpp_f64<F3DG_DPP_ROW_SHR(2), 0xF>(v);
+    v += dpp_f64<F3DG_DPP_ROW_SHR(4), 0xF>(v);
+    v += dpp_f64<F3DG_DPP_ROW_SHR(8), 0xF>(v);
+    return v;
+}
+
 __global__ void __launch_bounds__(F3DG_BLOCK)
 render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
@@ -577,31 +628,27 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 g_v9 = (float)dL_dC;
             }
 
-            // sum the 17 partials over the wave's 64 pixels on the VALU (DPP), lane 63 updates memory
-            g_col0 = wave_total_lane63(g_col0); g_col1 = wave_total_lane63(g_col1); g_col2 = wave_total_lane63(g_col2);
-            g_mx = wave_total_lane63(g_mx); g_my = wave_total_lane63(g_my); g_mz = wave_total_lane63(g_mz);
-            g_op = wave_total_lane63(g_op);
-            const double s_v0 = wave_total_lane63_f64(g_v0), s_v1 = wave_total_lane63_f64(g_v1),
-                         s_v2 = wave_total_lane63_f64(g_v2), s_v3 = wave_total_lane63_f64(g_v3),
-                         s_v4 = wave_total_lane63_f64(g_v4), s_v5 = wave_total_lane63_f64(g_v5),
-                         s_v6 = wave_total_lane63_f64(g_v6), s_v7 = wave_total_lane63_f64(g_v7),
-                         s_v8 = wave_total_lane63_f64(g_v8), s_v9 = wave_total_lane63_f64(g_v9);
-            if (lane == 63) {
+            // sum the 17 partials over the wave's 64 pixels on the VALU: transposed across the rows (see pair32 / pair16), then
+            // row-local DPP scans; lane 15 of row r holds the totals listed in its column
+            //                     row 0          row 1          row 2          row 3
+            const float f0 = row_total(pair16(pair32(g_col0, g_col1), pair32(g_col2, g_mx)));     // col0   col2   col1   mean2D.x
+            const float f1 = row_total(pair16(pair32(g_my, g_mz), pair32(g_op, 0.0f)));           // m2D.y  opacity m2D.z  -
+            const double d0 = row_total(pair16(pair32((double)g_v0, (double)g_v1), pair32((double)g_v2, (double)g_v3)));   // v0 v2 v1 v3
+            const double d1 = row_total(pair16(pair32((double)g_v4, (double)g_v5), pair32((double)g_v6, (double)g_v7)));   // v4 v6 v5 v7
+            const double d2 = row_total(pair16(pair32((double)g_v8, (double)g_v9), 0.0));                                  // v8 -  v9 -
+            if ((lane & 15u) == 15u) {
+                const unsigned row = lane >> 4;
                 const unsigned id = staged_id[j];
                 const size_t gi = vP + id;
-                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 0], g_col0);
-                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 1], g_col1);
-                unsafeAtomicAdd(&dL_dcolors[gi * 3 + 2], g_col2);
-                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 0], g_mx);
-                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 1], g_my);
-                unsafeAtomicAdd(&dL_dmean2D[gi * 3 + 2], g_mz);
-                unsafeAtomicAdd(&dL_dopacity[id], g_op);
-                double* a = dL_dv2g_acc + gi * 10;
-                unsafeAtomicAdd(a + 0, s_v0); unsafeAtomicAdd(a + 1, s_v1);
-                unsafeAtomicAdd(a + 2, s_v2); unsafeAtomicAdd(a + 3, s_v3);
-                unsafeAtomicAdd(a + 4, s_v4); unsafeAtomicAdd(a + 5, s_v5);
-                unsafeAtomicAdd(a + 6, s_v6); unsafeAtomicAdd(a + 7, s_v7);
-                unsafeAtomicAdd(a + 8, s_v8); unsafeAtomicAdd(a + 9, s_v9);
+                float* c = dL_dcolors + gi * 3;
+                float* m = dL_dmean2D + gi * 3;
+                unsafeAtomicAdd(row == 0 ? c : row == 1 ? c + 2 : row == 2 ? c + 1 : m, f0);
+                if (row < 3) unsafeAtomicAdd(row == 0 ? m + 1 : row == 1 ? dL_dopacity + id : m + 2, f1);
+                double* acc = dL_dv2g_acc + gi * 10;
+                const unsigned perm = row == 0 ? 0u : row == 1 ? 2u : row == 2 ? 1u : 3u;
+                unsafeAtomicAdd(acc + perm, d0);
+                unsafeAtomicAdd(acc + 4 + perm, d1);
+                if ((row & 1u) == 0) unsafeAtomicAdd(acc + 8 + (row >> 1), d2);
             }
         }
     }
