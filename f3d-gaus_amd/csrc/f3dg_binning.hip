@@ -90,11 +90,18 @@ scan_apply_kernel(const u32* in, u32* out /* may alias in */, u64 n, const u32* 
     const u64 base = (u64)blockIdx.x * F3DG_SCAN_CHUNK + (u64)threadIdx.x * F3DG_SCAN_ITEMS;
     u32 v[F3DG_SCAN_ITEMS];
     u32 s = 0;
+    if (base + F3DG_SCAN_ITEMS <= n) {           // 64 contiguous bytes per thread: four 16-byte loads
 #pragma unroll
-    for (int i = 0; i < F3DG_SCAN_ITEMS; i++) {
-        v[i] = (base + i < n) ? in[base + i] : 0;
-        s += v[i];
+        for (int i = 0; i < F3DG_SCAN_ITEMS / 4; i++) {
+            const uint4 w = reinterpret_cast<const uint4*>(in + base)[i];
+            v[4 * i] = w.x; v[4 * i + 1] = w.y; v[4 * i + 2] = w.z; v[4 * i + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < F3DG_SCAN_ITEMS; i++) v[i] = (base + i < n) ? in[base + i] : 0;
     }
+#pragma unroll
+    for (int i = 0; i < F3DG_SCAN_ITEMS; i++) s += v[i];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 x = s;
 #pragma unroll
@@ -106,11 +113,21 @@ scan_apply_kernel(const u32* in, u32* out /* may alias in */, u64 n, const u32* 
     __syncthreads();
     u32 run = block_sums[blockIdx.x] + x - s;
     for (int w = 0; w < wave; w++) run += wtot[w];
+    u32 o[F3DG_SCAN_ITEMS];
 #pragma unroll
     for (int i = 0; i < F3DG_SCAN_ITEMS; i++) {
         const u32 before = run;
         run += v[i];
-        if (base + i < n) out[base + i] = exclusive ? before : run;
+        o[i] = exclusive ? before : run;
+    }
+    if (base + F3DG_SCAN_ITEMS <= n) {
+#pragma unroll
+        for (int i = 0; i < F3DG_SCAN_ITEMS / 4; i++)
+            reinterpret_cast<uint4*>(out + base)[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < F3DG_SCAN_ITEMS; i++)
+            if (base + i < n) out[base + i] = o[i];
     }
 }
 
