@@ -386,10 +386,15 @@ group_counts_kernel(u32 nseg, const u32* __restrict__ gstart, const u32* __restr
 
 __global__ void __launch_bounds__(F3DG_BLOCK)
 group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restrict__ gcum /* inclusive scan */,
-                    uint2* __restrict__ ranges)
+                    uint2* __restrict__ ranges, F3dgHeader* __restrict__ hdr, u32 small_cap, u32 mid_cap)
 {
     const u32 i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
-    if (i < nseg) ranges[i] = gcount[i] ? make_uint2(gcum[i] - gcount[i], gcum[i]) : make_uint2(0u, 0u);
+    if (i < nseg) {
+        const u32 c = gcount[i];
+        ranges[i] = c ? make_uint2(gcum[i] - c, gcum[i]) : make_uint2(0u, 0u);
+        if (c > mid_cap) atomicAdd(&hdr->n_long_segments, 1u);
+        else if (c > small_cap) atomicAdd(&hdr->n_mid_segments, 1u);
+    }
 }
 
 // LDS-resident per-(view, tile) sort for segments of lo < n <= THREADS * ITEMS - 64 entries. The keys live in REGISTERS
@@ -424,6 +429,7 @@ tile_sort_lds_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ g
     __shared__ u32 sdepth[CAP];
     __shared__ unsigned short sidx[CAP];
     if (hdr->overflow) return;
+    if (n_lo != 0u && hdr->n_mid_segments == 0u) return;          // the medium tier is launched unconditionally
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 lane_lt = ((u64)1 << lane) - 1;
 
@@ -562,7 +568,7 @@ tile_sort_long_kernel(const uint2* __restrict__ ranges, const u32* __restrict__ 
     __shared__ u32 cursor[256];
     __shared__ u32 wtot[F3DG_BLOCK / 64];
     __shared__ u32 skip_flag;
-    if (hdr->overflow) return;
+    if (hdr->overflow || hdr->n_long_segments == 0u) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 lane_lt = ((u64)1 << lane) - 1;
 
@@ -740,7 +746,8 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int grid_y, int
     hipLaunchKernelGGL(group_counts_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gstart, gend, gcount);
     rc = f3dg_launch_scan_inclusive(s, gcount, hist /* reuse as gcum */, nseg, scan_tmp, L.scan_tmp_elems, 0, nullptr);
     if (rc != F3DG_OK) return rc;
-    hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges);
+    hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges, hdr,
+                       (u32)(F3DG_SMALL_THREADS * F3DG_SMALL_ITEMS - 64), (u32)(F3DG_MID_THREADS * F3DG_MID_ITEMS - 64));
 
     // 5. level 2: per-(view, tile) stable sort by the depth bits: gather the group from half 1, write it sorted to half 0
     //    three tiers by segment length (each kernel skips the segments of the others): <= 4032, <= 16320, longer

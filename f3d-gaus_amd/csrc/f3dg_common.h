@@ -24,7 +24,9 @@ struct F3dgHeader {
     unsigned int overflow;       // 1 if num_rendered > capacity
     unsigned int capacity;       // instance capacity the workspace was carved for
     unsigned int sort_cur;       // which ping-pong half holds the sorted result
-    unsigned int reserved[60];
+    unsigned int n_mid_segments;  // (view, tile) groups of 4033..16320 entries / longer ones: the rare sort tiers return at
+    unsigned int n_long_segments; // once when their count is 0
+    unsigned int reserved[58];
 };
 
 // Per-(view, Gaussian) record consumed by the compositing kernel: one 64-byte line.
