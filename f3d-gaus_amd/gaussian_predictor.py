@@ -88,8 +88,22 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_channels))
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
-    def forward(self, x, N_views_xa=1):
-        return F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
+    def forward(self, x, N_views_xa=1, silu=False):
+        """``silu=True`` returns ``F.silu(group_norm(x))``: the pair the residual blocks always apply together. In
+        inference on a HIP device the pair is ONE fused kernel (``f3dg_group_norm_silu``); with autograd
+        or on the host (the CPU fixtures of the backbone) it is the two PyTorch ops."""
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and not (
+                torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+            xc = x.contiguous()
+            y = torch.empty_like(xc)
+            N, Cc = xc.shape[0], xc.shape[1]
+            rc = _lib.lib().f3dg_group_norm_silu(_stream(), N, Cc, xc.numel() // max(N * Cc, 1), self.num_groups,
+                                                 _lib.ptr(xc), _lib.ptr(self.weight), _lib.ptr(self.bias), float(self.eps),
+                                                 1 if silu else 0, _lib.ptr(y))
+            _lib.check(rc, "f3dg_group_norm_silu")
+            return y
+        y = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
+        return F.silu(y) if silu else y
 
 
 class UNetBlock(nn.Module):
@@ -116,8 +130,8 @@ class UNetBlock(nn.Module):
 
     def forward(self, x, emb=None, N_views_xa=1):
         orig = x
-        x = self.conv0(F.silu(self.norm0(x)))
-        x = F.silu(self.norm1(x))
+        x = self.conv0(self.norm0(x, silu=True))
+        x = self.norm1(x, silu=True)
         x = self.conv1(F.dropout(x, p=self.dropout, training=self.training))
         x = x + (self.skip(orig) if self.skip is not None else orig)
         x = x * self.skip_scale
@@ -183,9 +197,9 @@ class SongUNet(nn.Module):
         out = None
         for name, blk in self.dec.items():
             if name.endswith('aux_norm'):
-                out = blk(x)
+                out = blk(x, silu=True)            # the reference applies silu before aux_conv (:487-488)
             elif name.endswith('aux_conv'):
-                out = blk(F.silu(out))
+                out = blk(out)
             else:
                 if x.shape[1] != blk.in_channels:
                     x = torch.cat([x, skips.pop()], dim=1)

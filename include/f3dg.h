@@ -184,6 +184,13 @@ int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* r
                          const float* c2w, float fx, float fy,
                          float* normal_world, float* depth_normal);
 
+/* Fused GroupNorm (+ SiLU when apply_silu != 0) of the predictor's SongUNet backbone (src/gaussian_predictor.py:250-262 and the
+ * `silu(norm(x))` of its residual blocks, :318-323): x, y [N,C,HW] float32 contiguous (NCHW), weight / bias [C],
+ * statistics per (sample, group) over C/groups x HW values, biased variance, y = (x - mean) / sqrt(var + eps) * weight + bias.
+ * x == y (in place) is allowed. SURVEY.md 8f-3. */
+int f3dg_group_norm_silu(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
+                         const float* bias, float eps, int apply_silu, float* y);
+
 /* Runtime switches (process-wide). Known names: "render_pretest" (default 1): the compositing kernel first runs a
  * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;
  * results are bit-identical with it on or off (asserted by the tests). "render_cull" (default 1): every 16x4 pixel strip
