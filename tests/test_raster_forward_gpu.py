@@ -20,6 +20,7 @@ SCENES = {
     "F6_small_splats": dict(P=30000, res=(128, 128), s0=0.01, view="oblique"),
     "F8_sh0": dict(P=1500, res=(64, 64), s0=0.05, view="oblique", sh_degree=0),
     "F9_long_tile_lists": dict(P=30000, res=(128, 128), s0=0.05, view="oblique"),      # lists of 4k..16k: 512-thread LDS tile sort
+    "F11_wide_radix": dict(P=20000, res=(320, 272), s0=0.02, view="oblique"),         # 340 tiles: two 8-bit tile passes
     "F10_huge_tile_lists": dict(P=50000, res=(32, 32), s0=0.05, view="canonical"),     # lists > 16320: global-memory tile sort path
 }
 
@@ -99,7 +100,7 @@ def test_wide_group_stream_is_identical(gpu_device):
     try:
         for wide in (0, 1):
             L.f3dg_set_option(b"sort_wide_groups", wide)
-            for name in ("F5_odd_size", "F9_long_tile_lists", "F10_huge_tile_lists"):
+            for name in ("F5_odd_size", "F9_long_tile_lists", "F10_huge_tile_lists", "F11_wide_radix"):
                 res.append((wide, name, run_hip(make_scene(**SCENES[name]), gpu_device)))
             res.append((wide, "multi", run_hip(make_scene(P=8000, res=(128, 128), s0=0.03, view=[0, 1, 3, 5, 6, 2, 4, 7, 8]), gpu_device)))
     finally:
