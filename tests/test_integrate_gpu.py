@@ -90,3 +90,17 @@ def test_renderer_wrapper_in():
     assert out["alpha_integrated"].shape == (5000,) and out["color_integrated"].shape == (5000, 3)
     assert out["render"].shape == (3, 64, 64) and not out["rendered_normal"].any()
     assert int(out["distortion_map"].sum().item()) > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_integrate_random_configurations(seed):
+    rng = np.random.default_rng(2000 + seed)
+    W, H = int(rng.integers(17, 150)), int(rng.integers(17, 150))
+    kw = dict(P=int(rng.integers(200, 5000)), res=(W, H), s0=float(np.exp(rng.uniform(np.log(0.01), np.log(0.1)))),
+              seed=int(rng.integers(0, 1000)), view="oblique" if seed % 2 else "canonical",
+              kernel_size=float(rng.choice([0.0, 0.1])), bg=tuple(float(x) for x in rng.uniform(0, 1, 3)),
+              colors_precomp=bool(seed % 3 == 2))
+    scene = make_scene(**kw)
+    pts = make_points(scene, int(rng.integers(100, 20000)), seed=seed, spread=float(rng.uniform(0.01, 0.2)))
+    o, h = run_both(scene, pts, torch.device("cuda:0"))
+    assert_integrate_parity(o, h, str(kw))

@@ -142,3 +142,24 @@ def test_known_answers_and_kernel_variants(gpu_device):
         L.f3dg_set_option(b"render_cull", 1)
     for k in ("dL_dview2gaussian", "dL_dopacity", "dL_dcolors", "dL_dmeans2D", "dL_dsh"):
         assert _rel(g2[k], g0[k]) <= 2e-6, k
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_backward_random_configurations(seed, gpu_device):
+    """Compositing-stage gradients on random image sizes / splat sizes / filters against the oracle."""
+    rng = np.random.default_rng(3000 + seed)
+    W, H = int(rng.integers(17, 120)), int(rng.integers(17, 120))
+    kw = dict(P=int(rng.integers(200, 4000)), res=(W, H), s0=float(np.exp(rng.uniform(np.log(0.02), np.log(0.1)))),
+              seed=int(rng.integers(0, 1000)), view="oblique" if seed % 2 else "canonical",
+              kernel_size=float(rng.choice([0.0, 0.1])), scale_modifier=float(rng.choice([1.0, 0.7])),
+              bg=tuple(float(x) for x in rng.uniform(0, 1, 3)), colors_precomp=bool(seed % 3 == 2))
+    scene = make_scene(**kw)
+    dpix = rng.standard_normal((9, H, W)).astype(np.float32)
+    o = run_oracle(scene)
+    go = o["oracle"].backward(dpix)
+    gh, radii = _hip_fwd_bwd(scene, dpix[None], gpu_device)
+    assert np.array_equal(radii[0], o["radii"])
+    assert _rel(gh["dL_dview2gaussian"][0], go["dL_dview2gaussian"]) <= 1e-5, kw
+    assert _rel(gh["dL_dopacity"], go["dL_dopacity"]) <= 1e-5, kw
+    assert _rel(gh["dL_dcolors"][0], go["dL_dcolor"]) <= 1e-5, kw
+    assert _rel(gh["dL_dmeans2D"][0], go["dL_dmean2D"]) <= 2e-5, kw
