@@ -112,7 +112,7 @@ def main():
     gather_buf = None
     pending = []
     if world > 1:
-        gather_buf = [torch.empty((V, 3, RES, RES), dtype=torch.uint8, device=comm_device) for _ in range(world)] if rank == 0 else None
+        gather_buf = [torch.empty((V, RES, RES, 3), dtype=torch.uint8, device=comm_device) for _ in range(world)] if rank == 0 else None
 
     def step():
         if streams:
@@ -128,7 +128,7 @@ def main():
             for a, b in chunks:
                 render_chunk(a, b, check=False)
         if world > 1:     # final gather of the RGB frames (the only exchange of the path)
-            frames = (out[:, :3].clamp(0, 1) * 255.0).to(torch.uint8).to(comm_device)
+            frames = f3d.gaussian_renderer.pack_frames(out).to(comm_device)          # uint8 [V,H,W,3], one kernel
             work = dist.gather(frames, gather_buf, dst=0, async_op=True)
             pending.append((work, frames))
             while len(pending) > 1:           # at most one gather in flight behind the current step

@@ -40,6 +40,7 @@ SIGNATURES = {
     "f3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
     "f3dg_splat_head": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _ll, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "f3dg_render_epilogue": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),
+    "f3dg_pack_frames": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "f3dg_group_norm_silu": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
     "f3dg_set_option": (_i, [C.c_char_p, _i]),
     "f3dg_profile_enable": (_i, [_i]),

@@ -140,6 +140,36 @@ epilogue_kernel(int H, int W, const float* __restrict__ raster, const float* __r
     }
 }
 
+
+// 8-bit RGB frames for the video writer / the multi-GPU gather: dst[n][y][x][c] = (uint8)(255 * clamp(src[n][c][y][x], 0, 1))
+// exactly as visualize.py:407,416 does on the host ((255 * np.clip(x, 0, 1)).astype(np.uint8): float32 product, truncation).
+// src is planar with `src_channels` planes per frame (9 for the rasterizer output) of which the first three are read.
+__global__ void __launch_bounds__(F3DG_BLOCK)
+pack_frames_kernel(size_t HW, int src_channels, const float* __restrict__ src, unsigned char* __restrict__ dst)
+{
+    const size_t q = (size_t)blockIdx.x * F3DG_BLOCK + threadIdx.x;      // group of 4 pixels
+    const size_t n = blockIdx.y;
+    const float* s = src + n * (size_t)src_channels * HW;
+    unsigned char* d = dst + n * 3 * HW;
+    auto cv = [](float v) -> unsigned { return (unsigned)(255.0f * fminf(fmaxf(v, 0.0f), 1.0f)); };
+    if (q * 4 + 4 <= HW && (HW & 3) == 0) {
+        const float4 r = reinterpret_cast<const float4*>(s)[q];
+        const float4 g = reinterpret_cast<const float4*>(s + HW)[q];
+        const float4 b = reinterpret_cast<const float4*>(s + 2 * HW)[q];
+        const unsigned w0 = cv(r.x) | (cv(g.x) << 8) | (cv(b.x) << 16) | (cv(r.y) << 24);
+        const unsigned w1 = cv(g.y) | (cv(b.y) << 8) | (cv(r.z) << 16) | (cv(g.z) << 24);
+        const unsigned w2 = cv(b.z) | (cv(r.w) << 8) | (cv(g.w) << 16) | (cv(b.w) << 24);
+        unsigned* o = reinterpret_cast<unsigned*>(d + q * 12);
+        o[0] = w0; o[1] = w1; o[2] = w2;
+    } else {
+        for (size_t p = q * 4; p < q * 4 + 4 && p < HW; p++) {
+            d[3 * p] = (unsigned char)cv(s[p]);
+            d[3 * p + 1] = (unsigned char)cv(s[HW + p]);
+            d[3 * p + 2] = (unsigned char)cv(s[2 * HW + p]);
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int f3dg_splat_head(void* stream, int B, int H, int W, const float* net_out, const float* depth,
@@ -170,6 +200,19 @@ extern "C" int f3dg_render_epilogue(void* stream, int n_views, int H, int W, con
     dim3 grid((unsigned)(((long long)H * W + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)n_views);
     hipLaunchKernelGGL(epilogue_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, H, W, raster, c2w, fx, fy,
                        normal_world, depth_normal);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+extern "C" int f3dg_pack_frames(void* stream, int n_frames, int H, int W, int src_channels, const float* src,
+                                unsigned char* dst)
+{
+    if (n_frames < 0 || H <= 0 || W <= 0 || src_channels < 3 || !src || !dst) return F3DG_ERR_BAD_ARG;
+    if (n_frames == 0) return F3DG_OK;
+    const size_t HW = (size_t)H * W;
+    if (((uintptr_t)src & 15u) || ((uintptr_t)dst & 3u)) return F3DG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_frames_kernel, dim3((unsigned)((HW / 4 + F3DG_BLOCK) / F3DG_BLOCK), (unsigned)n_frames), dim3(F3DG_BLOCK), 0,
+                       (hipStream_t)stream, HW, src_channels, src, dst);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -44,6 +44,19 @@ def _epilogue(raster, world_view, W, H, FoVx, FoVy, want_normal=True, want_depth
     return nw, dn
 
 
+def pack_frames(raster):
+    """raster [n,C>=3,H,W] float32 on the HIP device -> uint8 [n,H,W,3] = (255 * clip(raster[:, :3], 0, 1)).astype(uint8),
+    the frame format of visualize.py:416, in one kernel (f3dg_pack_frames)."""
+    if raster.device.type != "cuda":
+        raise RuntimeError("pack_frames needs a tensor on a HIP device (no CPU fallback)")
+    r = raster.contiguous().float()
+    n, Cc, H, W = r.shape
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=r.device)
+    rc = _lib.lib().f3dg_pack_frames(_stream(), n, H, W, Cc, _lib.ptr(r), _lib.ptr(out))
+    _lib.check(rc, "f3dg_pack_frames")
+    return out
+
+
 def depths_to_points(world_view_transform, image_width, image_height, FoVx, FoVy, depthmap):
     """Back-projects a depth map to world-space points [H*W,3] (gaussian_renderer/__init__.py:881-896).
     Small torch helper kept for API parity; the render path itself uses the fused epilogue kernel."""

@@ -184,6 +184,11 @@ int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* r
                          const float* c2w, float fx, float fy,
                          float* normal_world, float* depth_normal);
 
+/* 8-bit RGB frames for the video writer and the multi-GPU gather: dst [n_frames,H,W,3] uint8 =
+ * (uint8)(255 * clamp(src[:, 0:3], 0, 1)) with src [n_frames,src_channels,H,W] float32 planar (src_channels = 9 for the
+ * rasterizer output), i.e. what visualize.py:407,416 computes on the host per frame. */
+int f3dg_pack_frames(void* stream, int n_frames, int H, int W, int src_channels, const float* src, unsigned char* dst);
+
 /* Fused GroupNorm (+ SiLU when apply_silu != 0) of the predictor's SongUNet backbone (src/gaussian_predictor.py:250-262 and the
  * `silu(norm(x))` of its residual blocks, :318-323): x, y [N,C,HW] float32 contiguous (NCHW), weight / bias [C],
  * statistics per (sample, group) over C/groups x HW values, biased variance, y = (x - mean) / sqrt(var + eps) * weight + bias.

@@ -198,3 +198,15 @@ def test_group_norm_silu_kernel_matches_torch(gpu_device):
                 t = F.silu(t) if silu else t
                 err, err_t = (y.double() - ref).abs().max().item(), (t.double() - ref).abs().max().item()
                 assert err <= max(2 * err_t, 2e-6), (N, Cc, H, W, silu, err, err_t)
+
+
+def test_pack_frames_matches_reference_formula(gpu_device):
+    """(255 * np.clip(x, 0, 1)).astype(np.uint8) of visualize.py:416 on the first three planes, HWC order; bit-exact."""
+    from f3dgaus_amd.gaussian_renderer import pack_frames
+    torch.manual_seed(3)
+    for (n, C, H, W) in ((5, 9, 64, 64), (2, 3, 17, 23), (1, 9, 256, 256)):
+        x = (torch.rand(n, C, H, W) * 1.6 - 0.3)
+        x[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 254.9999 / 255.0, 0.5])
+        got = pack_frames(x.to(gpu_device)).cpu().numpy()
+        ref = (255 * np.clip(x[:, :3].permute(0, 2, 3, 1).numpy(), 0, 1)).astype(np.uint8)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (n, C, H, W)
