@@ -18,7 +18,7 @@ from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, Gaussian
 
 from . import gaussian_renderer, gaussian_predictor, unet_gs, cycle, dist  # noqa: E402,F401
 from .gaussian_renderer import (render_predicted_more_v2_gof, render_predicted_more_v3_gof,  # noqa: E402,F401
-                                render_predicted_more_v2_gof_in,
+                                render_predicted_more_v2_gof_in, AlphaSweep,
                                 render_views, depth_to_normal, depths_to_points)
 from .gaussian_predictor import GaussianSplatPredictor_gtunet, splat_head  # noqa: E402,F401
 from .unet_gs import Unet_GS_gtunet  # noqa: E402,F401

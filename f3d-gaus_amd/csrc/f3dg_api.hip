@@ -273,6 +273,64 @@ extern "C" size_t f3dg_integrate_workspace_bytes(int P, int PN, int W, int H, lo
     return f3dg_integ_layout(P, PN, W, H, max_rendered).total;
 }
 
+extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                            int PN_max, int P, int D, int M, const float* background, int W, int H,
+                                            const float* means3D, const float* shs, const float* colors_precomp,
+                                            const float* opacities, const float* scales, float scale_modifier,
+                                            const float* rotations, const float* cov3D_precomp,
+                                            const float* view2gaussian_precomp, const float* viewmatrix,
+                                            const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                            float kernel_size, float* out_color, int* radii, long long* h_needed)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (PN_max < 0 || P <= 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace || !background)
+        return F3DG_ERR_BAD_ARG;
+    if (max_rendered > 0xFFFFFFF0ll) return F3DG_ERR_BAD_ARG;
+    const F3dgLayout L = f3dg_layout(P, W, H, 1, max_rendered);
+    const F3dgIntegLayout I = f3dg_integ_layout(P, PN_max, W, H, max_rendered);
+    if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
+    if (h_needed) *h_needed = 0;
+    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
+    int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                 view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
+    if (rc != F3DG_OK) return rc;
+    const float focal_y = H / (2.0f * tan_fovy);           // rasterizer_impl.cu:567-568
+    const float focal_x = W / (2.0f * tan_fovx);
+    int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
+    rc = run_geometry(s, ws, L, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                      rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, nullptr);
+    if (rc != F3DG_OK) return rc;
+    rc = f3dg_launch_integrate_pass1(s, W, H, focal_x, focal_y, L, I, ws, background, out_color);
+    if (rc != F3DG_OK) return rc;
+    long long n = 0;
+    rc = f3dg_read_status(stream, workspace, &n);
+    if (h_needed) *h_needed = n;
+    if (rc != F3DG_OK) return rc;
+    return n;
+}
+
+extern "C" int f3dg_integrate_points(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                     int PN, int P, int W, int H, const float* points3D, const float* viewmatrix,
+                                     float tan_fovx, float tan_fovy, float* out_color, float* out_alpha_integrated,
+                                     float* out_color_integrated, float* alpha_min)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (PN < 0 || P <= 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace || !viewmatrix)
+        return F3DG_ERR_BAD_ARG;
+    if (PN == 0) return F3DG_OK;
+    if (!points3D) return F3DG_ERR_BAD_ARG;
+    const F3dgLayout L = f3dg_layout(P, W, H, 1, max_rendered);
+    const F3dgIntegLayout I = f3dg_integ_layout(P, PN, W, H, max_rendered);
+    if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
+    const float focal_y = H / (2.0f * tan_fovy);
+    const float focal_x = W / (2.0f * tan_fovx);
+    return f3dg_launch_integrate_points(s, PN, W, H, focal_x, focal_y, L, I, static_cast<char*>(workspace), points3D,
+                                        viewmatrix, out_color, out_alpha_integrated, out_color_integrated, alpha_min);
+}
+
 extern "C" long long f3dg_integrate(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
                                     int PN, int P, int D, int M, const float* background, int W, int H,
                                     const float* points3D, const float* means3D, const float* shs,
@@ -289,39 +347,23 @@ extern "C" long long f3dg_integrate(void* stream, void* workspace, size_t worksp
     hipStream_t s = (hipStream_t)stream;
     if (PN < 0 || P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace) return F3DG_ERR_BAD_ARG;
     if (PN > 0 && (!points3D || !out_alpha_integrated || !out_color_integrated)) return F3DG_ERR_BAD_ARG;
-    if (max_rendered > 0xFFFFFFF0ll) return F3DG_ERR_BAD_ARG;
-    const F3dgLayout L = f3dg_layout(P, W, H, 1, max_rendered);
-    const F3dgIntegLayout I = f3dg_integ_layout(P, PN, W, H, max_rendered);
-    if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
-    char* ws = static_cast<char*>(workspace);
-    F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
     if (h_needed) *h_needed = 0;
-
-    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
     if (P == 0 || PN == 0) {                               // rasterize_points.cu:300: nothing runs, the fills stay
+        if (workspace_bytes < sizeof(F3dgHeader)) return F3DG_ERR_WORKSPACE;
+        hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<F3dgHeader*>(workspace), (unsigned)max_rendered);
         int rc = f3dg_launch_integrate_fill(s, W, H, PN, out_color, out_alpha_integrated, out_color_integrated);
         if (rc != F3DG_OK) return rc;
         F3DG_HIP_CHECK(hipStreamSynchronize(s));
         return 0;
     }
-    if (!background) return F3DG_ERR_BAD_ARG;
-    int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                 view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
-    if (rc != F3DG_OK) return rc;
-
-    const float focal_y = H / (2.0f * tan_fovy);           // rasterizer_impl.cu:567-568
-    const float focal_x = W / (2.0f * tan_fovx);
-    int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
-    rc = run_geometry(s, ws, L, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
-                      rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, nullptr);
-    if (rc != F3DG_OK) return rc;
-    rc = f3dg_launch_integrate(s, PN, P, W, H, focal_x, focal_y, L, I, ws, points3D, viewmatrix, background, out_color,
-                               out_alpha_integrated, out_color_integrated);
-    if (rc != F3DG_OK) return rc;
-    long long n = 0;
-    rc = f3dg_read_status(stream, workspace, &n);
-    if (h_needed) *h_needed = n;
+    // = prepare (projection + binning + the per-pixel pass) followed by the point stage on the same workspace
+    const long long n = f3dg_integrate_prepare(stream, workspace, workspace_bytes, max_rendered, PN, P, D, M, background, W, H,
+                                               means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                               cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos,
+                                               tan_fovx, tan_fovy, kernel_size, out_color, radii, h_needed);
+    if (n < 0) return n;
+    const int rc = f3dg_integrate_points(stream, workspace, workspace_bytes, max_rendered, PN, P, W, H, points3D, viewmatrix,
+                                         tan_fovx, tan_fovy, out_color, out_alpha_integrated, out_color_integrated, nullptr);
     if (rc != F3DG_OK) return rc;
     return n;
 }

@@ -119,7 +119,8 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
 
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated);
-int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
-                          const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
-                          const float* background, float* out_color, float* out_alpha_integrated,
-                          float* out_color_integrated);
+int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+                                const F3dgIntegLayout& I, char* ws, const float* background, float* out_color);
+int f3dg_launch_integrate_points(hipStream_t s, int PN, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+                                 const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
+                                 float* out_color, float* out_alpha_integrated, float* out_color_integrated, float* alpha_min);

@@ -287,10 +287,13 @@ integrate_points_bin_kernel(int PN, const float* __restrict__ points3D, const fl
     float ix, iy, depth;
     const bool ok = !hdr->overflow && project_point(points3D, idx, viewmatrix, W, H, focal_x, focal_y, ix, iy, depth);
     if (!ok) {                                                      // the caller's fills, rasterize_points.cu:275-276
-        out_alpha_integrated[idx] = 1.0f;
-        out_color_integrated[3 * (size_t)idx] = 0.0f;
-        out_color_integrated[3 * (size_t)idx + 1] = 0.0f;
-        out_color_integrated[3 * (size_t)idx + 2] = 0.0f;
+        if (out_alpha_integrated)
+            out_alpha_integrated[idx] = 1.0f;
+        if (out_color_integrated) {
+            out_color_integrated[3 * (size_t)idx] = 0.0f;
+            out_color_integrated[3 * (size_t)idx + 1] = 0.0f;
+            out_color_integrated[3 * (size_t)idx + 2] = 0.0f;
+        }
         pt_pix[idx] = 0xFFFFFFFFu;
         return;
     }
@@ -324,7 +327,8 @@ integrate_points_kernel(int PN, const float* __restrict__ points3D, const float*
                         const unsigned* __restrict__ contrib_n, const unsigned* __restrict__ n_contrib,
                         const float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
                         float* __restrict__ out_color_integrated, const unsigned* __restrict__ pix_points,
-                        const unsigned* __restrict__ pix_start, const unsigned* __restrict__ perm)
+                        const unsigned* __restrict__ pix_start, const unsigned* __restrict__ perm,
+                        float* __restrict__ alpha_min)
 {
     const unsigned i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const size_t HW = (size_t)H * W;
@@ -373,10 +377,17 @@ integrate_points_kernel(int PN, const float* __restrict__ points3D, const float*
         point_alpha += alpha * point_T;
         point_T = test_T;
     }
-    out_alpha_integrated[idx] = point_alpha;
-    out_color_integrated[3 * (size_t)idx] = out_color[0 * HW + pix_id];         // C + T * bg of the pixel (forward.cu:1186)
-    out_color_integrated[3 * (size_t)idx + 1] = out_color[1 * HW + pix_id];
-    out_color_integrated[3 * (size_t)idx + 2] = out_color[2 * HW + pix_id];
+    if (out_alpha_integrated)
+        out_alpha_integrated[idx] = point_alpha;
+    if (out_color_integrated) {
+        out_color_integrated[3 * (size_t)idx] = out_color[0 * HW + pix_id];     // C + T * bg of the pixel (forward.cu:1186)
+        out_color_integrated[3 * (size_t)idx + 1] = out_color[1 * HW + pix_id];
+        out_color_integrated[3 * (size_t)idx + 2] = out_color[2 * HW + pix_id];
+    }
+    if (alpha_min) {                 // torch.min(final_alpha, alpha_integrated) of the mesh-extraction sweep (visualize.py:463)
+        const float cur = alpha_min[idx];
+        alpha_min[idx] = (cur != cur || point_alpha != point_alpha) ? __builtin_nanf("") : fminf(cur, point_alpha);
+    }
 }
 
 __global__ void __launch_bounds__(F3DG_BLOCK)
@@ -455,12 +466,11 @@ int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_c
     return F3DG_OK;
 }
 
-int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
-                          const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
-                          const float* background, float* out_color, float* out_alpha_integrated,
-                          float* out_color_integrated)
+// pass 1: depends on the Gaussians and the camera only (not on the points), so its result -- colours, last contributors and
+// the per-pixel contributor table inside the workspace -- can be kept and reused for any number of point sets
+int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+                                const F3dgIntegLayout& I, char* ws, const float* background, float* out_color)
 {
-    (void)P;
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
     const F3dgHeader* hdr = reinterpret_cast<const F3dgHeader*>(ws + L.header);
@@ -471,10 +481,6 @@ int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float foca
     unsigned* n_contrib = reinterpret_cast<unsigned*>(ws + L.n_contrib);
     unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
     unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
-    unsigned* pix_points = reinterpret_cast<unsigned*>(ws + I.pix_points);
-    unsigned long long* tile_last = reinterpret_cast<unsigned long long*>(ws + I.tile_last);
-
-    F3DG_HIP_CHECK(hipMemsetAsync(ws + I.pix_points, 0, I.clear_bytes, s));
     if (g_f3dg_render_pretest && g_f3dg_render_cull)
         hipLaunchKernelGGL((integrate_pass1_kernel<true>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
@@ -484,11 +490,32 @@ int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float foca
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);
     F3DG_HIP_CHECK(hipGetLastError());
-    // points: counting sort by pixel (bin, scan, perm), then the integration in pixel order
+    return F3DG_OK;
+}
+
+// the point stage against a prepared workspace: counting sort by pixel (bin, scan, perm), integration in pixel order,
+// points-per-pixel epilogue. Any of the three outputs may be null.
+int f3dg_launch_integrate_points(hipStream_t s, int PN, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+                                 const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
+                                 float* out_color, float* out_alpha_integrated, float* out_color_integrated, float* alpha_min)
+{
+    const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    const int T = tiles_x * tiles_y;
+    const F3dgHeader* hdr = reinterpret_cast<const F3dgHeader*>(ws + L.header);
+    const uint2* ranges = reinterpret_cast<const uint2*>(ws + L.ranges);
+    const unsigned* point_list = reinterpret_cast<const unsigned*>(ws + L.vals[0]);
+    const F3dgRec* rec = reinterpret_cast<const F3dgRec*>(ws + L.rec);
+    const unsigned* n_contrib = reinterpret_cast<const unsigned*>(ws + L.n_contrib);
+    const unsigned short* contrib_ids = reinterpret_cast<const unsigned short*>(ws + I.contrib_ids);
+    const unsigned* contrib_n = reinterpret_cast<const unsigned*>(ws + I.contrib_n);
+    unsigned* pix_points = reinterpret_cast<unsigned*>(ws + I.pix_points);
+    unsigned long long* tile_last = reinterpret_cast<unsigned long long*>(ws + I.tile_last);
     unsigned* pix_start = reinterpret_cast<unsigned*>(ws + I.pix_start);
     unsigned* pt_pix = reinterpret_cast<unsigned*>(ws + I.pt_pix);
     unsigned* pt_rank = reinterpret_cast<unsigned*>(ws + I.pt_rank);
     unsigned* perm = reinterpret_cast<unsigned*>(ws + I.perm);
+
+    F3DG_HIP_CHECK(hipMemsetAsync(ws + I.pix_points, 0, I.clear_bytes, s));
     const dim3 pgrid((PN + F3DG_BLOCK - 1) / F3DG_BLOCK);
     hipLaunchKernelGGL(integrate_points_bin_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
                        focal_x, focal_y, hdr, out_alpha_integrated, out_color_integrated, pix_points, tile_last, pt_pix, pt_rank);
@@ -498,7 +525,7 @@ int f3dg_launch_integrate(hipStream_t s, int PN, int P, int W, int H, float foca
     hipLaunchKernelGGL(integrate_points_perm_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, pt_pix, pt_rank, pix_start, perm);
     hipLaunchKernelGGL(integrate_points_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
                        focal_x, focal_y, hdr, ranges, point_list, rec, contrib_ids, contrib_n, n_contrib, out_color,
-                       out_alpha_integrated, out_color_integrated, pix_points, pix_start, perm);
+                       out_alpha_integrated, out_color_integrated, pix_points, pix_start, perm, alpha_min);
     F3DG_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(integrate_epilogue_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                        points3D, viewmatrix, pix_points, tile_last, out_color);

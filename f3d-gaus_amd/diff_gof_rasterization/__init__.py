@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import _lib
 
 __all__ = ["GaussianRasterizationSettings_GOF", "GaussianRasterizer_GOF", "rasterize_gaussians", "rasterize_views",
-           "integrate_gaussians_to_points", "Workspace"]
+           "integrate_gaussians_to_points", "integrate_prepare", "integrate_points", "PreparedIntegration", "Workspace"]
 
 
 class GaussianRasterizationSettings_GOF(NamedTuple):
@@ -274,6 +274,96 @@ def integrate_gaussians_to_points(points3D, means3D, sh, colors_precomp, opaciti
             _lib.check(rc, "f3dg_integrate")
             _CAP_HINT[(P, W, H, 1)] = max(int(rc * 1.5) + 1024, 1 << 14)
             return color, alpha_integrated, color_integrated, radii, int(rc)
+
+
+class PreparedIntegration:
+    """Everything of ``integrate`` that does not depend on the points, kept on the device for one camera: the workspace with
+    the projected Gaussians, the sorted tile lists and the per-pixel contributor table, and the [9,H,W] image of the
+    per-pixel pass. Built by ``integrate_prepare``; ``integrate_points`` runs any number of point sets against it.
+    (MI355X-first: ~0.25 GB per camera at 589,824 Gaussians / 256^2, so the 129 cameras of a mesh-extraction sweep stay
+    resident in the 288 GB of HBM instead of being recomputed for each of its 9 point sets.)"""
+
+    def __init__(self, buffer, capacity, max_points, P, W, H, tanfovx, tanfovy, viewmatrix, color, radii, num_rendered):
+        self.buffer, self.capacity, self.max_points, self.P, self.W, self.H = buffer, capacity, max_points, P, W, H
+        self.tanfovx, self.tanfovy, self.viewmatrix = tanfovx, tanfovy, viewmatrix
+        self.color, self.radii, self.num_rendered = color, radii, num_rendered
+
+
+def integrate_prepare(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp,
+                      raster_settings, max_points):
+    """``f3dg_integrate_prepare``: projection + binning + per-pixel pass of ``integrate`` for one camera."""
+    L = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("f3dgaus_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
+    if means3D.ndim != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    rs = raster_settings
+    with torch.no_grad():
+        P = means3D.size(0)
+        if P == 0:
+            raise RuntimeError("integrate_prepare needs at least one Gaussian")
+        H, W = int(rs.image_height), int(rs.image_width)
+        means3D_ = _dev_f32(means3D, device)
+        sh = _dev_f32(sh, device)
+        colors_precomp = _dev_f32(colors_precomp, device)
+        opacities_ = _dev_f32(opacities, device)
+        scales = _dev_f32(scales, device)
+        rotations = _dev_f32(rotations, device)
+        cov3Ds_precomp = _dev_f32(cov3Ds_precomp, device)
+        view2gaussian_precomp = _dev_f32(view2gaussian_precomp, device)
+        vm = _dev_f32(rs.viewmatrix, device).reshape(16).clone()
+        pm = _dev_f32(rs.projmatrix, device)
+        cp = _dev_f32(rs.campos, device)
+        bgt = _dev_f32(rs.bg, device)
+        M = 0 if sh is None else (sh.size(1) if sh.ndim == 3 else sh.numel() // (3 * max(P, 1)))
+        color = torch.empty((9, H, W), dtype=torch.float32, device=device)
+        radii = torch.zeros((P,), dtype=torch.int32, device=device)
+        cap = _initial_capacity(P, W, H, 1)
+        while True:
+            nbytes = L.f3dg_integrate_workspace_bytes(P, int(max_points), W, H, cap)
+            if nbytes == 0:
+                raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_integrate_workspace_bytes")
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            needed = C.c_longlong(0)
+            rc = L.f3dg_integrate_prepare(
+                _stream(), C.c_void_p(buf.data_ptr()), buf.numel(), cap, int(max_points), P, int(rs.sh_degree), int(M),
+                _lib.ptr(bgt), W, H, _lib.ptr(means3D_), _lib.ptr(sh), _lib.ptr(colors_precomp), _lib.ptr(opacities_),
+                _lib.ptr(scales), float(rs.scale_modifier), _lib.ptr(rotations), _lib.ptr(cov3Ds_precomp),
+                _lib.ptr(view2gaussian_precomp), _lib.ptr(vm), _lib.ptr(pm), _lib.ptr(cp), float(rs.tanfovx),
+                float(rs.tanfovy), float(rs.kernel_size), _lib.ptr(color), _lib.ptr(radii), C.byref(needed))
+            if rc == _lib.ERR_OVERFLOW:
+                cap = int(needed.value * 1.25) + 1024
+                continue
+            _lib.check(rc, "f3dg_integrate_prepare")
+            _CAP_HINT[(P, W, H, 1)] = max(int(rc * 1.5) + 1024, 1 << 14)
+            return PreparedIntegration(buf, cap, int(max_points), P, W, H, float(rs.tanfovx), float(rs.tanfovy), vm, color,
+                                       radii, int(rc))
+
+
+def integrate_points(prepared, points3D, alpha_min=None, want_outputs=True):
+    """``f3dg_integrate_points``: one point set against a ``PreparedIntegration``. Returns (alpha_integrated [PN],
+    color_integrated [PN,3]) (None, None with ``want_outputs=False``); ``alpha_min`` [PN] float32, if given, is updated in
+    place to ``torch.min(alpha_min, alpha_integrated)`` -- the accumulation of visualize.py:463 without a second kernel."""
+    pr = prepared
+    device = pr.buffer.device
+    if points3D.ndim != 2 or points3D.size(1) != 3:
+        raise RuntimeError("points3D must have dimensions (num_points, 3)")
+    PN = points3D.size(0)
+    if PN > pr.max_points:
+        raise RuntimeError(f"the integration was prepared for at most {pr.max_points} points, got {PN}")
+    with torch.no_grad():
+        pts = points3D.to(device=device, dtype=torch.float32).contiguous()
+        ai = torch.empty((PN,), dtype=torch.float32, device=device) if want_outputs else None
+        ci = torch.empty((PN, 3), dtype=torch.float32, device=device) if want_outputs else None
+        if alpha_min is not None and (alpha_min.dtype != torch.float32 or not alpha_min.is_contiguous() or alpha_min.numel() != PN
+                                      or alpha_min.device != device):
+            raise RuntimeError("alpha_min must be a contiguous float32 tensor of PN elements on the same device")
+        rc = _lib.lib().f3dg_integrate_points(
+            _stream(), C.c_void_p(pr.buffer.data_ptr()), pr.buffer.numel(), pr.capacity, PN, pr.P, pr.W, pr.H, _lib.ptr(pts),
+            _lib.ptr(pr.viewmatrix), pr.tanfovx, pr.tanfovy, _lib.ptr(pr.color), _lib.ptr(ai), _lib.ptr(ci), _lib.ptr(alpha_min))
+        _lib.check(rc, "f3dg_integrate_points")
+    return ai, ci
 
 
 class GaussianRasterizer_GOF(nn.Module):

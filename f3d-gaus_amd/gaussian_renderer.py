@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF, _stream,
-                                     rasterize_views)
+                                     integrate_points, integrate_prepare, rasterize_views)
 
 
 def focal2fov(focal, pixels):
@@ -169,6 +169,49 @@ def render_predicted_more_v2_gof_in(points3D, pc: dict, bs, world_view_transform
     that is what the reference's integrate kernel leaves in those channels.)"""
     return _render_one(lambda k: pc[k][bs], bs, world_view_transform, full_proj_transform, camera_center, bg_color,
                        cfg, kernel_size, scaling_modifier, override_color, points3D=points3D)
+
+
+class AlphaSweep:
+    """The opacity evaluation of the mesh extraction (visualize.py:449-464 and its 8 binary-search repeats :495-507):
+    ``final_alpha = min over cameras of integrate(points).alpha_integrated``. The reference re-runs the whole rasterizer
+    for every (camera, point set) pair; here every camera is prepared ONCE (``integrate_prepare``: projection, binning and
+    the per-pixel pass stay resident in HBM) and each call only runs the per-point stage of every camera, with the minimum
+    accumulated inside that kernel. Same numbers as looping ``render_predicted_more_v2_gof_in``.
+
+        sweep = AlphaSweep(pc, bs, world_views, full_projs, camera_centers, bg, cfg, max_points=points.shape[0])
+        final_alpha = sweep(points)          # [PN]; call again for the refined point sets
+    """
+
+    def __init__(self, pc: dict, bs, world_view_transforms, full_proj_transforms, camera_centers, bg_color, cfg, max_points,
+                 kernel_size=0.0, scaling_modifier=1.0, override_color=None):
+        get = lambda k: pc[k][bs]
+        xyz = get("xyz")
+        tanfov = math.tan(cfg['model']['fov'] * np.pi / 360)
+        res = int(cfg['model']['training_resolution'])
+        shs = torch.cat([get("features_dc"), get("features_rest")], dim=1).contiguous() if override_color is None else None
+        colors = None if override_color is None else get("rgbs")
+        wv = world_view_transforms.reshape(-1, 4, 4)
+        fp = full_proj_transforms.reshape(-1, 4, 4)
+        cc = camera_centers.reshape(-1, 3)
+        self.views = []
+        for v in range(wv.shape[0]):
+            rs = GaussianRasterizationSettings_GOF(
+                image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, kernel_size=kernel_size,
+                subpixel_offset=torch.empty((0,), device=xyz.device), bg=bg_color, scale_modifier=scaling_modifier,
+                viewmatrix=wv[v], projmatrix=fp[v], sh_degree=cfg['model']['max_sh_degree'], campos=cc[v],
+                prefiltered=False, debug=False)
+            self.views.append(integrate_prepare(xyz, shs, colors, get("opacity"), get("scaling"), get("rotation"), None, None,
+                                                rs, max_points))
+
+    @property
+    def nbytes(self):
+        return sum(v.buffer.numel() for v in self.views)
+
+    def __call__(self, points3D):
+        final_alpha = torch.ones((points3D.shape[0],), dtype=torch.float32, device=points3D.device)
+        for v in self.views:
+            integrate_points(v, points3D, alpha_min=final_alpha, want_outputs=False)
+        return final_alpha
 
 
 def render_predicted_more_v3_gof(pc, bs, world_view_transform, full_proj_transform, camera_center,

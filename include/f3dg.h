@@ -154,6 +154,26 @@ long long f3dg_integrate(void* stream, void* workspace, size_t workspace_bytes, 
                          int prefiltered, float* out_color, int* radii, float* out_alpha_integrated,
                          float* out_color_integrated, long long* h_needed);
 
+/* The two halves of f3dg_integrate, for callers that integrate MANY point sets against the same Gaussians and camera
+ * (the mesh-extraction sweep of visualize.py:449-505 runs 9 point sets through each of 129 cameras): everything that does
+ * not depend on the points -- projection, binning and the five-ray per-pixel pass with its contributor table -- is done
+ * once by f3dg_integrate_prepare and stays in the workspace (sized with PN_max = the largest point set that will follow);
+ * f3dg_integrate_points then costs one lane per point. out_color is written by prepare (channels 0..7) and read by
+ * points (which also writes channel 8). out_alpha_integrated / out_color_integrated may be NULL; alpha_min, if not NULL,
+ * is updated as alpha_min[i] = min(alpha_min[i], alpha_integrated[i]) (torch.min semantics, visualize.py:463). */
+long long f3dg_integrate_prepare(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                 int PN_max, int P, int D, int M, const float* background, int W, int H,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* view2gaussian_precomp,
+                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                 float tan_fovx, float tan_fovy, float kernel_size, float* out_color, int* radii,
+                                 long long* h_needed);
+int f3dg_integrate_points(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                          int PN, int P, int W, int H, const float* points3D, const float* viewmatrix,
+                          float tan_fovx, float tan_fovy, float* out_color, float* out_alpha_integrated,
+                          float* out_color_integrated, float* alpha_min);
+
 /* present[i] = (view-space z of means3D[i] > 0.2), auxiliary.h:177-202. present is uint8 [P]. */
 int f3dg_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present);

@@ -104,3 +104,41 @@ def test_integrate_random_configurations(seed):
     pts = make_points(scene, int(rng.integers(100, 20000)), seed=seed, spread=float(rng.uniform(0.01, 0.2)))
     o, h = run_both(scene, pts, torch.device("cuda:0"))
     assert_integrate_parity(o, h, str(kw))
+
+
+def test_prepared_integration_and_alpha_sweep():
+    """integrate_prepare + integrate_points give the bits of the one-shot integrate, for several point sets against the same
+    preparation; AlphaSweep equals the reference-shaped loop min_v integrate_v(points).alpha_integrated."""
+    from f3dgaus_amd import cameras
+    from f3dgaus_amd.diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF,
+                                                    integrate_points, integrate_prepare)
+    dev = torch.device("cuda:0")
+    scene = make_scene(P=6000, res=(64, 64), s0=0.04, view=[1, 3, 6])
+    d = lambda t: None if t is None else t.to(dev)
+    sets = [torch.from_numpy(make_points(scene, n, seed=s)).to(dev) for n, s in ((9000, 0), (4000, 1), (9000, 2))]
+    loops = [torch.ones(len(p), device=dev) for p in sets]
+    for v in range(3):
+        rs = GaussianRasterizationSettings_GOF(64, 64, scene["tanfovx"], scene["tanfovy"], 0.0, torch.zeros(0), d(scene["bg"]), 1.0,
+                                               d(scene["viewmatrix"][v]), d(scene["projmatrix"][v]), scene["sh_degree"],
+                                               d(scene["campos"][v]), False, False)
+        prep = integrate_prepare(d(scene["means3D"]), d(scene["shs"]), None, d(scene["opacities"]), d(scene["scales"]),
+                                 d(scene["rotations"]), None, None, rs, max_points=9000)
+        for k, pts in enumerate(sets):
+            color, ai, ci, radii = GaussianRasterizer_GOF(rs).integrate(
+                points3D=pts, means3D=d(scene["means3D"]), means2D=None, opacities=d(scene["opacities"]), shs=d(scene["shs"]),
+                scales=d(scene["scales"]), rotations=d(scene["rotations"]))
+            ai2, ci2 = integrate_points(prep, pts)
+            assert torch.equal(ai, ai2) and torch.equal(ci, ci2) and torch.equal(color, prep.color), (v, k)
+            assert torch.equal(radii, prep.radii)
+            loops[k] = torch.min(loops[k], ai)
+    cfg = cameras.default_cfg(resolution=64)
+    cfg["model"]["max_sh_degree"] = scene["sh_degree"]
+    pc = {"xyz": d(scene["means3D"])[None], "opacity": d(scene["opacities"])[None], "scaling": d(scene["scales"])[None],
+          "rotation": d(scene["rotations"])[None], "features_dc": d(scene["shs"])[None, :, :1],
+          "features_rest": d(scene["shs"])[None, :, 1:]}
+    sweep = f3d.AlphaSweep(pc, 0, d(scene["viewmatrix"]), d(scene["projmatrix"]), d(scene["campos"]), d(scene["bg"]), cfg,
+                           max_points=9000)
+    # the sweep uses cfg's field of view; the scene was built with the same one
+    assert abs(np.tan(cfg["model"]["fov"] * np.pi / 360) - scene["tanfovx"]) < 1e-12
+    for k, pts in enumerate(sets):
+        assert torch.equal(sweep(pts), loops[k]), k
