@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("F3DG_VIEWS_PER_CALL", "120")))
     ap.add_argument("--streams", type=int, default=int(os.environ.get("F3DG_STREAMS", "1")),
                     help="HIP streams the view chunks are distributed over (chunk i -> stream i %% streams)")
+    ap.add_argument("--render-mode", choices=["fast", "exact"], default=os.environ.get("F3DG_RENDER_MODE", "fast"),
+                    help="compositing arithmetic: fast = error-free float32 pairs for the float64 island (default, parity-gated "
+                         "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
     return ap.parse_args()
@@ -69,6 +72,7 @@ def main():
     import f3dgaus_amd as f3d
     from f3dgaus_amd import _lib, synthetic
     L = _lib.lib()
+    _lib.check(L.f3dg_set_option(b"render_fast", 1 if args.render_mode == "fast" else 0), "f3dg_set_option")
 
     P, V, RES = args.gaussians, args.views, args.res
     g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)     # every rank = a different image

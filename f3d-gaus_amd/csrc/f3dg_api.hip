@@ -63,6 +63,7 @@ inline void prof_mark(ProfCall* c, int stage_done, hipStream_t s) { if (c) (void
 int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
+int g_f3dg_render_fast = 1;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
@@ -70,6 +71,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
 {
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }

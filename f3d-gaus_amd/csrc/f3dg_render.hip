@@ -107,9 +107,78 @@ __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor
     return false;
 }
 
+
+// Fast-mode counterpart of blend_entry (option "render_fast", the default): the same decisions and the same float32
+// accumulations, but the reference's float64 island (forward.cu:511-522,545,548) is evaluated with error-free float32
+// pairs instead of float64 divides / square roots:
+//   * aaf, bhalf (and n0..n2) are the reference's own float32 values, computed in its operation order by the caller:
+//     their rounding errors are amplified 1e5..1e6 x by the cancellation and must be reproduced, not improved on;
+//   * b^2/a is formed as a double-single quotient (q1 + q2, relative error ~2^-45): b*b = p + e exactly (FMA), q1 = p*r,
+//     q2 = ((p - q1*a) + e)*r with r ~ 1/a; C - q1 is exact (Sterbenz) wherever the exponent matters, so
+//     min_value = (C - q1) - q2 carries one float32 rounding of a number of magnitude <~ 20: |d power| <~ 1e-6;
+//   * t = -b/a from the same reciprocal with one Newton step (<= 1 ulp), exp() as v_exp_f32(power * log2 e),
+//     the NDC depth as c0 - c1/t with a hardware reciprocal, the normal with v_rsq_f32.
+// Every output stays within ~1e-6 relative of blend_entry's; the parity tests gate this mode at the same 1e-4 / 99.9 % /
+// 80 dB bar as the exact one (tests/test_raster_forward_gpu.py) and report both against the oracle.
+__device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contributor, float n0, float n1, float n2, float aaf,
+                                                 float bhalf, float CC, float opac, float cr, float cg, float cb)
+{
+    const float r = __builtin_amdgcn_rcpf(aaf);
+    const float t0 = -bhalf * r;
+    const float t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+    if (t < 0.2f)                       // (double)t <= 0.2  <=>  t < 0.2f: 0.2f is the float just above 0.2 (false for NaN,
+        return false;                   // as the reference's test)
+
+    const float p = bhalf * bhalf;
+    const float e = fmaf(bhalf, bhalf, -p);
+    const float q1 = p * r;
+    const float q2 = (fmaf(-q1, aaf, p) + e) * r;
+    const float min_value = (CC - q1) - q2;
+    float power = -0.5f * min_value;
+    if (power > 0.0f)
+        power = 0.0f;
+
+    const float alpha = fminf(0.99f, opac * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+    if (alpha < 1.0f / 255.0f)
+        return false;
+    const float Tr = st.Tr;
+    const float test_T = Tr * (1 - alpha);
+    if (test_T < 0.0001f)
+        return true;
+
+    // (FAR*t - FAR*NEAR) / ((FAR - NEAR)*t) = FAR/(FAR-NEAR) - (FAR*NEAR/(FAR-NEAR)) / t
+    const float mapped_max_t = fmaf(-0.20040080160320642f, __builtin_amdgcn_rcpf(t), 1.0020040080160322f);
+
+    const float inv_len = __builtin_amdgcn_rsqf(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7f);
+    const float w = alpha * Tr;
+
+    const float A = 1 - Tr;
+    const float error = mapped_max_t * mapped_max_t * A + st.dist2 - 2 * mapped_max_t * st.dist1;
+    st.distortion += error * alpha * Tr;
+    st.dist1 += mapped_max_t * alpha * Tr;
+    st.dist2 += mapped_max_t * mapped_max_t * alpha * Tr;
+
+    const float wn = -w * inv_len;
+    st.C0 = fmaf(cr, w, st.C0);
+    st.C1 = fmaf(cg, w, st.C1);
+    st.C2 = fmaf(cb, w, st.C2);
+    st.C3 = fmaf(n0, wn, st.C3);
+    st.C4 = fmaf(n1, wn, st.C4);
+    st.C5 = fmaf(n2, wn, st.C5);
+    if (Tr > 0.5f) {
+        st.C6 = t;
+        st.max_contributor = contributor;
+    }
+    st.C7 += w;
+
+    st.Tr = test_T;
+    st.last_contributor = contributor;
+    return false;
+}
+
 #define F3DG_ROUND (F3DG_BLOCK - 1)     // list entries staged per round; LDS slot F3DG_ROUND is the sentinel
 
-template <bool SAVE_AUX, bool PRETEST, bool CULL, bool QUEUE>
+template <bool SAVE_AUX, bool PRETEST, bool CULL, bool QUEUE, bool FAST>
 __global__ void __launch_bounds__(F3DG_BLOCK, 8)
 render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
@@ -274,7 +343,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                         continue;
                 }
                 const float4 q3 = sq3[j];
-                done = blend_entry(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+                done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
             }
         } else {
             // ---- two-phase loop over windows of 64 entries
@@ -321,7 +390,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                     const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
                     const float aaf = ray_x * n0 + ray_y * n1 + n2;
                     const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-                    done = blend_entry(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+                    done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
                 }
             }
         }
@@ -367,10 +436,11 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     const int T = tiles_x * tiles_y;
     const unsigned groups = (unsigned)((V + 7) / 8);
     dim3 grid(groups * 8u * (unsigned)T);
-#define F3DG_LAUNCH(AUX, PRE, CUL, QUE) hipLaunchKernelGGL((render_fwd_kernel<AUX, PRE, CUL, QUE>), grid, dim3(F3DG_BLOCK), 0, s, V, P, \
+#define F3DG_LAUNCH(AUX, PRE, CUL, QUE, FST) hipLaunchKernelGGL((render_fwd_kernel<AUX, PRE, CUL, QUE, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, \
                                                             W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec,   \
                                                             bbox, background, bg_per_view, out_color, final_T, n_contrib)
-#define F3DG_LAUNCH_Q(AUX, PRE, CUL) do { if (g_f3dg_render_queue) F3DG_LAUNCH(AUX, PRE, CUL, true); else F3DG_LAUNCH(AUX, PRE, CUL, false); } while (0)
+#define F3DG_LAUNCH_Q(AUX, PRE, CUL) do { if (g_f3dg_render_fast) { if (g_f3dg_render_queue) F3DG_LAUNCH(AUX, PRE, CUL, true, true); else F3DG_LAUNCH(AUX, PRE, CUL, false, true); } \
+                                          else { if (g_f3dg_render_queue) F3DG_LAUNCH(AUX, PRE, CUL, true, false); else F3DG_LAUNCH(AUX, PRE, CUL, false, false); } } while (0)
     const int variant = (save_aux ? 4 : 0) | (g_f3dg_render_pretest ? 2 : 0) | (g_f3dg_render_cull ? 1 : 0);
     switch (variant) {
     case 0: F3DG_LAUNCH_Q(false, false, false); break;

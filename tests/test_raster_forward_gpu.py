@@ -11,6 +11,18 @@ from helpers import assert_render_parity, make_scene, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["fast", "exact"])
+def render_mode(request):
+    """Every test of this module runs in both compositing modes: "fast" (the default: error-free float32 pairs instead of the
+    float64 island, csrc/f3dg_render.hip) and "exact" (the reference's float32/float64 operation order). Both are held to
+    the same tolerances."""
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    assert L.f3dg_set_option(b"render_fast", 1 if request.param == "fast" else 0) == 0
+    yield request.param
+    L.f3dg_set_option(b"render_fast", 1)
+
 SCENES = {
     "F1_tiny_identity": dict(P=2000, res=(64, 64), s0=0.05, view="canonical"),
     "F2_oblique_aniso": dict(P=5000, res=(128, 128), s0=0.02, view="oblique", aniso=True, behind_fraction=0.05),
