@@ -64,6 +64,7 @@ int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
+int g_f3dg_render_kernel = 2;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
@@ -71,6 +72,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
 {
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : 2; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
@@ -135,6 +137,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.rec = take(VP * sizeof(F3dgRec));
     L.means2D = take(VP * sizeof(float2));
     L.bbox = take(VP * sizeof(float4));
+    L.cull = take(VP * 2 * sizeof(float4));
     L.depths = take(VP * sizeof(float));
     L.conic = take(VP * sizeof(float4));
     L.radii = take(VP * sizeof(int));
@@ -199,6 +202,7 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
                                     reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
                                     reinterpret_cast<float*>(ws + L.depths), reinterpret_cast<float4*>(ws + L.bbox),
+                                    reinterpret_cast<float4*>(ws + L.cull),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
                                     reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
@@ -261,7 +265,8 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
                               reinterpret_cast<const uint2*>(ws + L.ranges),
                               reinterpret_cast<const unsigned*>(ws + L.vals[0]),
                               reinterpret_cast<const F3dgRec*>(ws + L.rec),
-                              reinterpret_cast<const float4*>(ws + L.bbox), background,
+                              reinterpret_cast<const float4*>(ws + L.bbox),
+                              reinterpret_cast<const float4*>(ws + L.cull), background,
                               (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color,
                               reinterpret_cast<float*>(ws + L.final_T),
                               reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux);

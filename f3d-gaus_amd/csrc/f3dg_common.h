@@ -45,6 +45,7 @@ struct F3dgLayout {
     size_t means2D;        // [V*P] float2
     size_t depths;         // [V*P] float: view-space depth again, compact, for key generation (4 B instead of a 64-B record line)
     size_t bbox;           // [V*P] float4: conservative pixel-space box (x0,x1,y0,y1) outside of which alpha < 1/255 is certain
+    size_t cull;           // [V*P][2] float4: conservative ellipse of the same region (cx, cy, a, b | c, hx, hy, -), see f3dg_preprocess.hip
     size_t conic;          // [V*P] float4 (conic.xyz, opacity*coef) -- backward only
     size_t radii;          // [V*P] int   (internal copy when the caller passes none)
     size_t tiles;          // [V*P] u32   tiles_touched
@@ -96,8 +97,8 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox, float4* conic, int* radii,
-                           unsigned* tiles, unsigned char* clamped, int save_aux);
+                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox /* may be null */, float4* cull, float4* conic,
+                           int* radii, unsigned* tiles, unsigned char* clamped, int save_aux);
 
 int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out, unsigned long long n,
                                unsigned* tmp, unsigned tmp_elems, int exclusive,
@@ -111,12 +112,13 @@ extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
 extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
+extern int g_f3dg_render_kernel;       // 2 (default): render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
 extern int g_f3dg_render_fast;         // 1 (default): float64 island of the blend replaced by error-free float32 pairs; 0: bit-exact path
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
-                       const float4* bbox, const float* background, int bg_per_view, float* out_color, float* final_T,
-                       unsigned* n_contrib, int save_aux);
+                       const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
+                       float* final_T, unsigned* n_contrib, int save_aux);
 
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated);

@@ -72,32 +72,49 @@ __device__ __forceinline__ float pretest_constant(const float* vg, float thr)
 }
 
 // Conservative pixel-space box of the region where this Gaussian's alpha can reach 1/255 in the compositing kernel.
-//   alpha >= 1/255  =>  p = -(C - b^2/a)/2 >= thr  <=>  (C - k) a - b^2 <= 0, k = -2 thr, a = r^T Sigma' r, b = B^T r, r = (x, y, 1):
-// a conic in ray space with matrix M = (C - k) Sigma' - B B^T; its axis-aligned extent follows from the dual conic adj(M).
-// k is widened by a worst-case bound on the float32 evaluation error of the reference's own a and b:
-//   |da| <= 6 eps |r|^2 tr(Sigma'),  a >= S_min |r|^2 (S_min = min_i 1/(s_i^2 + 1e-7))  =>  da/a <= 6 eps tr(Sigma')/S_min;
-//   |db| <= 3 eps |B||r| with |B||r|/|b| <~ S_max/S_min near the splat                 =>  db/b <= 3 eps tr(Sigma')/S_min;
-//   dp = q (da/a + 2 db/b)/2 <= 6 eps C tr(Sigma')/S_min; 8 is used. Everything is done in float64, and the box is
-// inflated by 0.1 % + 0.25 px. Anything degenerate (camera inside the level set, non-finite,
+//   alpha >= 1/255  =>  p^ = -(C - b^^2/a^)/2 >= thr  =>  (C - k) a^ - b^^2 <= 0 with k = -2 thr (a^ > 0), where a^, b^ are the
+// reference's own float32 values of a = r^T Sigma' r and b = B^T r, r = (x, y, 1). Their rounding errors matter (they are
+// amplified by C ~ 1e5..1e6), so the region is widened by a worst-case bound on them, standard forward error analysis of the
+// reference's operation order (forward.cu:504-509; u = 2^-24):
+//   |a^ - a| <= 6u A(r),  A(r) = |r|^T |Sigma'| |r|   (two nested 3-term dot products: gamma_3 twice),
+//   |b^ - b| <= 3u Bn(r), Bn(r) = |B|^T |r|,
+//   (C - k) a - b^2  <=  [(C - k) a^ - b^^2] + (C - k) |a^ - a| + |b^ - b| (2 |b| + |b^ - b|)  <=  6u ((C - k) A + Bn^2) =: D.
+// |x| <= tan_fovx and |y| <= tan_fovy for every pixel centre, so A, Bn are bounded once per Gaussian with r = (tan_fovx,
+// tan_fovy, 1), and the widened region is the exact conic r^T M r <= 0, M = (C - k) Sigma' - B B^T - diag(0, 0, 1.1 D); 2e-3 is
+// added to k for the float32 rounding of the exponent itself. (Round 1 widened k by 8u C tr(Sigma')/S_min instead, which is
+// valid but 3x too wide in area on the C2 workload.) Its axis-aligned extent follows from the dual conic adj(M). Everything is
+// done in float64, and the box is inflated by 0.1 % + 0.25 px. Anything degenerate (camera inside the level set, non-finite,
 // ill-conditioned, precomputed view2gaussian without scales) returns the "everything" box, i.e. no culling.
-__device__ __forceinline__ float4 conservative_box(const float* vg, float thr, float3 scale, bool have_scale, int W, int H,
-                                                   float focal_x, float focal_y)
+struct CullConic { double m00, m01, m02, m11, m12, m22; bool ok; };
+__device__ __forceinline__ CullConic cull_conic(const float* vg, float thr, float tan_fovx, float tan_fovy)
+{
+    CullConic q;
+    q.ok = false;
+    const double u = 5.9604644775390625e-08;
+    const double C = vg[9];
+    const double k = -2.0 * (double)thr + 2e-3;
+    const double cK = C - k;
+    q.m00 = q.m01 = q.m02 = q.m11 = q.m12 = q.m22 = 0.0;
+    if (!(cK > 0.0)) return q;
+    const double X = tan_fovx, Y = tan_fovy;
+    const double A = fabs((double)vg[0]) * X * X + 2.0 * fabs((double)vg[1]) * X * Y + 2.0 * fabs((double)vg[2]) * X +
+                     fabs((double)vg[3]) * Y * Y + 2.0 * fabs((double)vg[4]) * Y + fabs((double)vg[5]);
+    const double Bn = fabs((double)vg[6]) * X + fabs((double)vg[7]) * Y + fabs((double)vg[8]);
+    const double D = 1.1 * 6.0 * u * (cK * A + Bn * Bn);
+    const double B0 = vg[6], B1 = vg[7], B2 = vg[8];
+    q.m00 = cK * vg[0] - B0 * B0; q.m01 = cK * vg[1] - B0 * B1; q.m02 = cK * vg[2] - B0 * B2;
+    q.m11 = cK * vg[3] - B1 * B1; q.m12 = cK * vg[4] - B1 * B2; q.m22 = cK * vg[5] - B2 * B2 - D;
+    q.ok = true;
+    return q;
+}
+__device__ __forceinline__ float4 conservative_box(const float* vg, float thr, bool have_scale, int W, int H,
+                                                   float focal_x, float focal_y, float tan_fovx, float tan_fovy)
 {
     const float4 all = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);
     if (!have_scale || !(thr < 3.0e38f)) return all;        // thr = +inf (alpha always < 1/255) is handled by the pre-test
-    const double C = vg[9];
-    const double eps = 5.9604644775390625e-08;
-    const double Sx = 1.0 / ((double)scale.x * scale.x + 1e-7), Sy = 1.0 / ((double)scale.y * scale.y + 1e-7),
-                 Sz = 1.0 / ((double)scale.z * scale.z + 1e-7);
-    const double Smin = fmin(Sx, fmin(Sy, Sz));
-    const double trS = (double)vg[0] + (double)vg[3] + (double)vg[5];
-    const double dp = fabs(C) * eps * 8.0 * fabs(trS) / Smin + 1e-3;
-    const double k = -2.0 * (double)thr + 2.0 * dp;
-    const double cK = C - k;
-    if (!(cK > 0.0)) return all;
-    const double B0 = vg[6], B1 = vg[7], B2 = vg[8];
-    const double m00 = cK * vg[0] - B0 * B0, m01 = cK * vg[1] - B0 * B1, m02 = cK * vg[2] - B0 * B2;
-    const double m11 = cK * vg[3] - B1 * B1, m12 = cK * vg[4] - B1 * B2, m22 = cK * vg[5] - B2 * B2;
+    const CullConic q = cull_conic(vg, thr, tan_fovx, tan_fovy);
+    if (!q.ok) return all;
+    const double m00 = q.m00, m01 = q.m01, m02 = q.m02, m11 = q.m11, m12 = q.m12, m22 = q.m22;
     const double D00 = m11 * m22 - m12 * m12, D11 = m00 * m22 - m02 * m02, D22 = m00 * m11 - m01 * m01;
     const double D02 = m01 * m12 - m02 * m11, D12 = m01 * m02 - m00 * m12;
     if (!(m00 > 0.0) || !(D22 > 1e-9 * fabs(m00 * m11))) return all;
@@ -113,6 +130,52 @@ __device__ __forceinline__ float4 conservative_box(const float* vg, float thr, f
                        (float)y0 - 1e-3f * (1.0f + fabsf((float)y0)), (float)y1 + 1e-3f * (1.0f + fabsf((float)y1)));
 }
 
+
+// Conservative ELLIPSE of the same region (the compositing kernel's phase 1 tests pixels against it; f3dg_render.hip).
+// The level set (C - k) a - b^2 <= 0 of conservative_box is an exact conic r^T M r <= 0 in ray space; with the centre
+// (cx, cy) of that conic and Qc < 0 its value there it reads  E(dx, dy) = a dx^2 + b dx dy + c dy^2 <= 1  in pixel offsets
+// from the centre. The record is that ellipse scaled UNIFORMLY about its centre by s = 1.001 + 0.05 px / semi-minor axis
+// (a point inside an ellipse stays inside any uniformly larger one), which covers the float32 rounding of the centre
+// (<= 2.5e-4 px for images up to 4096 px) and of the kernel's float32 evaluation of E (<= ~2e-4 relative for aspect ratios
+// up to 31; flatter ellipses keep only their box). The conic is cull_conic's, i.e. it carries the same worst-case bound on the
+// reference's own float32 rounding of a and b as conservative_box. out[0] = (cx, cy, a, b), out[1] = (c, hx, hy, 0): hx, hy are the half extents
+// of the ellipse's axis-aligned box (+1e-3 px), what the staging thread turns into the 4x4-block mask.
+//   "everything" (nothing can be proven): a = b = c = 0 (E = 0 passes everywhere), hx = hy = 3e38;
+//   "never" (alpha < 1/255 everywhere: opacity <= 0, or the level set is empty): hx = hy = -1e30 (in no block list).
+__device__ __forceinline__ void conservative_ellipse(const float* vg, float thr, bool have_scale, int W, int H,
+                                                     float focal_x, float focal_y, float tan_fovx, float tan_fovy, float4& e0, float4& e1)
+{
+    e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    e1 = make_float4(0.0f, 3.0e38f, 3.0e38f, 0.0f);
+    if (thr == __builtin_inff()) { e1.y = e1.z = -1.0e30f; return; }       // opacity <= 0: alpha <= 0 always
+    if (!have_scale || !(thr < 3.0e38f)) return;
+    const CullConic q = cull_conic(vg, thr, tan_fovx, tan_fovy);
+    if (!q.ok) return;
+    const double m00 = q.m00, m01 = q.m01, m02 = q.m02, m11 = q.m11, m12 = q.m12, m22 = q.m22;
+    const double D22 = m00 * m11 - m01 * m01;
+    if (!(m00 > 0.0) || !(m11 > 0.0) || !(D22 > 1e-9 * fabs(m00 * m11))) return;
+    const double cx = (m01 * m12 - m02 * m11) / D22, cy = (m01 * m02 - m00 * m12) / D22;
+    const double Qc = m22 + m02 * cx + m12 * cy;            // value of the conic at its centre; the quadratic part is positive definite
+    if (!(Qc == Qc) || !(cx == cx) || !(cy == cy)) return;
+    if (Qc > 0.0 && Qc < 1.0e300) { e1.y = e1.z = -1.0e30f; return; }      // empty level set: never visible
+    if (!(Qc < 0.0)) return;
+    const double a = m00 / (-Qc) / ((double)focal_x * focal_x), b = 2.0 * m01 / (-Qc) / ((double)focal_x * focal_y),
+                 c = m11 / (-Qc) / ((double)focal_y * focal_y);
+    const double det = a * c - 0.25 * b * b, tr = a + c;
+    if (!(det > 0.0) || !(tr < 1.0e300)) return;
+    const double lmax = 0.5 * tr + sqrt(fmax(0.25 * tr * tr - det, 0.0)), lmin = det / lmax;
+    const double s = 1.001 + 0.05 * sqrt(lmax);              // 0.05 px / semi-minor axis (= 1/sqrt(lmax))
+    const double hx = s * sqrt(c / det) + 1e-3, hy = s * sqrt(a / det) + 1e-3;
+    const double px = cx * focal_x + W / 2. - 0.5, py = cy * focal_y + H / 2. - 0.5;      // pixel-index coordinates
+    if (!(hx < 1.0e9) || !(hy < 1.0e9) || !(fabs(px) < 1.0e9) || !(fabs(py) < 1.0e9)) return;
+    e0.x = (float)px; e0.y = (float)py;
+    e1.y = (float)(hx * (1.0 + 1e-6)); e1.z = (float)(hy * (1.0 + 1e-6));
+    if (lmax <= 1000.0 * lmin && fabs(px) < 8192.0 && fabs(py) < 8192.0) {
+        const double is2 = 1.0 / (s * s);
+        e0.z = (float)(a * is2); e0.w = (float)(b * is2); e1.x = (float)(c * is2);
+    }
+}
+
 __global__ void __launch_bounds__(F3DG_BLOCK)
 preprocess_kernel(int P, int D, int M,
                   const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
@@ -123,7 +186,7 @@ preprocess_kernel(int P, int D, int M,
                   const float* __restrict__ cam_positions, int W, int H, int grid_x, int grid_y,
                   float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                   F3dgRec* __restrict__ rec, float2* __restrict__ means2D, float* __restrict__ depths_out,
-                  float4* __restrict__ bbox_out,
+                  float4* __restrict__ bbox_out, float4* __restrict__ cull_out,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
                   unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all)
@@ -142,6 +205,7 @@ preprocess_kernel(int P, int D, int M,
     float2 xy = make_float2(0, 0);
     float4 con = make_float4(0, 0, 0, 0);
     float4 box = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);     // "everything" unless proven smaller
+    float4 ce0 = make_float4(0, 0, 0, 0), ce1 = make_float4(0, -1.0e30f, -1.0e30f, 0);   // culled Gaussians are in no list anyway
     unsigned char clamp_bits = 0;
 
     const float px_ = means3D[3 * (size_t)g], py_ = means3D[3 * (size_t)g + 1], pz_ = means3D[3 * (size_t)g + 2];
@@ -347,7 +411,9 @@ preprocess_kernel(int P, int D, int M,
                 // rounding of power. opac <= 0 -> alpha <= 0 always (K = +inf); NaN opacity disables the test.
                 const float thr = debug_skip_all ? __builtin_inff() : opac > 0.0f ? logf(1.0f / (255.0f * opac)) - 1e-4f : (opac <= 0.0f ? __builtin_inff() : opac);
                 const float Kpre = pretest_constant(vg, thr);
-                box = conservative_box(vg, thr, scale, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y);
+                if (bbox_out)
+                    box = conservative_box(vg, thr, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y, tan_fovx, tan_fovy);
+                conservative_ellipse(vg, thr, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y, tan_fovx, tan_fovy, ce0, ce1);
                 r2 = make_float4(vg[8], vg[9], opac, Kpre);
                 r3 = make_float4(cr, cg, cb, pvz);
             }
@@ -358,7 +424,9 @@ preprocess_kernel(int P, int D, int M,
     tiles_touched[idx] = my_tiles;
     means2D[idx] = xy;
     depths_out[idx] = r3.w;
-    bbox_out[idx] = box;
+    if (bbox_out) bbox_out[idx] = box;
+    cull_out[2 * idx] = ce0;
+    cull_out[2 * idx + 1] = ce1;
     float4* dst = reinterpret_cast<float4*>(rec + idx);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
     if (save_aux) {
@@ -384,7 +452,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox, float4* conic, int* radii,
+                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox, float4* cull, float4* conic, int* radii,
                            unsigned* tiles, unsigned char* clamped, int save_aux)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
@@ -392,7 +460,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
-                       depths, bbox, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
+                       depths, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -425,17 +425,280 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     }
 }
 
+// =====================================================================================================================
+// render2: the same compositing with phase 1 turned around -- GAUSSIANS across the lanes instead of pixels.
+//
+// In the kernel above a phase-1 trip tests ONE list entry per 16-lane group against the group's 16 pixels and costs ~31 VALU
+// instructions (the reference's own a, b in its operation order + the K test), i.e. ~0.5 instruction per (pixel, entry) test;
+// with the float64 island gone it is half of the kernel. Here a sub-step gives every LANE one entry of its group's list (4 blocks
+// x 16 entries per wave) and the lane tests it against all 16 pixels of the group's 4x4 block with the conservative ellipse of
+// f3dg_preprocess.hip (E(dx, dy) = a dx^2 + b dx dy + c dy^2 <= 1 in pixel offsets from the ellipse centre: two FMAs per pixel
+// after per-row / per-column set-up, no cancellation, so plain float32 is safe). The 16 per-pixel comparisons ARE wave ballots
+// (v_cmp writes a lane mask): ballot p holds, for each of the wave's four blocks, which of its 16 entries can touch pixel p of
+// that block. Two v_writelane per ballot park them in lanes p and 16 + p of one register, one ds_bpermute hands every pixel lane
+// the 16 bits of its block, and four sub-steps fill the 64-bit pass mask phase 2 walks exactly as before. ~115 VALU instructions
+// per 1024 (pixel, entry) tests instead of ~500, independent of how many of the wave's pixels are still alive; blocks whose 16
+// pixels are all finished get an empty list.
+//
+// The ellipse test is conservative (it passes whenever alpha >= 1/255 is possible, with the worst-case bound on the reference's
+// own float32 rounding of a and b that the culling box already used), so phase 2 sees a superset of the pairs the K pre-test let
+// through and re-derives every decision from the reference's arithmetic: outputs are bit-identical to the kernel above in either
+// arithmetic mode (tests/test_raster_forward_gpu.py::test_render2_bit_identical).
+
+// Phase 1 of render2 for pixel P of the lane's 4x4 block (and, recursively, the following ones). One comparison = one wave
+// ballot (v_cmp writes a lane mask); two v_writelane_b32 (which ignore EXEC and take the SGPR halves as data) park it in lanes
+// P and 16 + P of `stage`. gfx950 needs two wait states between a VALU write of an SGPR / VCC and a VALU read of it, which the
+// compiler cannot see inside inline assembly: the two FMAs that evaluate the NEXT pixel's ellipse value are placed in that gap
+// (s_nop for the last pixel), so the sequence costs no extra issue slots.
+template <int P>
+__device__ __forceinline__ void ellipse_ballots(int& stage, float Ep, const float (&dxx)[4], const float (&adx)[4],
+                                                const float (&dyy)[4], const float (&cdy)[4], float eb)
+{
+    if constexpr (P < 15) {
+        float En;
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "v_fma_f32 %[en], %[eb], %[dy], %[ax]\n\t"
+            "v_fma_f32 %[en], %[dx], %[en], %[cy]\n\t"
+            "v_writelane_b32 %[st], vcc_lo, %[l0]\n\t"
+            "v_writelane_b32 %[st], vcc_hi, %[l1]"
+            : [st] "+v"(stage), [en] "=&v"(En)
+            : [ep] "v"(Ep), [eb] "v"(eb), [dy] "v"(dyy[(P + 1) >> 2]), [ax] "v"(adx[(P + 1) & 3]), [dx] "v"(dxx[(P + 1) & 3]),
+              [cy] "v"(cdy[(P + 1) >> 2]), [l0] "n"(P), [l1] "n"(16 + P)
+            : "vcc");
+        ellipse_ballots<P + 1>(stage, En, dxx, adx, dyy, cdy, eb);
+    } else {
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "s_nop 1\n\t"
+            "v_writelane_b32 %[st], vcc_lo, %[l0]\n\t"
+            "v_writelane_b32 %[st], vcc_hi, %[l1]\n\t"
+            "s_nop 0"
+            : [st] "+v"(stage)
+            : [ep] "v"(Ep), [l0] "n"(P), [l1] "n"(16 + P)
+            : "vcc");
+    }
+}
+
+template <bool SAVE_AUX, bool FAST>
+__global__ void __launch_bounds__(F3DG_BLOCK, 6)
+render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                   const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                   float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+{
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned slot = blockIdx.x >> 3;
+    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
+    const unsigned tile = slot % (unsigned)T;
+    if (view >= (unsigned)V)
+        return;
+
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned grp = lane >> 4, gi = lane & 15u;
+    const unsigned blk_x = (wave & 1u) * 2u + (grp & 1u), blk_y = (wave >> 1) * 2u + (grp >> 1);    // 4x4 block in tile
+    const unsigned lx = blk_x * 4u + (gi & 3u), ly = blk_y * 4u + (gi >> 2);
+    const unsigned pix_x = tile_x * F3DG_TILE + lx, pix_y = tile_y * F3DG_TILE + ly;
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+    const float blk_px0 = (float)(tile_x * F3DG_TILE + blk_x * 4u), blk_py0 = (float)(tile_y * F3DG_TILE + blk_y * 4u);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const int rounds = (int)((range.y - range.x + F3DG_BLOCK - 1) / F3DG_BLOCK);
+
+    __shared__ float4 sA[F3DG_BLOCK];            // v0 v1 v2 v3
+    __shared__ float4 sB[F3DG_BLOCK];            // v4 v5 v6 v7
+    __shared__ float4 sC[F3DG_BLOCK];            // v8 v9 opacity r
+    __shared__ float2 sD[F3DG_BLOCK];            // g b
+    __shared__ float4 sE[F3DG_BLOCK];            // ellipse: cx cy a b
+    __shared__ float sF[F3DG_BLOCK];             //          c
+    __shared__ unsigned short sM[F3DG_BLOCK];    // which of the tile's 16 4x4 blocks the ellipse's box touches
+    __shared__ __align__(16) unsigned char lists[F3DG_BLOCK / 64][4][F3DG_BLOCK];     // per wave, per 16-lane group
+    __shared__ int done_cnt[2];
+    if (threadIdx.x < 2) done_cnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vcull = cull + (size_t)view * P * 2;
+    const float tile_px0 = (float)(tile_x * F3DG_TILE), tile_py0 = (float)(tile_y * F3DG_TILE);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned pull = (gi + 16u * (grp >> 1)) * 4u;       // ds_bpermute source of this pixel's ballot half
+    const unsigned pull_shift = 16u * (grp & 1u);
+    const unsigned char* my_list = lists[wave][grp];
+
+    bool done = !inside;
+    PixelState st;
+    st.Tr = 1.0f;
+    st.last_contributor = 0; st.max_contributor = (unsigned)-1;
+    st.C0 = st.C1 = st.C2 = st.C3 = st.C4 = st.C5 = st.C6 = st.C7 = 0;
+    st.dist1 = st.dist2 = st.distortion = 0;
+
+    for (int i = 0; i < rounds; i++) {
+        const unsigned long long alive = __ballot(!done);
+        if (lane == 0)
+            atomicAdd(&done_cnt[i & 1], 64 - __popcll(alive));
+        __syncthreads();
+        const int num_done = done_cnt[i & 1];
+        if (threadIdx.x == 0)
+            done_cnt[(i + 1) & 1] = 0;          // everyone has read it (round i - 1); next added to after the barrier below
+        if (num_done == F3DG_BLOCK)
+            break;
+
+        const unsigned progress = (unsigned)i * F3DG_BLOCK + threadIdx.x;
+        unsigned short m16 = 0;
+        if (range.x + progress < range.y) {
+            const unsigned id = point_list[range.x + progress];
+            const float4* src = reinterpret_cast<const float4*>(vrec + id);
+            const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+            const float4 e0 = vcull[2 * (size_t)id], e1 = vcull[2 * (size_t)id + 1];
+            sA[threadIdx.x] = a;
+            sB[threadIdx.x] = b;
+            sC[threadIdx.x] = make_float4(c.x, c.y, c.z, d.x);
+            sD[threadIdx.x] = make_float2(d.y, d.z);
+            sE[threadIdx.x] = e0;
+            sF[threadIdx.x] = e1.x;
+            const float x0 = e0.x - e1.y, x1 = e0.x + e1.y, y0 = e0.y - e1.z, y1 = e0.y + e1.z;
+            unsigned mx = 0, my = 0;                          // which of the 4 block columns / rows the box touches
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (x0 <= tile_px0 + (float)(4 * q + 3) && x1 >= tile_px0 + (float)(4 * q)) mx |= 1u << q;
+                if (y0 <= tile_py0 + (float)(4 * q + 3) && y1 >= tile_py0 + (float)(4 * q)) my |= 1u << q;
+            }
+            m16 = (unsigned short)(((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 4 : 0u) | ((my & 4u) ? mx << 8 : 0u) |
+                                   ((my & 8u) ? mx << 12 : 0u));
+        }
+        sM[threadIdx.x] = m16;
+        __syncthreads();
+
+        // four compacted lists per wave, one per 16-lane group (4x4 block), in list order; finished blocks get none
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        {
+            const unsigned qx2 = (wave & 1u) * 2u, qy2 = (wave >> 1) * 2u;
+            const bool g0 = (alive & 0xFFFFull) != 0, g1 = (alive & 0xFFFF0000ull) != 0, g2 = (alive & 0xFFFF00000000ull) != 0,
+                       g3 = (alive >> 48) != 0;
+#pragma unroll
+            for (int c = 0; c < F3DG_BLOCK / 64; c++) {
+                const unsigned e = c * 64 + lane;
+                const unsigned m = sM[e];
+                const bool b0 = g0 && ((m >> ((qy2 + 0u) * 4u + qx2 + 0u)) & 1u), b1 = g1 && ((m >> ((qy2 + 0u) * 4u + qx2 + 1u)) & 1u);
+                const bool b2 = g2 && ((m >> ((qy2 + 1u) * 4u + qx2 + 0u)) & 1u), b3 = g3 && ((m >> ((qy2 + 1u) * 4u + qx2 + 1u)) & 1u);
+                const unsigned long long l0 = __ballot(b0), l1 = __ballot(b1), l2 = __ballot(b2), l3 = __ballot(b3);
+                if (b0) lists[wave][0][c0 + __popcll(l0 & lt)] = (unsigned char)e;
+                if (b1) lists[wave][1][c1 + __popcll(l1 & lt)] = (unsigned char)e;
+                if (b2) lists[wave][2][c2 + __popcll(l2 & lt)] = (unsigned char)e;
+                if (b3) lists[wave][3][c3 + __popcll(l3 & lt)] = (unsigned char)e;
+                c0 += __popcll(l0); c1 += __popcll(l1); c2 += __popcll(l2); c3 += __popcll(l3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const int count = max(max(c0, c1), max(c2, c3));
+        const int my_len = grp == 0 ? c0 : grp == 1 ? c1 : grp == 2 ? c2 : c3;
+        const unsigned round_base = (unsigned)i * F3DG_BLOCK;
+
+        for (int w0 = 0; w0 < count; w0 += 64) {
+            // ---- phase 1: lane (g, e) tests entry w0 + 16 sub + e of group g's list against the 16 pixels of g's block
+            unsigned pass_lo = 0, pass_hi = 0;
+#pragma unroll 1
+            for (int sub = 0; sub < 4; sub++) {
+                const int base = w0 + 16 * sub;
+                if (base >= count)
+                    break;
+                const int pos = base + (int)gi;
+                const int j = (int)my_list[pos];
+                const float4 e = sE[j];
+                const float cc = sF[j];
+                const float u0 = pos < my_len ? blk_px0 - e.x : __builtin_nanf("");     // NaN: every comparison below is false
+                const float v0 = blk_py0 - e.y;
+                float dxx[4], adx[4], dyy[4], cdy[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    dxx[q] = u0 + (float)q;
+                    adx[q] = e.z * dxx[q];
+                    dyy[q] = v0 + (float)q;
+                    cdy[q] = cc * dyy[q] * dyy[q];
+                }
+                int stage = 0;
+                ellipse_ballots<0>(stage, fmaf(dxx[0], fmaf(e.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e.w);
+                const unsigned piece = ((unsigned)__builtin_amdgcn_ds_bpermute((int)pull, stage) >> pull_shift) & 0xFFFFu;
+                if (sub & 2) pass_hi |= piece << (16 * (sub & 1));
+                else pass_lo |= piece << (16 * (sub & 1));
+            }
+            unsigned long long pass = done ? 0ull : ((unsigned long long)pass_hi << 32) | pass_lo;
+
+            // ---- phase 2: this pixel's own passing entries, in list order, through the reference's arithmetic
+            while (pass != 0 && !done) {
+                const int kk = __builtin_ctzll(pass);
+                pass &= pass - 1;
+                const int j = (int)my_list[w0 + kk];
+                const float4 q0 = sA[j], q1 = sB[j], q2 = sC[j];
+                const float2 q3 = sD[j];
+                const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+                const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+                const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+                const float aaf = ray_x * n0 + ray_y * n1 + n2;
+                const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+                done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q2.w, q3.x, q3.y);
+            }
+        }
+    }
+
+    if (inside) {
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = distortion_before_normalized;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        out[8 * HW + pix_id] = distortion;
+    }
+}
+
 } // namespace
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
-                       const float4* bbox, const float* background, int bg_per_view, float* out_color, float* final_T,
-                       unsigned* n_contrib, int save_aux)
+                       const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
+                       float* final_T, unsigned* n_contrib, int save_aux)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
     const unsigned groups = (unsigned)((V + 7) / 8);
     dim3 grid(groups * 8u * (unsigned)T);
+    if (g_f3dg_render_kernel == 2) {
+#define F3DG_LAUNCH2(AUX, FST) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
+                                                  focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \
+                                                  out_color, final_T, n_contrib)
+        if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH2(true, true); else F3DG_LAUNCH2(true, false); }
+        else { if (g_f3dg_render_fast) F3DG_LAUNCH2(false, true); else F3DG_LAUNCH2(false, false); }
+#undef F3DG_LAUNCH2
+        F3DG_HIP_CHECK(hipGetLastError());
+        return F3DG_OK;
+    }
 #define F3DG_LAUNCH(AUX, PRE, CUL, QUE, FST) hipLaunchKernelGGL((render_fwd_kernel<AUX, PRE, CUL, QUE, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, \
                                                             W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec,   \
                                                             bbox, background, bg_per_view, out_color, final_T, n_contrib)

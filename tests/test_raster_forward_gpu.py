@@ -178,6 +178,7 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
     scene = make_scene(**(SCENES[name] if name in SCENES else extra[name]))
     L = _lib.lib()
     try:
+        assert L.f3dg_set_option(b"render_kernel", 1) == 0
         for o in (b"render_pretest", b"render_cull", b"render_queue"):
             assert L.f3dg_set_option(o, 0) == 0
         a = run_hip(scene, gpu_device)              # plain transcription-order kernel
@@ -185,7 +186,10 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
         for pre, cull, que in ((1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)):
             L.f3dg_set_option(b"render_pretest", pre); L.f3dg_set_option(b"render_cull", cull); L.f3dg_set_option(b"render_queue", que)
             variants.append(run_hip(scene, gpu_device))
+        L.f3dg_set_option(b"render_kernel", 2)      # render2: Gaussians across the lanes + conservative ellipse in phase 1
+        variants.append(run_hip(scene, gpu_device))
     finally:
+        L.f3dg_set_option(b"render_kernel", 2)
         for o in (b"render_pretest", b"render_cull", b"render_queue"):
             L.f3dg_set_option(o, 1)
     for b in variants:
