@@ -64,7 +64,9 @@ int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
-int g_f3dg_render_kernel = 2;
+int g_f3dg_render_kernel = 3;
+int g_f3dg_render_lds_pad = 0;
+int g_f3dg_render_occ = 6;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
@@ -72,7 +74,9 @@ extern "C" int f3dg_set_option(const char* name, int value)
 {
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : 2; return F3DG_OK; }
+    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = (value >= 1 && value <= 4) ? value : 3; return F3DG_OK; }
+    if (name && strcmp(name, "render_occ") == 0) { g_f3dg_render_occ = value == 5 ? 5 : 6; return F3DG_OK; }
+    if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value > 0 ? value : 0; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
@@ -137,7 +141,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.rec = take(VP * sizeof(F3dgRec));
     L.means2D = take(VP * sizeof(float2));
     L.bbox = take(VP * sizeof(float4));
-    L.cull = take(VP * 2 * sizeof(float4));
+    L.cull = take(VP * sizeof(float4));
     L.depths = take(VP * sizeof(float));
     L.conic = take(VP * sizeof(float4));
     L.radii = take(VP * sizeof(int));
@@ -195,13 +199,14 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* cam_pos, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                 int* radii_used, int save_aux, ProfCall* prof)
+                 int* radii_used, int save_aux, int need_box, ProfCall* prof)
 {
     int rc = f3dg_launch_preprocess(s, n_views, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
                                     reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
-                                    reinterpret_cast<float*>(ws + L.depths), reinterpret_cast<float4*>(ws + L.bbox),
+                                    reinterpret_cast<float*>(ws + L.depths),
+                                    need_box ? reinterpret_cast<float4*>(ws + L.bbox) : nullptr,
                                     reinterpret_cast<float4*>(ws + L.cull),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
@@ -258,7 +263,8 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
     ProfCall* prof = prof_begin(s);
     rc = run_geometry(s, ws, L, n_views, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, save_aux, prof);
+                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, save_aux,
+                      save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, prof);
     if (rc != F3DG_OK) return rc;
 
     rc = f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
@@ -308,7 +314,7 @@ extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_
     int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
     rc = run_geometry(s, ws, L, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, nullptr);
+                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, 1 /* pass 1 culls by the box */, nullptr);
     if (rc != F3DG_OK) return rc;
     rc = f3dg_launch_integrate_pass1(s, W, H, focal_x, focal_y, L, I, ws, background, out_color);
     if (rc != F3DG_OK) return rc;
@@ -415,7 +421,7 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
                                  float* conic /*[V*P*4]*/, unsigned* tiles /*[V*P]*/, unsigned* offsets /*[V*P]*/,
                                  unsigned char* clamped /*[V*P]*/, unsigned long long* keys_sorted /*[cap]*/,
                                  unsigned* point_list /*[cap]*/, unsigned* ranges /*[V*T*2]*/,
-                                 float* final_T /*[V*4*HW]*/, unsigned* n_contrib /*[V*2*HW]*/)
+                                 float* final_T /*[V*4*HW]*/, unsigned* n_contrib /*[V*2*HW]*/, float* depths /*[V*P]*/)
 {
     hipStream_t s = (hipStream_t)stream;
     const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
@@ -435,6 +441,7 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
     CP(ranges, L.ranges, (size_t)n_views * T * 8);
     CP(final_T, L.final_T, (size_t)n_views * 4 * HW * 4);
     CP(n_contrib, L.n_contrib, (size_t)n_views * 2 * HW * 4);
+    CP(depths, L.depths, VP * 4);
 #undef CP
     return F3DG_OK;
 }

@@ -34,7 +34,7 @@ struct F3dgHeader {
 //   f[10]     opacity * coef (conic_opacity.w)                 forward.cu:392
 //   f[11]     pre-test constant K: alpha < 1/255 is CERTAIN when b^2 < K*a (see f3dg_render.hip)
 //   f[12..14] rgb                                              forward.cu:379-384
-//   f[15]     view-space depth                                 forward.cu:388
+//   f[15]     c of the conservative ellipse (f3dg_preprocess.hip); the view-space depth (forward.cu:388) is in `depths`
 // The first three float4 are everything the conservative pre-test needs; the 4th is only read by contributors.
 struct __attribute__((aligned(16))) F3dgRec { float f[F3DG_REC_FLOATS]; };
 
@@ -45,7 +45,7 @@ struct F3dgLayout {
     size_t means2D;        // [V*P] float2
     size_t depths;         // [V*P] float: view-space depth again, compact, for key generation (4 B instead of a 64-B record line)
     size_t bbox;           // [V*P] float4: conservative pixel-space box (x0,x1,y0,y1) outside of which alpha < 1/255 is certain
-    size_t cull;           // [V*P][2] float4: conservative ellipse of the same region (cx, cy, a, b | c, hx, hy, -), see f3dg_preprocess.hip
+    size_t cull;           // [V*P] float4: conservative ellipse of the same region (cx, cy, a, b); its c is record slot 15
     size_t conic;          // [V*P] float4 (conic.xyz, opacity*coef) -- backward only
     size_t radii;          // [V*P] int   (internal copy when the caller passes none)
     size_t tiles;          // [V*P] u32   tiles_touched
@@ -112,7 +112,10 @@ extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
 extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
-extern int g_f3dg_render_kernel;       // 2 (default): render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+extern int g_f3dg_render_kernel;       // 3 (default): render3 (render2 + whole-round queues + repacking of live pixels); 4: render3 without
+                                       // repacking; 2: render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+extern int g_f3dg_render_occ;          // experiment: register budget of render2 (waves per SIMD: 6 or 5)
+extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per workgroup of the compositing launch (lowers occupancy)
 extern int g_f3dg_render_fast;         // 1 (default): float64 island of the blend replaced by error-free float32 pairs; 0: bit-exact path
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,

@@ -107,12 +107,11 @@ __device__ __forceinline__ CullConic cull_conic(const float* vg, float thr, floa
     q.ok = true;
     return q;
 }
-__device__ __forceinline__ float4 conservative_box(const float* vg, float thr, bool have_scale, int W, int H,
-                                                   float focal_x, float focal_y, float tan_fovx, float tan_fovy)
+__device__ __forceinline__ float4 conservative_box(const CullConic& q, float thr, bool have_scale, int W, int H,
+                                                   float focal_x, float focal_y)
 {
     const float4 all = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);
     if (!have_scale || !(thr < 3.0e38f)) return all;        // thr = +inf (alpha always < 1/255) is handled by the pre-test
-    const CullConic q = cull_conic(vg, thr, tan_fovx, tan_fovy);
     if (!q.ok) return all;
     const double m00 = q.m00, m01 = q.m01, m02 = q.m02, m11 = q.m11, m12 = q.m12, m22 = q.m22;
     const double D00 = m11 * m22 - m12 * m12, D11 = m00 * m22 - m02 * m02, D22 = m00 * m11 - m01 * m01;
@@ -132,48 +131,58 @@ __device__ __forceinline__ float4 conservative_box(const float* vg, float thr, b
 
 
 // Conservative ELLIPSE of the same region (the compositing kernel's phase 1 tests pixels against it; f3dg_render.hip).
-// The level set (C - k) a - b^2 <= 0 of conservative_box is an exact conic r^T M r <= 0 in ray space; with the centre
-// (cx, cy) of that conic and Qc < 0 its value there it reads  E(dx, dy) = a dx^2 + b dx dy + c dy^2 <= 1  in pixel offsets
-// from the centre. The record is that ellipse scaled UNIFORMLY about its centre by s = 1.001 + 0.05 px / semi-minor axis
-// (a point inside an ellipse stays inside any uniformly larger one), which covers the float32 rounding of the centre
-// (<= 2.5e-4 px for images up to 4096 px) and of the kernel's float32 evaluation of E (<= ~2e-4 relative for aspect ratios
-// up to 31; flatter ellipses keep only their box). The conic is cull_conic's, i.e. it carries the same worst-case bound on the
-// reference's own float32 rounding of a and b as conservative_box. out[0] = (cx, cy, a, b), out[1] = (c, hx, hy, 0): hx, hy are the half extents
-// of the ellipse's axis-aligned box (+1e-3 px), what the staging thread turns into the 4x4-block mask.
-//   "everything" (nothing can be proven): a = b = c = 0 (E = 0 passes everywhere), hx = hy = 3e38;
-//   "never" (alpha < 1/255 everywhere: opacity <= 0, or the level set is empty): hx = hy = -1e30 (in no block list).
-__device__ __forceinline__ void conservative_ellipse(const float* vg, float thr, bool have_scale, int W, int H,
-                                                     float focal_x, float focal_y, float tan_fovx, float tan_fovy, float4& e0, float4& e1)
+// The level set of cull_conic is an exact conic r^T M r <= 0 in ray space; with the centre (cx, cy) of that conic and Qc < 0
+// its value there it reads  E(dx, dy) = a dx^2 + b dx dy + c dy^2 <= 1  in pixel offsets from the centre. The record is that
+// ellipse scaled UNIFORMLY about its centre by s = 1.001 + 0.05 px / semi-minor axis (a point inside an ellipse stays inside
+// any uniformly larger one), which covers the float32 rounding of the centre (<= 2.5e-4 px for images up to 4096 px) and of
+// the kernel's float32 evaluation of E (<= ~2e-4 relative for aspect ratios up to 31). Flatter ellipses are fattened to that
+// aspect ratio along their minor axis (the larger eigenvalue of the form is lowered: a superset). Output: e = (cx, cy, a, b)
+// in pixel-index coordinates and c; the staging threads derive the ellipse's axis-aligned box from (a, b, c).
+//   "everything" (nothing can be proven): a = b = c = 0 (E = 0 passes everywhere, no box);
+//   "never" (alpha < 1/255 everywhere: opacity <= 0, or the level set is empty): a tiny ellipse far outside any image.
+__device__ __forceinline__ void conservative_ellipse(const CullConic& q, float thr, bool have_scale, int W, int H,
+                                                     float focal_x, float focal_y, float4& e, float& ec)
 {
-    e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    e1 = make_float4(0.0f, 3.0e38f, 3.0e38f, 0.0f);
-    if (thr == __builtin_inff()) { e1.y = e1.z = -1.0e30f; return; }       // opacity <= 0: alpha <= 0 always
-    if (!have_scale || !(thr < 3.0e38f)) return;
-    const CullConic q = cull_conic(vg, thr, tan_fovx, tan_fovy);
-    if (!q.ok) return;
+    e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    ec = 0.0f;
+    const float4 never = make_float4(-1.0e9f, -1.0e9f, 1.0e30f, 0.0f);
+    if (thr == __builtin_inff()) { e = never; ec = 1.0e30f; return; }       // opacity <= 0: alpha <= 0 always
+    if (!have_scale || !(thr < 3.0e38f) || !q.ok) return;
     const double m00 = q.m00, m01 = q.m01, m02 = q.m02, m11 = q.m11, m12 = q.m12, m22 = q.m22;
     const double D22 = m00 * m11 - m01 * m01;
     if (!(m00 > 0.0) || !(m11 > 0.0) || !(D22 > 1e-9 * fabs(m00 * m11))) return;
     const double cx = (m01 * m12 - m02 * m11) / D22, cy = (m01 * m02 - m00 * m12) / D22;
     const double Qc = m22 + m02 * cx + m12 * cy;            // value of the conic at its centre; the quadratic part is positive definite
     if (!(Qc == Qc) || !(cx == cx) || !(cy == cy)) return;
-    if (Qc > 0.0 && Qc < 1.0e300) { e1.y = e1.z = -1.0e30f; return; }      // empty level set: never visible
+    if (Qc > 0.0 && Qc < 1.0e300) { e = never; ec = 1.0e30f; return; }      // empty level set: never visible
     if (!(Qc < 0.0)) return;
-    const double a = m00 / (-Qc) / ((double)focal_x * focal_x), b = 2.0 * m01 / (-Qc) / ((double)focal_x * focal_y),
-                 c = m11 / (-Qc) / ((double)focal_y * focal_y);
+    double a = m00 / (-Qc) / ((double)focal_x * focal_x), b = 2.0 * m01 / (-Qc) / ((double)focal_x * focal_y),
+           c = m11 / (-Qc) / ((double)focal_y * focal_y);
     const double det = a * c - 0.25 * b * b, tr = a + c;
     if (!(det > 0.0) || !(tr < 1.0e300)) return;
-    const double lmax = 0.5 * tr + sqrt(fmax(0.25 * tr * tr - det, 0.0)), lmin = det / lmax;
-    const double s = 1.001 + 0.05 * sqrt(lmax);              // 0.05 px / semi-minor axis (= 1/sqrt(lmax))
-    const double hx = s * sqrt(c / det) + 1e-3, hy = s * sqrt(a / det) + 1e-3;
-    const double px = cx * focal_x + W / 2. - 0.5, py = cy * focal_y + H / 2. - 0.5;      // pixel-index coordinates
-    if (!(hx < 1.0e9) || !(hy < 1.0e9) || !(fabs(px) < 1.0e9) || !(fabs(py) < 1.0e9)) return;
-    e0.x = (float)px; e0.y = (float)py;
-    e1.y = (float)(hx * (1.0 + 1e-6)); e1.z = (float)(hy * (1.0 + 1e-6));
-    if (lmax <= 1000.0 * lmin && fabs(px) < 8192.0 && fabs(py) < 8192.0) {
-        const double is2 = 1.0 / (s * s);
-        e0.z = (float)(a * is2); e0.w = (float)(b * is2); e1.x = (float)(c * is2);
+    const double disc = sqrt(fmax(0.25 * tr * tr - det, 0.0));
+    double lmax = 0.5 * tr + disc;
+    const double lmin = det / lmax;
+    if (!(lmin > 0.0)) return;
+    if (lmax > 1000.0 * lmin) {
+        // [[a, b/2], [b/2, c]] - (lmax - 1000 lmin) v v^T, v = unit eigenvector of lmax
+        double vx = 0.5 * b, vy = lmax - a;
+        if (fabs(vx) + fabs(vy) < 1e-300 * lmax || a > c) { vx = lmax - c; vy = 0.5 * b; }
+        const double n2 = vx * vx + vy * vy;
+        if (!(n2 > 0.0)) return;
+        const double d = (lmax - 1000.0 * lmin) / n2;
+        a -= d * vx * vx; b -= 2.0 * d * vx * vy; c -= d * vy * vy;
+        lmax = 1000.0 * lmin;
+        if (!(a > 0.0) || !(c > 0.0) || !(a * c - 0.25 * b * b > 0.0)) return;
     }
+    const double s = 1.001 + 0.05 * sqrt(lmax);              // 0.05 px / semi-minor axis (= 1/sqrt(lmax))
+    const double px = cx * focal_x + W / 2. - 0.5, py = cy * focal_y + H / 2. - 0.5;      // pixel-index coordinates
+    if (!(fabs(px) < 8192.0) || !(fabs(py) < 8192.0)) return;
+    const double is2 = 1.0 / (s * s);
+    const float fa = (float)(a * is2), fb = (float)(b * is2), fc = (float)(c * is2);
+    if (!(fa > 1.0e-30f) || !(fc > 1.0e-30f) || !(fa < 1.0e30f) || !(fc < 1.0e30f)) return;
+    e = make_float4((float)px, (float)py, fa, fb);
+    ec = fc;
 }
 
 __global__ void __launch_bounds__(F3DG_BLOCK)
@@ -205,8 +214,10 @@ preprocess_kernel(int P, int D, int M,
     float2 xy = make_float2(0, 0);
     float4 con = make_float4(0, 0, 0, 0);
     float4 box = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);     // "everything" unless proven smaller
-    float4 ce0 = make_float4(0, 0, 0, 0), ce1 = make_float4(0, -1.0e30f, -1.0e30f, 0);   // culled Gaussians are in no list anyway
+    float4 ce = make_float4(-1.0e9f, -1.0e9f, 1.0e30f, 0.0f);      // "never": culled Gaussians are in no list anyway
+    float cec = 1.0e30f;
     unsigned char clamp_bits = 0;
+    float depth = 0.0f;
 
     const float px_ = means3D[3 * (size_t)g], py_ = means3D[3 * (size_t)g + 1], pz_ = means3D[3 * (size_t)g + 2];
 
@@ -411,11 +422,19 @@ preprocess_kernel(int P, int D, int M,
                 // rounding of power. opac <= 0 -> alpha <= 0 always (K = +inf); NaN opacity disables the test.
                 const float thr = debug_skip_all ? __builtin_inff() : opac > 0.0f ? logf(1.0f / (255.0f * opac)) - 1e-4f : (opac <= 0.0f ? __builtin_inff() : opac);
                 const float Kpre = pretest_constant(vg, thr);
-                if (bbox_out)
-                    box = conservative_box(vg, thr, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y, tan_fovx, tan_fovy);
-                conservative_ellipse(vg, thr, scales != nullptr && v2g_precomp == nullptr, W, H, focal_x, focal_y, tan_fovx, tan_fovy, ce0, ce1);
+                {
+                    const bool have_scale = scales != nullptr && v2g_precomp == nullptr;
+                    CullConic cq;
+                    cq.ok = false;
+                    if (have_scale && thr < 3.0e38f)
+                        cq = cull_conic(vg, thr, tan_fovx, tan_fovy);
+                    if (bbox_out)
+                        box = conservative_box(cq, thr, have_scale, W, H, focal_x, focal_y);
+                    conservative_ellipse(cq, thr, have_scale, W, H, focal_x, focal_y, ce, cec);
+                }
                 r2 = make_float4(vg[8], vg[9], opac, Kpre);
-                r3 = make_float4(cr, cg, cb, pvz);
+                r3 = make_float4(cr, cg, cb, 0.0f);
+                depth = pvz;
             }
         }
     }
@@ -423,10 +442,10 @@ preprocess_kernel(int P, int D, int M,
     radii[idx] = my_radii;
     tiles_touched[idx] = my_tiles;
     means2D[idx] = xy;
-    depths_out[idx] = r3.w;
+    depths_out[idx] = depth;
     if (bbox_out) bbox_out[idx] = box;
-    cull_out[2 * idx] = ce0;
-    cull_out[2 * idx + 1] = ce1;
+    cull_out[idx] = ce;
+    r3.w = cec;                             // record slot 15: the ellipse's c (the depth lives in depths_out)
     float4* dst = reinterpret_cast<float4*>(rec + idx);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
     if (save_aux) {

@@ -236,13 +236,18 @@ int f3dg_profile_collect(double* h_stage_ms, int* h_calls);
 /* Test/inspection hook: device-to-device copies of the library's internal per-call state into caller buffers
  * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the
  * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
- *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], depth), means2D [V*P*2], conic [V*P*4] (SAVE_AUX),
+ *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], culling-ellipse c), depths [V*P], means2D [V*P*2], conic [V*P*4] (SAVE_AUX),
  *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped; SAVE_AUX), keys_sorted [cap] u64 (SAVE_AUX),
  *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX). */
 int f3dg_debug_export(void* stream, const void* workspace, int P, int W, int H, int n_views,
                       long long max_rendered, float* rec, float* means2D, float* conic, unsigned* tiles,
                       unsigned* offsets, unsigned char* clamped, unsigned long long* keys_sorted,
-                      unsigned* point_list, unsigned* ranges, float* final_T, unsigned* n_contrib);
+                      unsigned* point_list, unsigned* ranges, float* final_T, unsigned* n_contrib, float* depths);
+
+/* Inspection hook of the compositing kernel: shader-clock cycles per wave, summed over all waves of all launches since the
+ * last reset, h_out8 = {barrier waits, staging, list build, phase 1, phase 2, repack, total, waves}. Only a library built
+ * with -DF3DG_TIMING (tools/render_timing.sh) counts; the product build returns zeros. BLOCKING (device-to-host copy). */
+int f3dg_debug_timing(unsigned long long* h_out8, int reset);
 
 #ifdef __cplusplus
 }

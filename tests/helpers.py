@@ -79,18 +79,19 @@ def run_hip(scene, device, save_aux=True, max_rendered=None):
         point_list=torch.zeros(max(cap, 1), dtype=torch.int32, device=device),
         ranges=torch.zeros(V * T * 2, dtype=torch.int32, device=device),
         final_T=torch.zeros(V * 4 * H * W, dtype=torch.float32, device=device),
-        n_contrib=torch.zeros(V * 2 * H * W, dtype=torch.int32, device=device))
+        n_contrib=torch.zeros(V * 2 * H * W, dtype=torch.int32, device=device),
+        depths=torch.zeros(V * max(P, 1), dtype=torch.float32, device=device))
     if P > 0:
         rc = _lib.lib().f3dg_debug_export(
             C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), P, W, H, V, cap,
             *[C.c_void_p(e[k].data_ptr()) for k in ("rec", "means2D", "conic", "tiles", "offsets", "clamped", "keys",
-                                                     "point_list", "ranges", "final_T", "n_contrib")])
+                                                     "point_list", "ranges", "final_T", "n_contrib", "depths")])
         assert rc == 0
     torch.cuda.synchronize()
     rec = e["rec"].cpu().numpy().reshape(V, max(P, 1), 16)
     res = dict(
         out_color=out.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R,
-        view2gaussian=rec[:, :, 0:10], opac=rec[:, :, 10], rgb=rec[:, :, 12:15], depths=rec[:, :, 15],
+        view2gaussian=rec[:, :, 0:10], opac=rec[:, :, 10], rgb=rec[:, :, 12:15], depths=e["depths"].cpu().numpy().reshape(V, max(P, 1)),
         means2D=e["means2D"].cpu().numpy().reshape(V, max(P, 1), 2),
         conic_opacity=e["conic"].cpu().numpy().reshape(V, max(P, 1), 4),
         tiles_touched=e["tiles"].cpu().numpy().view(np.uint32).reshape(V, max(P, 1)),

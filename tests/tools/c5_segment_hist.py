@@ -16,7 +16,7 @@ T = (RES // 16) ** 2
 ranges = torch.empty((V * T, 2), dtype=torch.int32, device=dev)
 L = _lib.lib()
 L.f3dg_debug_export(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), P, RES, RES, V, ws.max_rendered,
-                    None, None, None, None, None, None, None, None, C.c_void_p(ranges.data_ptr()), None, None)
+                    None, None, None, None, None, None, None, None, C.c_void_p(ranges.data_ptr()), None, None, None)
 torch.cuda.synchronize()
 r = ranges.cpu().numpy().astype(np.int64); n = r[:, 1] - r[:, 0]
 print("instances", ws.num_rendered, "segments", len(n), "mean", n.mean(), "max", n.max(), "pct>4032", (n > 4032).mean(), "pct>8192", (n > 8192).mean(), "pct>16384", (n > 16384).mean())

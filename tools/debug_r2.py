@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 sc = make_scene(P=2000, res=(64, 64), s0=0.05, view="canonical")
 L.f3dg_set_option(b"render_fast", 0)
 L.f3dg_set_option(b"render_kernel", 1); a = run_hip(sc, dev)
-L.f3dg_set_option(b"render_kernel", 2); b = run_hip(sc, dev)
+L.f3dg_set_option(b"render_kernel", int(sys.argv[1]) if len(sys.argv) > 1 else 3); b = run_hip(sc, dev)
 d = np.abs(a["out_color"][0] - b["out_color"][0]).max(0)
 bad = d > 0
 print("pixels differing", bad.sum(), "of", bad.size)
