@@ -75,10 +75,6 @@ def main():
     _lib.check(L.f3dg_set_option(b"render_fast", 1 if args.render_mode == "fast" else 0), "f3dg_set_option")
     if os.environ.get("F3DG_DEBUG_SKIP_ALL"):    # experiment: no Gaussian ever passes -> the compositing kernel only stages
         _lib.check(L.f3dg_set_option(b"debug_skip_all", 1), "f3dg_set_option")
-    if os.environ.get("F3DG_RENDER_OCC"):
-        _lib.check(L.f3dg_set_option(b"render_occ", int(os.environ["F3DG_RENDER_OCC"])), "f3dg_set_option")
-    if os.environ.get("F3DG_RENDER_LDS_PAD"):    # experiment: occupancy sensitivity of the compositing kernel
-        _lib.check(L.f3dg_set_option(b"render_lds_pad", int(os.environ["F3DG_RENDER_LDS_PAD"])), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
 

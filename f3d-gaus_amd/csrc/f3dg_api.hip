@@ -64,9 +64,7 @@ int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
-int g_f3dg_render_kernel = 3;
-int g_f3dg_render_lds_pad = 0;
-int g_f3dg_render_occ = 6;
+int g_f3dg_render_kernel = 2;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
@@ -74,9 +72,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
 {
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = (value >= 1 && value <= 4) ? value : 3; return F3DG_OK; }
-    if (name && strcmp(name, "render_occ") == 0) { g_f3dg_render_occ = value == 5 ? 5 : 6; return F3DG_OK; }
-    if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value > 0 ? value : 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : 2; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }

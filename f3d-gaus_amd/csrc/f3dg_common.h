@@ -112,10 +112,7 @@ extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
 extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
-extern int g_f3dg_render_kernel;       // 3 (default): render3 (render2 + whole-round queues + repacking of live pixels); 4: render3 without
-                                       // repacking; 2: render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
-extern int g_f3dg_render_occ;          // experiment: register budget of render2 (waves per SIMD: 6 or 5)
-extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per workgroup of the compositing launch (lowers occupancy)
+extern int g_f3dg_render_kernel;       // 2 (default): render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
 extern int g_f3dg_render_fast;         // 1 (default): float64 island of the blend replaced by error-free float32 pairs; 0: bit-exact path
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,

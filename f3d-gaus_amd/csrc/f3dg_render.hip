@@ -468,7 +468,7 @@ __device__ __forceinline__ unsigned ellipse_block_mask(float4 e, float c, float 
 
 // ---- optional phase timing (build with -DF3DG_TIMING: tools/render_timing.py). Shader-clock cycles per wave, summed over all
 // waves of all launches since the last reset: [0] barrier waits, [1] staging, [2] list build, [3] phase 1, [4] phase 2,
-// [5] repack, [6] total, [7] waves.
+// [5] unused, [6] total, [7] waves.
 __device__ unsigned long long g_f3dg_timing[8];
 #ifdef F3DG_TIMING
 #define F3DG_T_DECL unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_amdgcn_s_memtime(); const unsigned long long t_begin = t_last;
@@ -514,8 +514,8 @@ __device__ __forceinline__ void ellipse_ballots(int& stage, float Ep, const floa
     }
 }
 
-template <bool SAVE_AUX, bool FAST, int OCC>
-__global__ void __launch_bounds__(F3DG_BLOCK, OCC)
+template <bool SAVE_AUX, bool FAST>
+__global__ void __launch_bounds__(F3DG_BLOCK, 6)
 render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
@@ -666,53 +666,19 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             F3DG_T_MARK(3);
             unsigned long long pass = done ? 0ull : ((unsigned long long)pass_hi << 32) | pass_lo;
 
-            // ---- phase 2: this pixel's own passing entries, in list order, through the reference's arithmetic. The loop is
-            // software-pipelined two deep: while entry k is blended, the record of entry k + 1 is on its way from LDS and the
-            // list byte of entry k + 2 is being looked up, so that neither LDS latency sits on the per-entry dependency chain
-            // (the kernel is bound by that chain, not by VALU issue: tools/r02_* occupancy sweeps in DESIGN.md).
-            {
-                auto next_slot = [&](bool& have) -> int {          // pops the lowest set bit of `pass`; slot 0 when none is left
-                    have = pass != 0 && !done;
-                    const int kk = have ? __builtin_ctzll(pass) : 0;
-                    pass &= pass - 1;
-                    return (int)my_list[w0 + kk];
-                };
-                bool haveA, haveB, haveC;
-                int jA = next_slot(haveA);
-                float4 a0 = sA[jA], a1 = sB[jA], a2 = sC[jA];
-                float2 a3 = sD[jA];
-                int jB = next_slot(haveB);
-                while (haveA) {
-                    // entry A is in registers; fetch B, look up C
-                    const float4 b0 = sA[jB], b1 = sB[jB], b2 = sC[jB];
-                    const float2 b3 = sD[jB];
-                    const int jC = next_slot(haveC);
-                    {
-                        const float n0 = a0.x * ray_x + a0.y * ray_y + a0.z;
-                        const float n1 = a0.y * ray_x + a0.w * ray_y + a1.x;
-                        const float n2 = a0.z * ray_x + a1.x * ray_y + a1.y;
-                        const float aaf = ray_x * n0 + ray_y * n1 + n2;
-                        const float bhalf = a1.z * ray_x + a1.w * ray_y + a2.x;
-                        done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)jA + 1u, n0, n1, n2, aaf, bhalf, a2.y, a2.z, a2.w, a3.x, a3.y);
-                    }
-                    haveB = haveB && !done;
-                    if (!haveB)
-                        break;
-                    // entry B is in registers; fetch C, look up D
-                    a0 = sA[jC]; a1 = sB[jC]; a2 = sC[jC]; a3 = sD[jC];
-                    bool haveD;
-                    const int jD = next_slot(haveD);
-                    {
-                        const float n0 = b0.x * ray_x + b0.y * ray_y + b0.z;
-                        const float n1 = b0.y * ray_x + b0.w * ray_y + b1.x;
-                        const float n2 = b0.z * ray_x + b1.x * ray_y + b1.y;
-                        const float aaf = ray_x * n0 + ray_y * n1 + n2;
-                        const float bhalf = b1.z * ray_x + b1.w * ray_y + b2.x;
-                        done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)jB + 1u, n0, n1, n2, aaf, bhalf, b2.y, b2.z, b2.w, b3.x, b3.y);
-                    }
-                    jA = jC; haveA = haveC && !done;
-                    jB = jD; haveB = haveD;
-                }
+            // ---- phase 2: this pixel's own passing entries, in list order, through the reference's arithmetic
+            while (pass != 0 && !done) {
+                const int kk = __builtin_ctzll(pass);
+                pass &= pass - 1;
+                const int j = (int)my_list[w0 + kk];
+                const float4 q0 = sA[j], q1 = sB[j], q2 = sC[j];
+                const float2 q3 = sD[j];
+                const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+                const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+                const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+                const float aaf = ray_x * n0 + ray_y * n1 + n2;
+                const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+                done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q2.w, q3.x, q3.y);
             }
             F3DG_T_MARK(4);
         }
@@ -748,328 +714,6 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     }
 }
 
-// =====================================================================================================================
-// render3 = render2 + whole-round work queues in LDS + repacking of the live pixels.
-//
-// After render2 the per-pixel blend (phase 2) is ~80 % of the instructions and runs with ~47 % of the lanes busy: a wave pays, per
-// 64-entry window, the largest number of passing entries over its 64 pixels, and a third of the lanes belong to pixels that are
-// already saturated. Two changes (tests/tools/compaction_model.py measures both on the C2 workload):
-//  * phase 1 runs for the whole round (<= 256 staged entries) at once and leaves every pixel's pass bits in LDS (pm: 8 words per
-//    pixel and round); phase 2 is ONE loop per round in which every lane walks its own words, so the wave pays the largest count
-//    over a round instead of the sum of the largest counts of four windows (-16 % trips);
-//  * pixel ownership is dynamic. Whenever the number of unfinished pixels of the tile fits in fewer waves than are active, the
-//    finished pixels are written out, and the live ones (state = 14 registers + pixel id) are packed into the first ceil(A/64)
-//    waves through LDS (the staging arrays are dead between rounds). Phase 1 does not care who owns a pixel: wave w always
-//    evaluates the lists of the four 4x4 blocks of quadrant w and delivers the bits to pm[pixel]; a repacked lane finds its
-//    block's list and its own words by pixel id. Waves without pixels only stage, build lists and run phase 1.
-// Per pixel the sequence of blended Gaussians and all arithmetic on them are unchanged: bit-identical outputs.
-template <bool SAVE_AUX, bool FAST>
-__global__ void __launch_bounds__(F3DG_BLOCK, 4)
-render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
-                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
-                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
-                   const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
-                   float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib, int repack)
-{
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned slot = blockIdx.x >> 3;
-    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
-    const unsigned tile = slot % (unsigned)T;
-    if (view >= (unsigned)V)
-        return;
-
-    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned grp = lane >> 4, gi = lane & 15u;
-    const size_t HW = (size_t)H * W;
-
-    // phase-1 role of this lane (fixed): entries of the list of block 4 * wave + grp, block = 4x4 pixels
-    const unsigned blk1 = wave * 4u + grp;
-    const float blk_px0 = (float)(tile_x * F3DG_TILE + ((wave & 1u) * 2u + (grp & 1u)) * 4u);
-    const float blk_py0 = (float)(tile_y * F3DG_TILE + ((wave >> 1) * 2u + (grp >> 1)) * 4u);
-
-    // pixel owned by this lane (dynamic): pid = 16 * block + pixel-in-block, block = 4 * quadrant + group as above
-    unsigned pid = threadIdx.x;
-    unsigned pix_x, pix_y;
-    float ray_x, ray_y;
-    auto set_pixel = [&](unsigned id) {
-        const unsigned b = id >> 4, q = b >> 2, g = b & 3u, pp = id & 15u;
-        pix_x = tile_x * F3DG_TILE + ((q & 1u) * 2u + (g & 1u)) * 4u + (pp & 3u);
-        pix_y = tile_y * F3DG_TILE + ((q >> 1) * 2u + (g >> 1)) * 4u + (pp >> 2);
-        const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
-        ray_x = (float)((pixf_x - W / 2.) / focal_x);
-        ray_y = (float)((pixf_y - H / 2.) / focal_y);
-    };
-    set_pixel(pid);
-    bool owner = pix_x < (unsigned)W && pix_y < (unsigned)H;       // holds a pixel whose outputs are still to be written
-    bool done = !owner;
-
-    uint2 range = ranges[(size_t)view * T + tile];
-    if (hdr->overflow) range = make_uint2(0, 0);
-    const int rounds = (int)((range.y - range.x + F3DG_BLOCK - 1) / F3DG_BLOCK);
-
-    // LDS: four float4 staging arrays in one 16 KB block, which is also the exchange buffer of a repack (256 x 15 dwords)
-    __shared__ __align__(16) float4 stg[5 * F3DG_BLOCK];
-    float4* const sA = stg;                                    // v0 v1 v2 v3         } the record as it lies in memory: the
-    float4* const sB = stg + F3DG_BLOCK;                       // v4 v5 v6 v7         } prefetched registers are stored as they
-    float4* const sC = stg + 2 * F3DG_BLOCK;                   // v8 v9 opacity K     } are (any re-packing would make the compiler
-    float4* const sD = stg + 3 * F3DG_BLOCK;                   // r g b, ellipse c    } wait for the loads where they are issued)
-    float4* const sE = stg + 4 * F3DG_BLOCK;                   // ellipse: cx cy a b
-    __shared__ unsigned short sM[F3DG_BLOCK];                  // which of the tile's 16 4x4 blocks the ellipse's box touches
-    __shared__ __align__(16) unsigned char lists[16][F3DG_BLOCK];      // per 4x4 block: staged slots whose box touches it
-    __shared__ __align__(16) unsigned pm[F3DG_BLOCK][8];       // per pixel: pass bits of the round, by list position
-    __shared__ int lens[16];
-    __shared__ int wave_cnt[2][4];
-    __shared__ unsigned blk_alive[2];
-    if (threadIdx.x < 2) blk_alive[threadIdx.x] = 0;
-    __syncthreads();
-
-    const F3dgRec* vrec = rec + (size_t)view * P;
-    const float4* vcull = cull + (size_t)view * P;
-    const float tile_px0 = (float)(tile_x * F3DG_TILE), tile_py0 = (float)(tile_y * F3DG_TILE);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned pull = (gi + 16u * (grp >> 1)) * 4u;       // ds_bpermute source of this pixel's ballot half
-    const unsigned pull_shift = 16u * (grp & 1u);
-    unsigned short* pm16 = reinterpret_cast<unsigned short*>(&pm[0][0]) + (size_t)(blk1 * 16u + gi) * 16u;
-
-    PixelState st;
-    st.Tr = 1.0f;
-    st.last_contributor = 0; st.max_contributor = (unsigned)-1;
-    st.C0 = st.C1 = st.C2 = st.C3 = st.C4 = st.C5 = st.C6 = st.C7 = 0;
-    st.dist1 = st.dist2 = st.distortion = 0;
-
-    auto write_out = [&]() {
-        const size_t pix_id = (size_t)W * pix_y + pix_x;
-        const float* bg = background + (bg_per_view ? 3 * view : 0);
-        const float Tr = st.Tr;
-        const float distortion_before_normalized = st.distortion;
-        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
-        if (SAVE_AUX) {
-            float* fT = final_T + (size_t)view * 4 * HW;
-            fT[pix_id] = Tr;
-            fT[pix_id + HW] = st.dist1;
-            fT[pix_id + 2 * HW] = st.dist2;
-            fT[pix_id + 3 * HW] = distortion_before_normalized;
-            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
-            nc[pix_id] = st.last_contributor;
-            nc[pix_id + HW] = st.max_contributor;
-        }
-        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
-        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
-        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
-        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
-        out[3 * HW + pix_id] = st.C3;
-        out[4 * HW + pix_id] = st.C4;
-        out[5 * HW + pix_id] = st.C5;
-        out[6 * HW + pix_id] = st.C6;
-        out[7 * HW + pix_id] = st.C7;
-        out[8 * HW + pix_id] = distortion;
-    };
-
-    // software prefetch: the 80 bytes of list entry (round, thread) travel in registers while the previous round computes
-    typedef float v4f __attribute__((ext_vector_type(4)));     // plain SSA vectors: HIP's float4 (a struct) was left in memory
-    v4f pf_a = {0, 0, 0, 0}, pf_b = pf_a, pf_c = pf_a, pf_d = pf_a, pf_e = pf_a;
-    bool pf_valid = false;
-    unsigned pf_id = 0;                                  // entry id of the round AFTER the one in pf_*: one more round ahead
-    auto fetch = [&](int round) {                        // pf_* <- records of `round` (its id is in pf_id), pf_id <- id of round + 1
-        const unsigned progress = (unsigned)round * F3DG_BLOCK + threadIdx.x;
-        const unsigned cur = pf_id;
-        if (range.x + progress + F3DG_BLOCK < range.y)   // issued first: nothing may follow the record loads that needs a register
-            pf_id = point_list[range.x + progress + F3DG_BLOCK];
-        pf_valid = range.x + progress < range.y;
-        if (pf_valid) {
-            const v4f* src = reinterpret_cast<const v4f*>(vrec + cur);
-            const v4f* cul = reinterpret_cast<const v4f*>(vcull + cur);
-            pf_e = cul[0];
-            pf_a = src[0]; pf_b = src[1]; pf_c = src[2]; pf_d = src[3];
-        }
-    };
-    if (range.x + threadIdx.x < range.y)
-        pf_id = point_list[range.x + threadIdx.x];
-    fetch(0);
-
-    int active_waves = F3DG_BLOCK / 64;
-    F3DG_T_DECL
-    for (int i = 0; i < rounds; i++) {
-        const unsigned long long alive = __ballot(!done);
-        if (lane == 0)
-            wave_cnt[i & 1][wave] = __popcll(alive);
-        if (!done)
-            atomicOr(&blk_alive[i & 1], 1u << (pid >> 4));
-        __syncthreads();
-        F3DG_T_MARK(0);
-        const int a0 = wave_cnt[i & 1][0], a1 = wave_cnt[i & 1][1], a2 = wave_cnt[i & 1][2], a3 = wave_cnt[i & 1][3];
-        const int num_alive = a0 + a1 + a2 + a3;
-        const unsigned alive_blocks = blk_alive[i & 1];
-        if (threadIdx.x == 0)
-            blk_alive[(i + 1) & 1] = 0;           // next written to at the top of round i + 1, two barriers from here
-        if (num_alive == 0)
-            break;
-
-        const int need = (num_alive + 63) >> 6;
-        if (repack && need < active_waves) {
-            // ---- repack: finished pixels leave, live ones move to threads 0 .. num_alive - 1 (order kept)
-            if (owner && done)
-                write_out();
-            unsigned* xb = reinterpret_cast<unsigned*>(&stg[0]);         // [15][256] dwords
-            const int rank = (wave > 0 ? a0 : 0) + (wave > 1 ? a1 : 0) + (wave > 2 ? a2 : 0) + __popcll(alive & lt);
-            if (!done) {
-                xb[0 * F3DG_BLOCK + rank] = pid;
-                xb[1 * F3DG_BLOCK + rank] = __float_as_uint(st.Tr);
-                xb[2 * F3DG_BLOCK + rank] = st.last_contributor;
-                xb[3 * F3DG_BLOCK + rank] = st.max_contributor;
-                xb[4 * F3DG_BLOCK + rank] = __float_as_uint(st.C0);
-                xb[5 * F3DG_BLOCK + rank] = __float_as_uint(st.C1);
-                xb[6 * F3DG_BLOCK + rank] = __float_as_uint(st.C2);
-                xb[7 * F3DG_BLOCK + rank] = __float_as_uint(st.C3);
-                xb[8 * F3DG_BLOCK + rank] = __float_as_uint(st.C4);
-                xb[9 * F3DG_BLOCK + rank] = __float_as_uint(st.C5);
-                xb[10 * F3DG_BLOCK + rank] = __float_as_uint(st.C6);
-                xb[11 * F3DG_BLOCK + rank] = __float_as_uint(st.C7);
-                xb[12 * F3DG_BLOCK + rank] = __float_as_uint(st.dist1);
-                xb[13 * F3DG_BLOCK + rank] = __float_as_uint(st.dist2);
-                xb[14 * F3DG_BLOCK + rank] = __float_as_uint(st.distortion);
-            }
-            __syncthreads();
-            owner = (int)threadIdx.x < num_alive;
-            done = !owner;
-            if (owner) {
-                const unsigned t = threadIdx.x;
-                pid = xb[0 * F3DG_BLOCK + t];
-                st.Tr = __uint_as_float(xb[1 * F3DG_BLOCK + t]);
-                st.last_contributor = xb[2 * F3DG_BLOCK + t];
-                st.max_contributor = xb[3 * F3DG_BLOCK + t];
-                st.C0 = __uint_as_float(xb[4 * F3DG_BLOCK + t]);
-                st.C1 = __uint_as_float(xb[5 * F3DG_BLOCK + t]);
-                st.C2 = __uint_as_float(xb[6 * F3DG_BLOCK + t]);
-                st.C3 = __uint_as_float(xb[7 * F3DG_BLOCK + t]);
-                st.C4 = __uint_as_float(xb[8 * F3DG_BLOCK + t]);
-                st.C5 = __uint_as_float(xb[9 * F3DG_BLOCK + t]);
-                st.C6 = __uint_as_float(xb[10 * F3DG_BLOCK + t]);
-                st.C7 = __uint_as_float(xb[11 * F3DG_BLOCK + t]);
-                st.dist1 = __uint_as_float(xb[12 * F3DG_BLOCK + t]);
-                st.dist2 = __uint_as_float(xb[13 * F3DG_BLOCK + t]);
-                st.distortion = __uint_as_float(xb[14 * F3DG_BLOCK + t]);
-                set_pixel(pid);
-            }
-            active_waves = need;
-            __syncthreads();                       // the exchange buffer is the staging area
-            F3DG_T_MARK(5);
-        }
-
-        // the round's records were fetched during the previous round (registers pf*): publish them, then start the next fetch
-        unsigned short m16 = 0;
-        if (pf_valid) {
-            reinterpret_cast<v4f*>(sA)[threadIdx.x] = pf_a;
-            reinterpret_cast<v4f*>(sB)[threadIdx.x] = pf_b;
-            reinterpret_cast<v4f*>(sC)[threadIdx.x] = pf_c;
-            reinterpret_cast<v4f*>(sD)[threadIdx.x] = pf_d;
-            reinterpret_cast<v4f*>(sE)[threadIdx.x] = pf_e;
-            m16 = (unsigned short)ellipse_block_mask(make_float4(pf_e[0], pf_e[1], pf_e[2], pf_e[3]), pf_d[3], tile_px0, tile_py0);
-        }
-        sM[threadIdx.x] = m16;
-        fetch(i + 1);
-        F3DG_T_MARK(1);
-        __syncthreads();
-        F3DG_T_MARK(0);
-
-        // lists of the four blocks of quadrant `wave`, in list order; blocks without a live pixel get none
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        {
-            const unsigned qx2 = (wave & 1u) * 2u, qy2 = (wave >> 1) * 2u;
-            const unsigned ab = alive_blocks >> (wave * 4u);
-            const bool g0 = ab & 1u, g1 = ab & 2u, g2 = ab & 4u, g3 = ab & 8u;
-#pragma unroll
-            for (int c = 0; c < F3DG_BLOCK / 64; c++) {
-                const unsigned e = c * 64 + lane;
-                const unsigned m = sM[e];
-                const bool b0 = g0 && ((m >> ((qy2 + 0u) * 4u + qx2 + 0u)) & 1u), b1 = g1 && ((m >> ((qy2 + 0u) * 4u + qx2 + 1u)) & 1u);
-                const bool b2 = g2 && ((m >> ((qy2 + 1u) * 4u + qx2 + 0u)) & 1u), b3 = g3 && ((m >> ((qy2 + 1u) * 4u + qx2 + 1u)) & 1u);
-                const unsigned long long l0 = __ballot(b0), l1 = __ballot(b1), l2 = __ballot(b2), l3 = __ballot(b3);
-                if (b0) lists[wave * 4 + 0][c0 + __popcll(l0 & lt)] = (unsigned char)e;
-                if (b1) lists[wave * 4 + 1][c1 + __popcll(l1 & lt)] = (unsigned char)e;
-                if (b2) lists[wave * 4 + 2][c2 + __popcll(l2 & lt)] = (unsigned char)e;
-                if (b3) lists[wave * 4 + 3][c3 + __popcll(l3 & lt)] = (unsigned char)e;
-                c0 += __popcll(l0); c1 += __popcll(l1); c2 += __popcll(l2); c3 += __popcll(l3);
-            }
-            if (lane < 4)
-                lens[wave * 4 + lane] = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-
-        F3DG_T_MARK(2);
-        // ---- phase 1, whole round: lane (g, e) tests entry 16 sub + e of block g's list against the 16 pixels of the block
-        {
-            const int count = max(max(c0, c1), max(c2, c3));
-            const int my_len = grp == 0 ? c0 : grp == 1 ? c1 : grp == 2 ? c2 : c3;
-            const unsigned char* list1 = lists[blk1];
-            const int nsub = ((count + 31) >> 5) << 1;           // whole 32-bit words
-#pragma unroll 1
-            for (int sub = 0; sub < nsub; sub++) {
-                const int pos = 16 * sub + (int)gi;
-                const int j = (int)list1[pos & (F3DG_BLOCK - 1)];
-                const float4 e = sE[j];
-                const float cc = sD[j].w;
-                const float u0 = pos < my_len ? blk_px0 - e.x : __builtin_nanf("");     // NaN: every comparison below is false
-                const float v0 = blk_py0 - e.y;
-                float dxx[4], adx[4], dyy[4], cdy[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    dxx[q] = u0 + (float)q;
-                    adx[q] = e.z * dxx[q];
-                    dyy[q] = v0 + (float)q;
-                    cdy[q] = cc * dyy[q] * dyy[q];
-                }
-                int stage = 0;
-                ellipse_ballots<0>(stage, fmaf(dxx[0], fmaf(e.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e.w);
-                const unsigned piece = ((unsigned)__builtin_amdgcn_ds_bpermute((int)pull, stage) >> pull_shift) & 0xFFFFu;
-                pm16[sub] = (unsigned short)piece;
-            }
-        }
-        F3DG_T_MARK(3);
-        __syncthreads();
-        F3DG_T_MARK(0);
-
-        // ---- phase 2, whole round: this lane's pixel walks its own pass bits in list order through the reference's arithmetic
-        if (!done) {
-            const unsigned blk = pid >> 4;
-            const unsigned char* my_list = lists[blk];
-            const unsigned* my_pm = pm[pid];
-            const int nw = (lens[blk] + 31) >> 5;
-            const unsigned round_base = (unsigned)i * F3DG_BLOCK;
-            int wi = 0;
-            unsigned cur = nw > 0 ? my_pm[0] : 0u;
-            for (;;) {
-                while (cur == 0 && wi + 1 < nw) {
-                    wi++;
-                    cur = my_pm[wi];
-                }
-                if (cur == 0)
-                    break;
-                const int kk = __builtin_ctz(cur);
-                cur &= cur - 1;
-                const int j = (int)my_list[32 * wi + kk];
-                const float4 q0 = sA[j], q1 = sB[j], q2 = sC[j], q3 = sD[j];
-                const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
-                const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
-                const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
-                const float aaf = ray_x * n0 + ray_y * n1 + n2;
-                const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-                done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
-                if (done)
-                    break;
-            }
-        }
-        F3DG_T_MARK(4);
-    }
-    F3DG_T_FLUSH;
-
-    if (owner)
-        write_out();
-}
-
 } // namespace
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
@@ -1081,21 +725,8 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     const int T = tiles_x * tiles_y;
     const unsigned groups = (unsigned)((V + 7) / 8);
     dim3 grid(groups * 8u * (unsigned)T);
-    if (g_f3dg_render_kernel >= 3) {
-#define F3DG_LAUNCH3(AUX, FST) hipLaunchKernelGGL((render3_fwd_kernel<AUX, FST>), grid, dim3(F3DG_BLOCK), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
-                                                  focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \
-                                                  out_color, final_T, n_contrib, g_f3dg_render_kernel == 3 ? 1 : 0)
-        if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3(true, true); else F3DG_LAUNCH3(true, false); }
-        else { if (g_f3dg_render_fast) F3DG_LAUNCH3(false, true); else F3DG_LAUNCH3(false, false); }
-#undef F3DG_LAUNCH3
-        F3DG_HIP_CHECK(hipGetLastError());
-        return F3DG_OK;
-    }
     if (g_f3dg_render_kernel == 2) {
-#define F3DG_LAUNCH2(AUX, FST) if (g_f3dg_render_occ == 5) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST, 5>), grid, dim3(F3DG_BLOCK), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
-                                                  focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \
-                                                  out_color, final_T, n_contrib); else \
-                               hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST, 6>), grid, dim3(F3DG_BLOCK), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
+#define F3DG_LAUNCH2(AUX, FST) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \
                                                   out_color, final_T, n_contrib)
         if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH2(true, true); else F3DG_LAUNCH2(true, false); }

@@ -186,11 +186,10 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
         for pre, cull, que in ((1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)):
             L.f3dg_set_option(b"render_pretest", pre); L.f3dg_set_option(b"render_cull", cull); L.f3dg_set_option(b"render_queue", que)
             variants.append(run_hip(scene, gpu_device))
-        for kern in (2, 3, 4):      # render2: Gaussians across the lanes + conservative ellipse in phase 1; render3 (default):
-            L.f3dg_set_option(b"render_kernel", kern)     # + whole-round queues + repacking of live pixels; 4: without repacking
-            variants.append(run_hip(scene, gpu_device))
+        L.f3dg_set_option(b"render_kernel", 2)      # render2 (default): Gaussians across the lanes + conservative ellipse in phase 1
+        variants.append(run_hip(scene, gpu_device))
     finally:
-        L.f3dg_set_option(b"render_kernel", 3)
+        L.f3dg_set_option(b"render_kernel", 2)
         for o in (b"render_pretest", b"render_cull", b"render_queue"):
             L.f3dg_set_option(o, 1)
     for b in variants:

@@ -16,8 +16,8 @@ cams = synthetic.orbit_cameras(V, resolution=RES, device=dev)
 shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
 bg = torch.zeros(3, device=dev)
 ws = None
-names = ["barrier", "staging", "lists", "phase1", "phase2", "repack", "total", "waves"]
-for kern in [int(a) for a in sys.argv[1:]] or [2, 4, 3]:
+names = ["barrier", "staging", "lists", "phase1", "phase2", "unused", "total", "waves"]
+for kern in [int(a) for a in sys.argv[1:]] or [2]:
     L.f3dg_set_option(b"render_kernel", kern)
     for rep in range(2):
         out, radii, ws = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg,
