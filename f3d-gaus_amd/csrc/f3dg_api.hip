@@ -73,7 +73,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : 2; return F3DG_OK; }
-    if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }

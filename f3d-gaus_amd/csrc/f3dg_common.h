@@ -113,7 +113,8 @@ extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the 
 extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
 extern int g_f3dg_render_kernel;       // 2 (default): render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
-extern int g_f3dg_render_fast;         // 1 (default): float64 island of the blend replaced by error-free float32 pairs; 0: bit-exact path
+extern int g_f3dg_render_fast;         // 1 (default): float64 island of the blend replaced by error-free float32 pairs in inference
+                                       // calls (no SAVE_AUX); 2: also with SAVE_AUX (tests); 0: the reference's float32/float64 order always
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 P, RES, V = 196608, 256, 8
 
 
-def _render(scene, device, colors=None, bg=None, views=None, save_aux=False):
+def _render(scene, device, colors=None, bg=None, views=None, save_aux=True):      # SAVE_AUX: same arithmetic mode as run_hip
     dev = lambda t: None if t is None else t.to(device)
     sl = slice(None) if views is None else views
     out, radii, ws = f3d.rasterize_views(

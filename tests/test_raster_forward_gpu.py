@@ -19,7 +19,7 @@ def render_mode(request):
     the same tolerances."""
     from f3dgaus_amd import _lib
     L = _lib.lib()
-    assert L.f3dg_set_option(b"render_fast", 1 if request.param == "fast" else 0) == 0
+    assert L.f3dg_set_option(b"render_fast", 2 if request.param == "fast" else 0) == 0      # 2: fast also in SAVE_AUX calls
     yield request.param
     L.f3dg_set_option(b"render_fast", 1)
 
