@@ -52,7 +52,8 @@ scan_blocksums_kernel(u32* __restrict__ block_sums, u32 nblocks, F3dgHeader* __r
 {
     __shared__ u32 wtot[16];
     __shared__ u32 carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    __shared__ u64 carry64_s, wtot64[16];   // the same sum without wrap-around: a batch can hold more than 2^32 instances (V * P * tiles)
+    if (threadIdx.x == 0) { carry_s = 0; carry64_s = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (u32 start = 0; start < nblocks; start += 1024) {
@@ -65,19 +66,29 @@ scan_blocksums_kernel(u32* __restrict__ block_sums, u32 nblocks, F3dgHeader* __r
             if (lane >= off) x += y;
         }
         if (lane == 63) wtot[wave] = x;
+        unsigned long long v64 = v;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v64 += __shfl_down(v64, off, 64);
+        if (lane == 0) wtot64[wave] = v64;
         __syncthreads();
         u32 wave_off = 0;
         for (int w = 0; w < wave; w++) wave_off += wtot[w];
         const u32 carry = carry_s;
         if (i < nblocks) block_sums[i] = carry + wave_off + x - v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wave_off + x;
+        if (threadIdx.x == 1023) {
+            carry_s = carry + wave_off + x;
+            u64 t = 0;
+            for (int w = 0; w < 16; w++) t += wtot64[w];
+            carry64_s += t;
+        }
         __syncthreads();
     }
     if (hdr && threadIdx.x == 0) {
-        const u32 total = carry_s;
-        hdr->num_rendered = total;
-        hdr->overflow = total > hdr->capacity ? 1u : 0u;
+        // a wrapped 32-bit total must not pass for a small one: later kernels index the instance arrays with it
+        const u64 total = carry64_s;
+        hdr->num_rendered = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)total;
+        hdr->overflow = total > (u64)hdr->capacity ? 1u : 0u;
     }
 }
 

@@ -55,7 +55,9 @@ def _dev_f32(t, device):
 
 class Workspace:
     """Caller-owned scratch for one forward (and its backward): the counterpart of the three resizable byte
-    tensors of the reference (RAST/rasterize_points.cu:72-82), sized once per capacity instead of grown mid-call."""
+    tensors of the reference (RAST/rasterize_points.cu:72-82), sized once per capacity instead of grown mid-call.
+    The library carves the buffer from (P, W, H, n_views, max_rendered) on every call, so a buffer can be reused for any
+    call it is large enough for (``fits`` re-targets it); forward and backward of one call must use the same five numbers."""
 
     def __init__(self, P, W, H, n_views, max_rendered, device):
         self.P, self.W, self.H, self.n_views, self.max_rendered = int(P), int(W), int(H), int(n_views), int(max_rendered)
@@ -63,16 +65,24 @@ class Workspace:
         if nbytes == 0:
             raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_workspace_bytes")
         self.buffer = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self.num_rendered = None
 
     @property
     def nbytes(self):
         return self.buffer.numel()
 
     def fits(self, P, W, H, n_views, max_rendered):
-        return (self.P, self.W, self.H, self.n_views) == (P, W, H, n_views) and self.max_rendered >= max_rendered
+        """True (and the workspace now describes that call) if the buffer is large enough for it."""
+        if (self.P, self.W, self.H, self.n_views) == (P, W, H, n_views) and self.max_rendered >= max_rendered:
+            return True
+        need = _lib.lib().f3dg_workspace_bytes(int(P), int(W), int(H), int(n_views), int(max_rendered))
+        if need == 0 or need > self.buffer.numel():
+            return False
+        self.P, self.W, self.H, self.n_views, self.max_rendered = int(P), int(W), int(H), int(n_views), int(max_rendered)
+        return True
 
 
-_WS_CACHE = {}      # (device index) -> Workspace reused by no-grad single-view calls
+_WS_CACHE = {}      # (device index, stream) -> Workspace reused by no-grad single-view calls on that stream
 _CAP_HINT = {}      # (P, W, H, n_views) -> instances/capacity that worked last time
 
 
@@ -84,9 +94,30 @@ def _initial_capacity(P, W, H, n_views):
     return int(n_views * max(4 * P, 4 * tiles, 1 << 14))
 
 
-def _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+def _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp=None,
+                  n_views=1):
+    """Shapes the kernels rely on (they receive raw pointers): a mismatch must be a Python error, not an out-of-bounds access."""
     if means3D.ndim != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")     # AT_ERROR, rasterize_points.cu:61-63
+    P = means3D.size(0)
+
+    def want(name, t, numel, last=None):
+        if t is None or t.numel() == 0:
+            return
+        if t.numel() != numel or (last is not None and t.ndim >= 2 and t.size(-1) != last):
+            raise RuntimeError(f"{name} has shape {tuple(t.shape)}; expected {numel} elements" +
+                               (f" with last dimension {last}" if last else "") + f" for {P} points")
+    if opacities is None or opacities.numel() != P:
+        raise RuntimeError(f"opacities must have {P} elements (num_points, 1), got "
+                           f"{None if opacities is None else tuple(opacities.shape)}")
+    want("scales", scales, 3 * P, 3)
+    want("rotations", rotations, 4 * P, 4)
+    want("colors_precomp", colors_precomp, 3 * P, 3)
+    want("cov3D_precomp", cov3Ds_precomp, 6 * P, 6)
+    want("view2gaussian_precomp", view2gaussian_precomp, 10 * P * n_views, 10)
+    if sh is not None and sh.numel():
+        if sh.ndim != 3 or sh.size(0) != P or sh.size(2) != 3:
+            raise RuntimeError(f"shs must have dimensions (num_points, M, 3), got {tuple(sh.shape)}")
 
 
 def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg, *, image_height, image_width,
@@ -104,11 +135,11 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
     device = means3D.device
     if device.type != "cuda":
         raise RuntimeError("f3dgaus_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
-    _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
-    P = means3D.size(0)
+    P = means3D.size(0) if means3D.ndim == 2 else 0
     H, W = int(image_height), int(image_width)
     vm = _dev_f32(viewmatrices, device).reshape(-1, 16)
     V = vm.size(0)
+    _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, V)
     pm = _dev_f32(projmatrices, device).reshape(-1, 16)
     cp = _dev_f32(camposs, device).reshape(-1, 3)
     bgt = _dev_f32(bg, device).reshape(-1, 3)
@@ -128,8 +159,12 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
 
     if out is None:
         out = torch.empty((V, 9, H, W), dtype=torch.float32, device=device)
+    elif out.dtype != torch.float32 or out.device != device or not out.is_contiguous() or out.numel() != V * 9 * H * W:
+        raise RuntimeError(f"out must be a contiguous float32 tensor of shape ({V}, 9, {H}, {W}) on {device}")
     if radii is None:
         radii = torch.empty((V, P), dtype=torch.int32, device=device)
+    elif radii.dtype != torch.int32 or radii.device != device or not radii.is_contiguous() or radii.numel() != V * P:
+        raise RuntimeError(f"radii must be a contiguous int32 tensor of shape ({V}, {P}) on {device}")
 
     cap = int(max_rendered) if max_rendered is not None else (workspace.max_rendered if workspace is not None else _initial_capacity(P, W, H, V))
     while True:
@@ -166,6 +201,11 @@ def read_status(workspace):
     return workspace.num_rendered
 
 
+def cpu_deep_copy_tuple(input_tuple):
+    """rast_py:15-17: tensors cloned to the host, everything else as is."""
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         view2gaussian_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -182,15 +222,33 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         needs_grad = any(ctx.needs_input_grad)      # (grad mode is always off inside Function.forward)
         device = means3D.device
-        P = means3D.size(0) if means3D.ndim == 2 else 0
-        key = device.index
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         ws = None if needs_grad else _WS_CACHE.get(key)
-        color, radii, ws = rasterize_views(
-            means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg.reshape(-1)[:3],
-            image_height=rs.image_height, image_width=rs.image_width, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, sh=sh,
-            colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp,
-            view2gaussian_precomp=view2gaussian_precomp, sh_degree=rs.sh_degree, scale_modifier=rs.scale_modifier,
-            kernel_size=rs.kernel_size, workspace=ws, save_aux=needs_grad, check=True)
+
+        def call():
+            return rasterize_views(
+                means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg.reshape(-1)[:3],
+                image_height=rs.image_height, image_width=rs.image_width, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, sh=sh,
+                colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp,
+                view2gaussian_precomp=view2gaussian_precomp, sh_degree=rs.sh_degree, scale_modifier=rs.scale_modifier,
+                kernel_size=rs.kernel_size, workspace=ws, save_aux=needs_grad, check=True)
+
+        if rs.debug:
+            # rast_py:88-98: keep a host copy of the arguments (in the order of the reference's tuple, rast_py:61-84) and dump
+            # it if the rasterizer fails
+            cpu_args = cpu_deep_copy_tuple((rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
+                                            cov3Ds_precomp, view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                            rs.tanfovy, rs.kernel_size, rs.subpixel_offset, rs.image_height, rs.image_width, sh,
+                                            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug))
+            try:
+                color, radii, ws = call()
+                torch.cuda.synchronize(device)       # debug mode: surface asynchronous HIP errors here (auxiliary.h:204-211)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            color, radii, ws = call()
         if not needs_grad:
             _WS_CACHE[key] = ws
         ctx.raster_settings = rs
@@ -206,10 +264,26 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _):
         from .backward import rasterize_backward
-        return rasterize_backward(ctx, grad_out_color)
+        rs = ctx.raster_settings
+        if not rs.debug:
+            return rasterize_backward(ctx, grad_out_color)
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh = ctx.saved_tensors
+        # rast_py:138-150 (argument order of rast_py:113-136; the three buffers of the reference are this build's one workspace)
+        cpu_args = cpu_deep_copy_tuple((rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier,
+                                        cov3Ds_precomp, view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                        rs.tanfovy, rs.kernel_size, rs.subpixel_offset, grad_out_color, sh, rs.sh_degree,
+                                        rs.campos, ctx.num_rendered, rs.debug))
+        try:
+            grads = rasterize_backward(ctx, grad_out_color)
+            torch.cuda.synchronize(means3D.device)
+        except Exception as ex:
+            torch.save(cpu_args, "snapshot_bw.dump")
+            print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+            raise ex
+        return grads
 
 
-_INTEG_WS = {}      # device index -> (key, capacity, buffer) reused by integrate calls
+_INTEG_WS = {}      # (device index, stream) -> (key, capacity, buffer) reused by integrate calls on that stream
 
 
 def integrate_gaussians_to_points(points3D, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -251,13 +325,14 @@ def integrate_gaussians_to_points(points3D, means3D, sh, colors_precomp, opaciti
         cap = _initial_capacity(P, W, H, 1)
         key = (P, PN, W, H)
         while True:
-            cached = _INTEG_WS.get(device.index)
+            ckey = (device.index, torch.cuda.current_stream(device).cuda_stream)
+            cached = _INTEG_WS.get(ckey)
             if cached is None or cached[0] != key or cached[1] < cap:
                 nbytes = L.f3dg_integrate_workspace_bytes(P, PN, W, H, cap)
                 if nbytes == 0:
                     raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_integrate_workspace_bytes")
                 cached = (key, cap, torch.empty(int(nbytes), dtype=torch.uint8, device=device))
-                _INTEG_WS[device.index] = cached
+                _INTEG_WS[ckey] = cached
             buf = cached[2]
             needed = C.c_longlong(0)
             rc = L.f3dg_integrate(
