@@ -33,6 +33,7 @@ SCENES = {
     "F8_sh0": dict(P=1500, res=(64, 64), s0=0.05, view="oblique", sh_degree=0),
     "F9_long_tile_lists": dict(P=30000, res=(128, 128), s0=0.05, view="oblique"),      # lists of 4k..16k: 512-thread LDS tile sort
     "F11_wide_radix": dict(P=20000, res=(320, 272), s0=0.02, view="oblique"),         # 340 tiles: two 8-bit tile passes
+    "F12_depth_spread": dict(P=800, res=(64, 64), s0=0.3, view="canonical", depth_range=(1.0, 30.0)),   # distortion values > 1e-4: rel 1e-3 applies
     "F10_huge_tile_lists": dict(P=50000, res=(32, 32), s0=0.05, view="canonical"),     # lists > 16320: global-memory tile sort path
 }
 

@@ -1,4 +1,7 @@
-"""Prints per-channel parity statistics of the HIP path vs the CPU oracle on the test scenes (run on the GPU box)."""
+"""Per-channel parity statistics of the HIP path vs the CPU oracle on the test scenes, in BOTH arithmetic modes (exact = the
+reference's float32/float64 order, fast = error-free float32 pairs), next to the NOISE FLOOR of the reference's own arithmetic
+(SURVEY 8d): the oracle against itself with tan_fov moved by one float32 ulp -- the GOF exponent amplifies that 6e-8 relative
+change by C = t^2/sigma^2. Run on the GPU box; the output is committed under profiles/ (markdown)."""
 import os
 import sys
 
@@ -8,19 +11,40 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import make_scene, psnr, run_hip, run_oracle  # noqa: E402
+from f3dgaus_amd import _lib  # noqa: E402
+from helpers import frac_within, make_scene, psnr, run_hip, run_oracle  # noqa: E402
 from test_raster_forward_gpu import SCENES  # noqa: E402
 
 dev = torch.device("cuda:0")
-scenes = dict(SCENES)
+L = _lib.lib()
+scenes = {k: v for k, v in SCENES.items() if k not in ("F10_huge_tile_lists",)}
 scenes["C1_65536_256"] = dict(P=65536, res=(256, 256), s0=0.01, view="oblique")
-names = ["rgb", "rgb", "rgb", "nrm", "nrm", "nrm", "depth", "alpha", "dist"]
+scenes["C2_view_196608_256"] = dict(P=196608, res=(256, 256), s0=0.01, view="oblique")
+
+
+def stats(a, b):
+    d = np.abs(a.astype(np.float64) - b)
+    rel = (d[8] / np.maximum(np.abs(b[8]), 1e-12))[np.abs(b[8]) > 1e-7]
+    return (f"{d[:3].max():.1e} | {psnr(a[:3], b[:3]):.1f} | {frac_within(a[:3], b[:3], 1e-4):.5f} | {d[3:6].max():.1e} | "
+            f"{int((d[6] > 1e-4 * np.abs(b[6])).sum())} | {d[7].max():.1e} | {d[8].max():.1e} | {np.median(rel) if rel.size else 0:.1e}")
+
+
+print("| scene | instances | what | rgb max abs | rgb PSNR dB | rgb frac <= 1e-4 | normal max | depth px off | alpha max | dist max abs | dist median rel |")
+print("|---|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|")
 for name, kw in scenes.items():
     sc = make_scene(**kw)
-    h, o = run_hip(sc, dev), run_oracle(sc)
-    a, b = h["out_color"][0], o["out_color"]
-    d = np.abs(a.astype(np.float64) - b)
-    print(f"{name}: R={h['num_rendered']} rgb max {d[:3].max():.2e} psnr {psnr(a[:3], b[:3]):.1f} dB | normal max {d[3:6].max():.2e} | "
-          f"depth max {d[6].max():.2e} (#>1e-4*z: {(d[6] > 1e-4 * np.abs(b[6])).sum()}) | alpha max {d[7].max():.2e} | "
-          f"dist max abs {d[8].max():.2e} max rel {(d[8] / np.maximum(np.abs(b[8]), 1e-12))[np.abs(b[8]) > 1e-7].max() if (np.abs(b[8]) > 1e-7).any() else 0:.2e} | "
-          f"n_contrib equal {(h['n_contrib'][0] == o['n_contrib']).mean():.6f}")
+    o = run_oracle(sc)
+    res = {}
+    for mode, val in (("exact", 0), ("fast", 2)):
+        L.f3dg_set_option(b"render_fast", val)
+        res[mode] = run_hip(sc, dev)
+    L.f3dg_set_option(b"render_fast", 1)
+    sc2 = dict(sc)
+    sc2["tanfovx"] = float(np.nextafter(np.float32(sc["tanfovx"]), np.float32(1)))      # +1 ulp in float32
+    sc2["tanfovy"] = float(np.nextafter(np.float32(sc["tanfovy"]), np.float32(1)))
+    o2 = run_oracle(sc2)
+    for what, a in (("HIP exact vs oracle", res["exact"]["out_color"][0]), ("HIP fast vs oracle", res["fast"]["out_color"][0]),
+                    ("noise floor: oracle vs oracle(tan_fov + 1 ulp)", o2["out_color"])):
+        print(f"| {name} | {o['num_rendered']} | {what} | {stats(a, o['out_color'])} |")
+    same = (res["exact"]["n_contrib"][0] == o["n_contrib"]).mean(), (res["fast"]["n_contrib"][0] == o["n_contrib"]).mean()
+    print(f"| {name} | | n_contrib identical: exact {same[0]:.6f}, fast {same[1]:.6f} | | | | | | | | |")
