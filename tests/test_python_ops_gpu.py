@@ -167,3 +167,33 @@ def test_pack_frames_matches_reference_formula(gpu_device):
         got = pack_frames(x.to(gpu_device)).cpu().numpy()
         ref = (255 * np.clip(x[:, :3].permute(0, 2, 3, 1).numpy(), 0, 1)).astype(np.uint8)
         assert got.shape == ref.shape and np.array_equal(got, ref), (n, C, H, W)
+
+
+def test_cycle_aggregation_matches_the_reference_loop_fixture(gpu_device):
+    """tests/golden/cycle_loop.npz was produced by the reference's OWN loop (visualize.py:224-340 executed from where it lies)
+    around the reference's own predictor and renderer wrapper, with the C oracle as the rasterizer and formula-defined weights
+    (tests/tools/gen_cycle_golden.py). The batched HIP loop with the same weights must reproduce the 8 intermediate renders and
+    the merged 9 x 1024 Gaussians of every checked image."""
+    import os
+    from helpers_weights import formula_state_dict
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cycle_loop.npz"))
+    res, V = 32, 8
+    cfg = cameras.default_cfg(res)
+    torch.manual_seed(0)
+    model = f3d.Unet_GS_gtunet(cfg, renderer=f3d.render_predicted_more_v2_gof).eval()
+    sd = model.state_dict()
+    keep = {k: v for k, v in sd.items() if k.split(".")[-1] in ("ray_dirs", "sh_to_v_transform", "v_to_sh_transform") or k.endswith("resample_filter")}
+    model.load_state_dict(formula_state_dict({k: tuple(v.shape) for k, v in sd.items()}, keep=keep))
+    model = model.to(gpu_device)
+    images, depth = torch.from_numpy(gold["images"]).to(gpu_device), torch.from_numpy(gold["depth"]).to(gpu_device)
+    merged, renders = f3d.cycle.cycle_aggregate(model, images, depth, cfg, rig=cameras.OrbitRig(cfg), num_views=V, return_renders=True)
+    sel = [int(i) for i in gold["sel"]]
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    for name, ours in (("rendered_8", renders["rgb"]), ("alpha_8", renders["alpha"]), ("depth_8", renders["depth"])):
+        e = rel(ours[sel].cpu().numpy(), gold[name])
+        assert e <= 2e-4, (name, e)
+    for k in ("xyz", "opacity", "scaling", "rotation", "features_dc", "features_rest", "unet_depth"):
+        ref = gold["m_" + k]
+        assert merged[k][sel].shape == ref.shape, k
+        e = rel(merged[k][sel].cpu().numpy(), ref)
+        assert e <= 5e-4, (k, e)
