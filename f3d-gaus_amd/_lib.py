@@ -27,6 +27,8 @@ SIGNATURES = {
     "f3dg_workspace_bytes": (_sz, [_i, _i, _i, _i, _ll]),
     "f3dg_forward_batched": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p,
                                   _p, _p, _p, _f, _f, _f, _p, _p, _u]),
+    "f3dg_forward_sets": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p,
+                               _p, _p, _p, _f, _f, _f, _p, _p, _u]),
     "f3dg_read_status": (_i, [_p, _p, C.POINTER(_ll)]),
     "f3dg_forward": (_ll, [_p, _p, _sz, _ll, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,
                            _f, _f, _f, _i, _p, _p, _u, C.POINTER(_ll)]),
@@ -43,6 +45,7 @@ SIGNATURES = {
     "f3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
     "f3dg_splat_head": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _ll, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "f3dg_render_epilogue": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),
+    "f3dg_cycle_inputs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "f3dg_pack_frames": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "f3dg_group_norm_silu": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
     "f3dg_set_option": (_i, [C.c_char_p, _i]),

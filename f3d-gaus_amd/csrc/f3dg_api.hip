@@ -190,14 +190,14 @@ int check_gaussian_args(int P, int D, int M, const float* means3D, const float* 
 }
 
 // projection + binning of n_views views: everything of Rasterizer::forward / ::integrate before the tile kernel
-int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int P, int D, int M, int W, int H,
+int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int views_per_set, int P, int D, int M, int W, int H,
                  const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* cam_pos, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                  int* radii_used, int save_aux, int need_box, ProfCall* prof)
 {
-    int rc = f3dg_launch_preprocess(s, n_views, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+    int rc = f3dg_launch_preprocess(s, n_views, views_per_set, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
                                     reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
@@ -228,6 +228,24 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
                                     float tan_fovx, float tan_fovy, float kernel_size,
                                     float* out_color, int* radii, unsigned flags)
 {
+    return f3dg_forward_sets(stream, workspace, workspace_bytes, max_rendered, 1, n_views, P, D, M, background, W, H, means3D, shs,
+                             colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, view2gaussian_precomp,
+                             viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, out_color, radii, flags);
+}
+
+extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                 int n_sets, int views_per_set, int P, int D, int M,
+                                 const float* background, int W, int H,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp,
+                                 const float* view2gaussian_precomp,
+                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                 float tan_fovx, float tan_fovy, float kernel_size,
+                                 float* out_color, int* radii, unsigned flags)
+{
+    if (n_sets <= 0 || views_per_set <= 0 || (long long)n_sets * views_per_set > 0x7FFFFFF0ll) return F3DG_ERR_BAD_ARG;
+    const int n_views = n_sets * views_per_set;
     hipStream_t s = (hipStream_t)stream;
     if (n_views <= 0 || P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !background || !workspace)
         return F3DG_ERR_BAD_ARG;
@@ -257,7 +275,7 @@ extern "C" int f3dg_forward_batched(void* stream, void* workspace, size_t worksp
     int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
 
     ProfCall* prof = prof_begin(s);
-    rc = run_geometry(s, ws, L, n_views, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+    rc = run_geometry(s, ws, L, n_views, views_per_set, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                       tan_fovy, focal_x, focal_y, kernel_size, radii_used, save_aux,
                       save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, prof);
@@ -308,7 +326,7 @@ extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_
     const float focal_y = H / (2.0f * tan_fovy);           // rasterizer_impl.cu:567-568
     const float focal_x = W / (2.0f * tan_fovx);
     int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
-    rc = run_geometry(s, ws, L, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+    rc = run_geometry(s, ws, L, 1, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                       tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, 1 /* pass 1 culls by the box */, nullptr);
     if (rc != F3DG_OK) return rc;

@@ -92,7 +92,8 @@ struct F3dgViewConsts {           // passed by pointer: [V] of these are the cal
 };
 
 // ---- launchers (each returns F3DG_OK or a negative error) -------------------------------------------
-int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const float* means3D, const float* scales,
+// views_per_set: the V views are n_sets = V / views_per_set groups, group i renders Gaussian set i of the [n_sets, P, ...] inputs
+int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D, int M, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations, const float* opacities, const float* shs,
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,

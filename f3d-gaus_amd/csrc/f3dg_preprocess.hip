@@ -186,7 +186,7 @@ __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float t
 }
 
 __global__ void __launch_bounds__(F3DG_BLOCK)
-preprocess_kernel(int P, int D, int M,
+preprocess_kernel(int P, int D, int M, int views_per_set,
                   const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
                   const float* __restrict__ rotations, const float* __restrict__ opacities,
                   const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
@@ -202,6 +202,7 @@ preprocess_kernel(int P, int D, int M,
 {
     const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
+    const size_t gs = (size_t)(v / views_per_set) * P + g;       // this view's Gaussian set: inputs are [n_sets, P, ...]
     if (g >= P)
         return;
     const size_t idx = (size_t)v * P + g;
@@ -219,7 +220,7 @@ preprocess_kernel(int P, int D, int M,
     unsigned char clamp_bits = 0;
     float depth = 0.0f;
 
-    const float px_ = means3D[3 * (size_t)g], py_ = means3D[3 * (size_t)g + 1], pz_ = means3D[3 * (size_t)g + 2];
+    const float px_ = means3D[3 * gs], py_ = means3D[3 * gs + 1], pz_ = means3D[3 * gs + 2];
 
     // in_frustum (auxiliary.h:177-202): near cull only, the x/y test is commented out in the reference
     const float pvx = view[0] * px_ + view[4] * py_ + view[8] * pz_ + view[12];
@@ -235,14 +236,14 @@ preprocess_kernel(int P, int D, int M,
 
         float3 scale = make_float3(0, 0, 0);
         float4 rot = make_float4(1, 0, 0, 0);
-        if (scales) scale = make_float3(scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]);
-        if (rotations) rot = reinterpret_cast<const float4*>(rotations)[g];
+        if (scales) scale = make_float3(scales[3 * gs], scales[3 * gs + 1], scales[3 * gs + 2]);
+        if (rotations) rot = reinterpret_cast<const float4*>(rotations)[gs];
 
         // ---- computeCov3D (forward.cu:129-163) or the precomputed one
         float c3[6];
         if (cov3D_precomp) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)g + i];
+            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * gs + i];
         } else {
             M3 S = {};
             S.m[0][0] = scale_modifier * scale.x;
@@ -309,13 +310,13 @@ preprocess_kernel(int P, int D, int M,
                 // ---- colour (forward.cu:20-71) or precomputed
                 float cr, cg, cb;
                 if (colors_precomp) {
-                    cr = colors_precomp[3 * (size_t)g]; cg = colors_precomp[3 * (size_t)g + 1]; cb = colors_precomp[3 * (size_t)g + 2];
+                    cr = colors_precomp[3 * gs]; cg = colors_precomp[3 * gs + 1]; cb = colors_precomp[3 * gs + 2];
                 } else {
                     const float* campos = cam_positions + 3 * v;
                     float dx = px_ - campos[0], dy = py_ - campos[1], dz = pz_ - campos[2];
                     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                     dx = dx / len; dy = dy / len; dz = dz / len;
-                    const float* sh = shs + (size_t)g * M * 3;
+                    const float* sh = shs + gs * M * 3;
                     float res[3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) res[ch] = SH_C0 * sh[ch];
@@ -410,7 +411,7 @@ preprocess_kernel(int P, int D, int M,
                     vg[6] = Bx; vg[7] = By; vg[8] = Bz; vg[9] = (float)Cc;
                 }
 
-                const float opac = opacities[g] * coef;
+                const float opac = opacities[gs] * coef;
                 my_radii = max_radius;
                 my_tiles = (unsigned)area;
                 xy = make_float2(pix_x, pix_y);
@@ -466,7 +467,7 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 } // namespace
 
-int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const float* means3D, const float* scales,
+int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D, int M, const float* means3D, const float* scales,
                            float scale_modifier, const float* rotations, const float* opacities, const float* shs,
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
@@ -476,7 +477,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int P, int D, int M, const floa
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
-    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, means3D, scales, scale_modifier,
+    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
                        depths, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);

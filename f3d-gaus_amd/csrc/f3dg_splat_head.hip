@@ -216,3 +216,51 @@ extern "C" int f3dg_pack_frames(void* stream, int n_frames, int H, int W, int sr
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ cycle inputs
+// Hand-off of the cycle aggregation (reference visualize.py:311, 331-333): every rendered view becomes the next predictor
+// input  cat(clamp(rgb, 0, 1), alpha)  [4, H, W]  with its median depth [1, H, W] as unet_depth. One pass over the 9-channel
+// raster instead of clamp + two slices + cat (and the .cpu() round trips of the reference). Frame n = b * V + v of the raster is
+// written to slot v * B + b, so that the B inputs of one novel view are one contiguous predictor batch.
+namespace {
+__global__ void __launch_bounds__(F3DG_BLOCK)
+cycle_inputs_kernel(size_t HW, int B, int V, const float* __restrict__ raster, float* __restrict__ xin, float* __restrict__ depth)
+{
+    const size_t i = ((size_t)blockIdx.x * F3DG_BLOCK + threadIdx.x) * 4;
+    if (i >= HW) return;
+    const unsigned n = blockIdx.y, b = n / (unsigned)V, v = n % (unsigned)V;
+    const float* src = raster + (size_t)n * F3DG_OUT_CHANNELS * HW;
+    const size_t slot = (size_t)v * B + b;
+    float* x = xin + slot * 4 * HW;
+    auto clamp4 = [](float4 q) {      // torch.clamp(x, 0, 1): NaN stays NaN
+        q.x = q.x < 0.0f ? 0.0f : (q.x > 1.0f ? 1.0f : q.x); q.y = q.y < 0.0f ? 0.0f : (q.y > 1.0f ? 1.0f : q.y);
+        q.z = q.z < 0.0f ? 0.0f : (q.z > 1.0f ? 1.0f : q.z); q.w = q.w < 0.0f ? 0.0f : (q.w > 1.0f ? 1.0f : q.w);
+        return q;
+    };
+    if (i + 4 <= HW) {
+        *reinterpret_cast<float4*>(x + 0 * HW + i) = clamp4(*reinterpret_cast<const float4*>(src + 0 * HW + i));
+        *reinterpret_cast<float4*>(x + 1 * HW + i) = clamp4(*reinterpret_cast<const float4*>(src + 1 * HW + i));
+        *reinterpret_cast<float4*>(x + 2 * HW + i) = clamp4(*reinterpret_cast<const float4*>(src + 2 * HW + i));
+        *reinterpret_cast<float4*>(x + 3 * HW + i) = *reinterpret_cast<const float4*>(src + 7 * HW + i);
+        *reinterpret_cast<float4*>(depth + slot * HW + i) = *reinterpret_cast<const float4*>(src + 6 * HW + i);
+    } else {
+        for (size_t k = i; k < HW; k++) {
+            for (int c = 0; c < 3; c++) { const float q = src[c * HW + k]; x[c * HW + k] = q < 0.0f ? 0.0f : (q > 1.0f ? 1.0f : q); }
+            x[3 * HW + k] = src[7 * HW + k];
+            depth[slot * HW + k] = src[6 * HW + k];
+        }
+    }
+}
+} // namespace
+
+extern "C" int f3dg_cycle_inputs(void* stream, int B, int V, int H, int W, const float* raster, float* xin, float* depth)
+{
+    if (B < 0 || V <= 0 || H <= 0 || W <= 0 || !raster || !xin || !depth) return F3DG_ERR_BAD_ARG;
+    if (B == 0) return F3DG_OK;
+    const size_t HW = (size_t)H * W;
+    if ((HW & 3u) || ((uintptr_t)raster & 15u) || ((uintptr_t)xin & 15u) || ((uintptr_t)depth & 15u)) return F3DG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cycle_inputs_kernel, dim3((unsigned)((HW / 4 + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)(B * V)), dim3(F3DG_BLOCK), 0,
+                       (hipStream_t)stream, HW, B, V, raster, xin, depth);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}

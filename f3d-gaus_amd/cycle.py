@@ -7,16 +7,20 @@ Reference shape of the work per batch of B images (visualize.py):
              and torch.cat the 9 Gaussian sets per key                              (B x 589,824 Gaussians)
   :387-416   render the merged set along a 128-view orbit: 128 x B rasterizer calls
 MI355X shape of the same work here:
-  * the 8 (resp. 128) cameras of an image go through ONE launch sequence (render_views), nothing leaves the GPU;
-  * the 8 re-predictions run as ONE predictor batch of 8*B images, and the splat head writes every pass directly
-    into the preallocated merged buffers (no torch.cat chain, no O(n^2) re-copies);
+  * the 8 novel views of ALL B images are ONE launch sequence (f3dg_forward_sets: B Gaussian sets x 8 cameras, ~20 kernel
+    launches per batch instead of per (image, view)); the 128 orbit cameras of an image go through one launch sequence per
+    chunk of views (render_views); nothing leaves the GPU;
+  * one kernel (f3dg_cycle_inputs) turns the rendered rasters into the next predictor inputs -- clamp(rgb) || alpha and
+    the median depth, view-major so that the B inputs of a novel view are one contiguous predictor batch;
+  * the 8 re-predictions are 8 predictor calls of B images each, as in the reference (visualize.py:326-340), and the splat
+    head writes every pass directly into the preallocated merged buffers (no torch.cat chain, no O(n^2) re-copies);
   * the order of the merged set is the reference's: canonical view first, then orbit views 0..7.
 """
 import torch
 
 from . import cameras
 from .gaussian_predictor import GAUSSIAN_KEYS, allocate_gaussians
-from .gaussian_renderer import render_views
+from .gaussian_renderer import cycle_inputs, render_views
 
 
 @torch.no_grad()
@@ -43,40 +47,33 @@ def cycle_aggregate(model, images, depth, cfg, rig=None, num_views=8, yaw_diff=0
           out=merged, n_offset=0)
     first = {k: merged[k][:, :HW] for k in GAUSSIAN_KEYS}
 
-    # 8 novel views of every image in one launch sequence per image (visualize.py:293-314)
+    # 8 novel views of every image: one launch sequence for the whole batch (visualize.py:293-314), then the hand-off kernel
     wv, fp, cc = (orbit.world_view_transforms.to(device), orbit.full_proj_transforms.to(device),
                   orbit.camera_centers.to(device))
-    rgb = torch.empty((B, num_views, 3, H, W), dtype=torch.float32, device=device)
-    alpha = torch.empty((B, num_views, 1, H, W), dtype=torch.float32, device=device)
-    zmed = torch.empty((B, num_views, 1, H, W), dtype=torch.float32, device=device)
-    ws = None
-    for b in range(B):
-        r = render_views(first, b, wv, fp, cc, background, cfg, workspace=ws, epilogue=False)
-        ws = r["workspace"]
-        rgb[b] = r["render"].clamp(0, 1)              # visualize.py:311
-        alpha[b] = r["rendered_alpha"]
-        zmed[b] = r["rendered_depth"]
+    r = render_views(first, None, wv, fp, cc, background, cfg, epilogue=False)
+    xin, zmed = cycle_inputs(r["raster"], B, num_views)        # [V,B,4,H,W] = clamp(rgb) || alpha (visualize.py:311,332), [V,B,1,H,W]
 
     # re-predict from every novel view with its own camera and merge in place (visualize.py:326-340)
     v2w = orbit.view_to_world_transforms.to(device)       # [V,1,4,4]
     quat = orbit.source_cv2wT_quat.to(device)              # [V,1,4]
     for v in range(num_views):
-        xin = torch.cat([rgb[:, v], alpha[:, v]], 1).unsqueeze(1)          # [B,1,4,H,W]
-        model(xin, background, v2w[v:v + 1].expand(B, 1, 4, 4), quat[v:v + 1].expand(B, 1, 4),
-              return_3d_features=True, render=False, squre_clip=squre_clip, unet_depth=zmed[:, v],
+        model(xin[v].unsqueeze(1), background, v2w[v:v + 1].expand(B, 1, 4, 4), quat[v:v + 1].expand(B, 1, 4),
+              return_3d_features=True, render=False, squre_clip=squre_clip, unet_depth=zmed[v],
               out=merged, n_offset=(1 + v) * HW)
     if return_renders:
-        return merged, dict(rgb=rgb, alpha=alpha, depth=zmed)
+        xb = xin.transpose(0, 1)                           # [B,V,4,H,W]
+        return merged, dict(rgb=xb[:, :, :3], alpha=xb[:, :, 3:4], depth=zmed.transpose(0, 1))
     return merged
 
 
 @torch.no_grad()
 def render_orbit(gaussians, cfg, rig=None, num_views=128, yaw_diff=0.25, pitch_diff=0.15, views_per_call=32,
-                 epilogue=True):
+                 epilogue=True, images_per_call=1):
     """visualize.py:343-416: the frontal camera + num_views orbit cameras are built exactly as the reference does,
     and views 1..num_views are rendered. Returns dict of [B, num_views, C, H, W] tensors (render, rendered_depth,
     rendered_alpha, depth_normal). The reference's background[th:th+1] out-of-range read is NOT
-    reproduced: the intended background (0,0,0) is used."""
+    reproduced: the intended background (0,0,0) is used. ``images_per_call`` > 1 renders that many images' views in one launch
+    sequence (f3dg_forward_sets); the workspace grows with images_per_call x views_per_call x Gaussians."""
     rig = rig or cameras.OrbitRig(cfg)
     cams = rig.orbit_with_frontal(num_views, yaw_diff, pitch_diff)
     device = gaussians["xyz"].device
@@ -92,15 +89,16 @@ def render_orbit(gaussians, cfg, rig=None, num_views=128, yaw_diff=0.25, pitch_d
     if epilogue:
         out["depth_normal"] = torch.empty((B, num_views, 3, res, res), device=device)
     workspaces = {}
-    for b in range(B):
+    keys = ("render", "rendered_depth", "rendered_alpha") + (("depth_normal",) if epilogue else ())
+    for b0 in range(0, B, max(int(images_per_call), 1)):
+        b1 = min(b0 + max(int(images_per_call), 1), B)
+        sub = gaussians if (b0, b1) == (0, B) else {k: v[b0:b1] for k, v in gaussians.items() if torch.is_tensor(v)}
         for a in range(0, num_views, views_per_call):
             e = min(a + views_per_call, num_views)
-            r = render_views(gaussians, b, wv[a:e], fp[a:e], cc[a:e], bg, cfg, workspace=workspaces.get(e - a),
-                             epilogue=epilogue)
-            workspaces[e - a] = r["workspace"]
-            out["render"][b, a:e] = r["render"]
-            out["rendered_depth"][b, a:e] = r["rendered_depth"]
-            out["rendered_alpha"][b, a:e] = r["rendered_alpha"]
-            if epilogue:
-                out["depth_normal"][b, a:e] = r["depth_normal"]
+            one = b1 - b0 == 1
+            r = render_views(gaussians if one else sub, b0 if one else None, wv[a:e], fp[a:e], cc[a:e], bg, cfg,
+                             workspace=workspaces.get((b1 - b0, e - a)), epilogue=epilogue)
+            workspaces[(b1 - b0, e - a)] = r["workspace"]
+            for k in keys:
+                out[k][b0:b1, a:e] = r[k].reshape((b1 - b0, e - a) + tuple(r[k].shape[1:]))
     return out

@@ -123,23 +123,32 @@ def _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov
 def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg, *, image_height, image_width,
                     tanfovx, tanfovy, sh=None, colors_precomp=None, scales=None, rotations=None, cov3Ds_precomp=None,
                     view2gaussian_precomp=None, sh_degree=0, scale_modifier=1.0, kernel_size=0.0, workspace=None,
-                    max_rendered=None, save_aux=False, out=None, radii=None, check=True):
+                    max_rendered=None, save_aux=False, out=None, radii=None, check=True, n_sets=1):
     """Render ``n_views`` cameras of the same Gaussians in ONE launch sequence (f3dg_forward_batched).
 
     viewmatrices / projmatrices: [V,4,4] (any leading singleton dims), camposs [V,3], bg [3] or [V,3].
     Returns (color [V,9,H,W], radii [V,P] int32, workspace). With ``check=False`` nothing synchronises; the
     caller may later call ``read_status(workspace)``. With ``check=True`` an overflow grows the workspace and
     re-runs the call (the analogue of the reference's resize callback).
+
+    ``n_sets`` > 1 (f3dg_forward_sets): the Gaussian tensors hold n_sets sets of equal size one after the other
+    ([n_sets * P, ...]) and the V cameras are n_sets groups of V / n_sets (set-major): camera i renders set i // (V / n_sets).
+    This is how the cycle aggregation renders the 8 novel views of every image of a batch in one launch sequence.
     """
     L = _lib.lib()
     device = means3D.device
     if device.type != "cuda":
         raise RuntimeError("f3dgaus_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
-    P = means3D.size(0) if means3D.ndim == 2 else 0
+    n_sets = int(n_sets)
     H, W = int(image_height), int(image_width)
     vm = _dev_f32(viewmatrices, device).reshape(-1, 16)
     V = vm.size(0)
+    if n_sets < 1 or V % n_sets or (means3D.ndim == 2 and means3D.size(0) % n_sets):
+        raise RuntimeError("n_sets must divide the number of views and the number of Gaussians")
+    if n_sets > 1 and (save_aux or view2gaussian_precomp is not None):
+        raise RuntimeError("n_sets > 1 is an inference path: no SAVE_AUX / backward, no view2gaussian_precomp")
     _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, V)
+    P = means3D.size(0) // n_sets
     pm = _dev_f32(projmatrices, device).reshape(-1, 16)
     cp = _dev_f32(camposs, device).reshape(-1, 3)
     bgt = _dev_f32(bg, device).reshape(-1, 3)
@@ -170,13 +179,13 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
     while True:
         if workspace is None or not workspace.fits(P, W, H, V, cap):
             workspace = Workspace(P, W, H, V, cap, device)
-        rc = L.f3dg_forward_batched(
-            _stream(), C.c_void_p(workspace.buffer.data_ptr()), workspace.nbytes, workspace.max_rendered, V, P,
+        rc = L.f3dg_forward_sets(
+            _stream(), C.c_void_p(workspace.buffer.data_ptr()), workspace.nbytes, workspace.max_rendered, n_sets, V // n_sets, P,
             int(sh_degree), int(M), _lib.ptr(bgt), W, H, _lib.ptr(means3D), _lib.ptr(sh), _lib.ptr(colors_precomp),
             _lib.ptr(opacities), _lib.ptr(scales), float(scale_modifier), _lib.ptr(rotations),
             _lib.ptr(cov3Ds_precomp), _lib.ptr(view2gaussian_precomp), _lib.ptr(vm), _lib.ptr(pm), _lib.ptr(cp),
             float(tanfovx), float(tanfovy), float(kernel_size), _lib.ptr(out), _lib.ptr(radii), flags)
-        _lib.check(rc, "f3dg_forward_batched")
+        _lib.check(rc, "f3dg_forward_sets")
         if not check:
             workspace.num_rendered = None
             return out, radii, workspace

@@ -228,26 +228,51 @@ def render_views(pc: dict, bs, world_view_transforms, full_proj_transforms, came
     """All V cameras of image ``bs`` in one launch sequence (no per-view Python loop, no per-view host sync).
     Returns a dict with the same keys as ``render_predicted_more_v2_gof`` but a leading view axis:
     render [V,3,H,W], rendered_normal [V,3,H,W], rendered_depth [V,1,H,W], depth_normal [V,3,H,W],
-    rendered_alpha [V,1,H,W], distortion_map [V,1,H,W], radii [V,P], visibility_filter [V,P], plus 'workspace'."""
+    rendered_alpha [V,1,H,W], distortion_map [V,1,H,W], radii [V,P], visibility_filter [V,P], plus 'workspace'.
+
+    ``bs=None``: ALL B images of the batch through the same V cameras in one launch sequence (f3dg_forward_sets); the leading
+    axis is then B * V, image-major (frame b * V + v)."""
     fov = cfg['model']['fov']
     tanfov = math.tan(fov * np.pi / 360)
     res = int(cfg['model']['training_resolution'])
     V = world_view_transforms.reshape(-1, 16).shape[0]
+    n_sets = 1
+    take = (lambda t: t[bs])
+    wv, fp, cc = world_view_transforms, full_proj_transforms, camera_centers
+    if bs is None:
+        n_sets = pc["xyz"].shape[0]
+        take = (lambda t: t.reshape((-1,) + tuple(t.shape[2:])))
+        wv, fp, cc = (t.reshape(V, -1).repeat(n_sets, 1) for t in (wv, fp, cc))       # set-major: b * V + v
     if override_color is None:
-        shs = torch.cat([pc["features_dc"][bs], pc["features_rest"][bs]], dim=1).contiguous()
+        shs = torch.cat([take(pc["features_dc"]), take(pc["features_rest"])], dim=1).contiguous()
         colors = None
     else:
-        shs, colors = None, pc["rgbs"][bs]
+        shs, colors = None, take(pc["rgbs"])
     with torch.no_grad():
         raster, radii, ws = rasterize_views(
-            pc["xyz"][bs], pc["opacity"][bs], world_view_transforms, full_proj_transforms, camera_centers, bg_color,
+            take(pc["xyz"]), take(pc["opacity"]), wv, fp, cc, bg_color,
             image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, sh=shs, colors_precomp=colors,
-            scales=pc["scaling"][bs], rotations=pc["rotation"][bs], sh_degree=cfg['model']['max_sh_degree'],
-            scale_modifier=scaling_modifier, kernel_size=kernel_size, workspace=workspace, check=check)
+            scales=take(pc["scaling"]), rotations=take(pc["rotation"]), sh_degree=cfg['model']['max_sh_degree'],
+            scale_modifier=scaling_modifier, kernel_size=kernel_size, workspace=workspace, check=check, n_sets=n_sets)
         nw = dn = None
         if epilogue:
-            nw, dn = _epilogue(raster, world_view_transforms.reshape(V, 4, 4).to(raster.device), res, res,
+            nw, dn = _epilogue(raster, wv.reshape(V * n_sets, 4, 4).to(raster.device), res, res,
                                fov * np.pi / 180, fov * np.pi / 180)
     return {"render": raster[:, :3], "rendered_normal": nw, "rendered_depth": raster[:, 6:7], "depth_normal": dn,
             "rendered_alpha": raster[:, 7:8], "distortion_map": raster[:, 8:9], "visibility_filter": radii > 0,
             "radii": radii, "raster": raster, "workspace": ws}
+
+
+def cycle_inputs(raster, B, V):
+    """rasters [B * V, 9, H, W] (image-major) -> (xin [V, B, 4, H, W] = cat(clamp(rgb, 0, 1), alpha), depth [V, B, 1, H, W]):
+    the next predictor inputs of the cycle aggregation (visualize.py:311, 331-333), view-major, in one kernel."""
+    if raster.device.type != "cuda":
+        raise RuntimeError("f3dgaus_amd.cycle_inputs needs a HIP tensor (no CPU fallback)")
+    raster = raster.contiguous()
+    H, W = raster.shape[-2:]
+    xin = torch.empty((V, B, 4, H, W), dtype=torch.float32, device=raster.device)
+    depth = torch.empty((V, B, 1, H, W), dtype=torch.float32, device=raster.device)
+    rc = _lib.lib().f3dg_cycle_inputs(C.c_void_p(torch.cuda.current_stream().cuda_stream), int(B), int(V), int(H), int(W),
+                                      _lib.ptr(raster), _lib.ptr(xin), _lib.ptr(depth))
+    _lib.check(rc, "f3dg_cycle_inputs")
+    return xin, depth

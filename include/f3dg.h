@@ -96,6 +96,22 @@ int f3dg_forward_batched(void* stream, void* workspace, size_t workspace_bytes, 
                          float tan_fovx, float tan_fovy, float kernel_size,
                          float* out_color, int* radii, unsigned flags);
 
+/* The same for n_sets DIFFERENT Gaussian sets of equal size in one launch sequence -- the image-batched form of the cycle
+ * aggregation loop (reference visualize.py:293-314 renders 8 views of each of B images with B x 8 separate rasterizer calls):
+ * means3D ... rotations are [n_sets, P, ...], the cameras [n_sets * views_per_set, ...] (set-major), out_color
+ * [n_sets * views_per_set, 9, H, W], radii [n_sets * views_per_set, P]; view i renders set i / views_per_set.
+ * f3dg_forward_batched is the n_sets = 1 case. Workspace: f3dg_workspace_bytes(P, W, H, n_sets * views_per_set, max_rendered). */
+int f3dg_forward_sets(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                      int n_sets, int views_per_set, int P, int D, int M,
+                      const float* background, int W, int H,
+                      const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp,
+                      const float* view2gaussian_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                      float tan_fovx, float tan_fovy, float kernel_size,
+                      float* out_color, int* radii, unsigned flags);
+
 /* BLOCKING. Waits for `stream`, then reads the workspace header written by the last forward on it.
  * h_num_rendered: total instances the call needed; returns F3DG_OK, or F3DG_ERR_OVERFLOW if that exceeded
  * the capacity the workspace was sized for (outputs of that call are then undefined). */
@@ -208,6 +224,11 @@ int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* r
  * (uint8)(255 * clamp(src[:, 0:3], 0, 1)) with src [n_frames,src_channels,H,W] float32 planar (src_channels = 9 for the
  * rasterizer output), i.e. what visualize.py:407,416 computes on the host per frame. */
 int f3dg_pack_frames(void* stream, int n_frames, int H, int W, int src_channels, const float* src, unsigned char* dst);
+
+/* Hand-off of the cycle aggregation (reference visualize.py:311, 331-333): from the rendered rasters [B * V, 9, H, W] (frame
+ * b * V + v) to the next predictor inputs, view-major: xin [V, B, 4, H, W] = cat(clamp(rgb, 0, 1), alpha) and
+ * depth [V, B, 1, H, W] = the median depth. One kernel; H * W must be a multiple of 4 and the pointers 16-byte aligned. */
+int f3dg_cycle_inputs(void* stream, int B, int V, int H, int W, const float* raster, float* xin, float* depth);
 
 /* Fused GroupNorm (+ SiLU when apply_silu != 0) of the predictor's SongUNet backbone (src/gaussian_predictor.py:250-262 and the
  * `silu(norm(x))` of its residual blocks, :318-323): x, y [N,C,HW] float32 contiguous (NCHW), weight / bias [C],
