@@ -2,20 +2,28 @@
 """bench.py -- headline benchmark of the GOF rasterization hot path on MI355X.
 
 Metric (BASELINE.json): rendered views/s at 256x256 for (N Gaussians, K cameras), plus the achieved bytes/s of the
-per-tile compositing kernel against the gfx950 HBM roofline. Workload at N=1 = BASELINE config C2: one image's
-196,608 Gaussians ("~200k" = 3 cycle views x 65,536) rendered along a 120-view orbit at 256x256, forward only.
-A "step" = one pass of the hot path over that batch: 120 views. With --gpus N every rank renders its own image
-(weak scaling: the batch of input images shards embarrassingly) and the RGB frames are gathered to
-rank 0 over RCCL inside the timed region.
+per-tile compositing kernel against the gfx950 HBM roofline.
 
-Prints ONE JSON line (rank 0). `roofline` is measured live with HIP events recorded by the library on the launch
-stream; `cpu_baseline` times the CPU oracle (the build's plain-C restatement: kind "port") on a bounded sample of
-the same workload on this box's host cores.
+Workloads (`--workload`):
+  c2 (default; the configuration the metric is quoted on): one image's 196,608 Gaussians ("~200k" = 3 cycle views x 65,536)
+      rendered along a 120-view orbit at 256x256, forward only, all 120 views in one launch sequence. A "step" = those 120 views.
+      With --gpus N every rank renders its own image (weak scaling: the batch of input images shards embarrassingly)
+      and the RGB frames are gathered to rank 0 over RCCL inside the timed region.
+  c4 (BASELINE config C4's shape per rank; C3 at N = 1): --images B input images per rank @256x256 through predictor (random
+      weights) + cycle aggregation (8 novel views of all B images in one launch sequence, 8 re-predictions, in-place merge)
+      + the 8 orbit views of every merged set + frame packing + the gather. A "step" = B x 8 final views.
+
+Every number of the JSON line is measured in THIS run except the two `*_from_profiles` objects, which are read from the
+committed rocprofv3 PMC passes of the same command (profiles/<round>/traffic.json) and say so: hardware counters cannot be read
+from inside the process. `roofline` is the compositing kernel, timed with HIP events the library records on the launch stream;
+`rooflines_other` prices the projection and binning stages with SURVEY 8d's byte formulas; `with_d2h` repeats the timed loop with
+frame packing + the device-to-host copy of the RGB frames inside it (SURVEY 8d "how to time"); `cpu_baseline` times the CPU
+oracle (the build's plain-C restatement: kind "port") on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
 import ctypes as C
+import glob
 import json
-import math
 import os
 import sys
 import time
@@ -27,6 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+RASTER_LAUNCHES_PER_CALL = 22    # kernels of one forward call at 256^2 (profiles/*/summary.md): projection, 9 scan, keys, 2 radix,
+                                 # bounds / counts / ranges, 3 tile-sort tiers, header, compositing
 
 
 def parse():
@@ -34,32 +44,32 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2")
     ap.add_argument("--gaussians", type=int, default=196608)
     ap.add_argument("--views", type=int, default=120)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--sigma0", type=float, default=0.01)
+    ap.add_argument("--images", type=int, default=16, help="c4: input images per rank (BASELINE C4 = 64 per rank at 8 GPUs)")
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("F3DG_VIEWS_PER_CALL", "120")))
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("F3DG_STREAMS", "1")),
-                    help="HIP streams the view chunks are distributed over (chunk i -> stream i %% streams)")
     ap.add_argument("--render-mode", choices=["fast", "exact"], default=os.environ.get("F3DG_RENDER_MODE", "fast"),
                     help="compositing arithmetic: fast = error-free float32 pairs for the float64 island (default, parity-gated "
                          "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the second timed loop (frame packing + device-to-host copy)")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
     return ap.parse_args()
 
 
-def main():
-    args = parse()
+def setup_dist():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
     # F3DG_DIST_BACKEND=gloo is a functional check of the N>1 logic on a box with fewer GPUs than ranks (ranks share
     # devices, frames are gathered through host memory); the measured configuration is always nccl = RCCL.
     backend = os.environ.get("F3DG_DIST_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -67,17 +77,76 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    comm_device = device if backend == "nccl" else torch.device("cpu")
+    return rank, world, dist, device, (device if backend == "nccl" else torch.device("cpu"))
 
+
+class Gatherer:
+    """The only exchange of the path: the rendered frames go to rank 0 as 8-bit RGB (what the reference turns every frame into
+    before writing its video, visualize.py:416). Asynchronous on RCCL's stream, at most one gather in flight behind the current
+    step; all of them are waited for inside the timed region."""
+
+    def __init__(self, dist, world, rank, shape, comm_device):
+        self.dist, self.world, self.comm_device, self.pending = dist, world, comm_device, []
+        self.buf = [torch.empty(shape, dtype=torch.uint8, device=comm_device) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def submit(self, frames_u8):
+        if self.world == 1:
+            return
+        frames = frames_u8.to(self.comm_device)
+        self.pending.append((self.dist.gather(frames, self.buf, dst=0, async_op=True), frames))
+        while len(self.pending) > 1:
+            self.pending.pop(0)[0].wait()
+
+    def barrier(self):
+        while self.pending:
+            self.pending.pop(0)[0].wait()
+        if self.world > 1:
+            self.dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+
+def timed(step, barrier, warmup, steps):
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(elapsed, dist, world, device):
+    if world == 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def main():
+    args = parse()
+    rank, world, dist, device, comm_device = setup_dist()
     import f3dgaus_amd as f3d
-    from f3dgaus_amd import _lib, synthetic
+    from f3dgaus_amd import _lib
     L = _lib.lib()
     _lib.check(L.f3dg_set_option(b"render_fast", 1 if args.render_mode == "fast" else 0), "f3dg_set_option")
     if os.environ.get("F3DG_DEBUG_SKIP_ALL"):    # experiment: no Gaussian ever passes -> the compositing kernel only stages
         _lib.check(L.f3dg_set_option(b"debug_skip_all", 1), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
+    result = (run_c4 if args.workload == "c4" else run_c2)(args, rank, world, dist, device, comm_device, f3d, L)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+# ---------------------------------------------------------------------------------------------------------------- C2
+def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
+    from f3dgaus_amd import _lib, synthetic
     P, V, RES = args.gaussians, args.views, args.res
     g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)     # every rank = a different image
     cams = synthetic.orbit_cameras(V, resolution=RES, device=device)
@@ -87,15 +156,13 @@ def main():
     radii = torch.empty((V, P), dtype=torch.int32, device=device)
     chunks = [(a, min(a + args.views_per_call, V)) for a in range(0, V, args.views_per_call)]
     workspaces = {}
-    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
 
     def render_chunk(a, b, check):
-        ws = workspaces.get((a, b) if streams else b - a)
         o, r, ws = f3d.rasterize_views(
             g["xyz"], g["opacity"], cams["viewmatrix"][a:b], cams["projmatrix"][a:b], cams["campos"][a:b], bg,
             image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs,
-            scales=g["scaling"], rotations=g["rotation"], sh_degree=1, workspace=ws, out=out[a:b], radii=radii[a:b],
-            save_aux=False, check=check)
+            scales=g["scaling"], rotations=g["rotation"], sh_degree=1, workspace=workspaces.get(b - a), out=out[a:b],
+            radii=radii[a:b], save_aux=False, check=check)
         return ws
 
     # calibration pass: sizes every chunk's workspace (capacity = max over chunks, +25 %), counts instances
@@ -105,111 +172,171 @@ def main():
         counts.append((b - a, ws.num_rendered))
     for n in set(c[0] for c in counts):
         cap = int(max(c[1] for c in counts if c[0] == n) * 1.25) + 4096
-        if streams:      # concurrent chunks need their own workspace
-            for (a, b) in chunks:
-                if b - a == n:
-                    workspaces[(a, b)] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
-        else:
-            workspaces[n] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
+        workspaces[n] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
     R_total = sum(c[1] for c in counts)
 
-    # final exchange of the path: the rendered frames go to rank 0 as 8-bit RGB, which is what the reference turns every
-    # frame into before writing the video (visualize.py:416); 120 x 3 x 256 x 256 B = 23.6 MB per rank and step. The
-    # gather is asynchronous on RCCL's stream and overlaps the next step's rendering; all of them are waited for inside
-    # the timed region.
-    gather_buf = None
-    pending = []
-    if world > 1:
-        gather_buf = [torch.empty((V, RES, RES, 3), dtype=torch.uint8, device=comm_device) for _ in range(world)] if rank == 0 else None
+    gat = Gatherer(dist, world, rank, (V, RES, RES, 3), comm_device)
 
     def step():
-        if streams:
-            main = torch.cuda.current_stream()
-            for i, (a, b) in enumerate(chunks):
-                st = streams[i % len(streams)]
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    render_chunk(a, b, check=False)
-            for st in streams:
-                main.wait_stream(st)
-        else:
-            for a, b in chunks:
-                render_chunk(a, b, check=False)
-        if world > 1:     # final gather of the RGB frames (the only exchange of the path)
-            frames = f3d.gaussian_renderer.pack_frames(out).to(comm_device)          # uint8 [V,H,W,3], one kernel
-            work = dist.gather(frames, gather_buf, dst=0, async_op=True)
-            pending.append((work, frames))
-            while len(pending) > 1:           # at most one gather in flight behind the current step
-                pending.pop(0)[0].wait()
-
-    def barrier():
-        while pending:
-            pending.pop(0)[0].wait()
+        for a, b in chunks:
+            render_chunk(a, b, check=False)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            gat.submit(f3d.gaussian_renderer.pack_frames(out))          # uint8 [V,H,W,3], one kernel
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    timed(step, gat.barrier, args.warmup, 0)
     L.f3dg_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(step, gat.barrier, 0, args.steps)
     L.f3dg_profile_enable(0)
-    stage_ms = (C.c_double * 3)()
+    stage_ms = (C.c_double * 5)()
     ncalls = C.c_int(0)
     _lib.check(L.f3dg_profile_collect(stage_ms, C.byref(ncalls)), "f3dg_profile_collect")
-    for n, ws in workspaces.items():      # no overflow happened in the timed region
+    for ws in workspaces.values():      # no overflow happened in the timed region
         f3d.diff_gof_rasterization.read_status(ws)
+    elapsed = max_over_ranks(elapsed, dist, world, comm_device if world > 1 else device)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device if world > 1 else device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # second timed loop (N = 1): the frames leave the GPU -- packing to 8-bit RGB (visualize.py:416) or the float32 RGB planes, and
+    # the device-to-host copy into pinned memory, inside the timed region (SURVEY 8d "views/s ... including the final D2H of RGB")
+    d2h = None
+    if world == 1 and not args.no_d2h:
+        host_u8 = torch.empty((V, RES, RES, 3), dtype=torch.uint8).pin_memory()
+        host_f32 = torch.empty((V, 3, RES, RES), dtype=torch.float32).pin_memory()
 
-    copy_gbs = measured_copy_bandwidth(device) if rank == 0 else None
+        def step_u8():
+            step()
+            host_u8.copy_(f3d.gaussian_renderer.pack_frames(out), non_blocking=True)
 
-    if rank == 0:
-        T = ((RES + 15) // 16) ** 2
-        launches = max(int(ncalls.value), 1)
-        # algorithmic bytes of the compositing kernel per launch: 72*R + 36*W*H (inference mode: the
-        # aux planes final_T / n_contrib are not written) + 8*T, summed over the views of the launch
-        bytes_per_step = 72.0 * R_total + (36.0 * RES * RES + 8.0 * T) * V
-        render_ms_per_launch = stage_ms[2] / launches
-        bytes_per_launch = bytes_per_step / len(chunks)
-        achieved = bytes_per_launch / (render_ms_per_launch * 1e-3) / 1e9 if render_ms_per_launch > 0 else 0.0
-        result = {
-            "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)",
-            "value": world * V * args.steps / elapsed,
-            "unit": "views/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (+f64 islands, as the reference)", "data": "synthetic",
-            "config": {"workload": "C2: 1 image/GPU, %d Gaussians (sigma0=%g), %d-view orbit @%dx%d, GOF forward raster only"
-                       % (P, args.sigma0, V, RES, RES), "gaussians": P, "views": V, "resolution": RES,
-                       "instances_per_step": R_total, "views_per_call": args.views_per_call,
-                       "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "render_fwd_kernel<SAVE_AUX=false, PRETEST, CULL, QUEUE>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(P, V, RES, args.views_per_call),
-                         "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
-                         "valu": measured_valu(P, V, RES, args.views_per_call),
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": render_ms_per_launch,
-                         "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
-                                               "compositing": stage_ms[2] / args.steps}},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(g, cams, shs, P, RES, args.cpu_sample_views)
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        def step_f32():
+            step()
+            host_f32.copy_(out[:, :3], non_blocking=True)
+
+        e8 = timed(step_u8, gat.barrier, 1, args.steps)
+        e32 = timed(step_f32, gat.barrier, 1, args.steps)
+        d2h = {"uint8_rgb": {"value": V * args.steps / e8, "unit": "views/s", "ms_per_step": 1e3 * e8 / args.steps,
+                             "bytes_per_step": V * RES * RES * 3},
+               "float32_rgb": {"value": V * args.steps / e32, "unit": "views/s", "ms_per_step": 1e3 * e32 / args.steps,
+                               "bytes_per_step": V * RES * RES * 12},
+               "note": "same step + f3dg_pack_frames (uint8) or the three float planes, + cudaMemcpyAsync to pinned host memory, "
+                       "synchronised once after the last step"}
+
+    if rank != 0:
+        return None
+    copy_gbs = measured_copy_bandwidth(device)
+    T = ((RES + 15) // 16) ** 2
+    launches = max(int(ncalls.value), 1)
+    per = lambda ms: ms / launches
+    # algorithmic bytes per launch, summed over the views of a launch
+    nl = len(chunks)
+    b_render = (72.0 * R_total + (36.0 * RES * RES + 8.0 * T) * V) / nl      # inference mode: the aux planes are not written
+    b_pre = 207.0 * P * V / nl
+    sort_bits = 32 + T.bit_length()       # getHigherMsb(T) of rasterizer_impl.cu:35-50 (9 for 256 tiles): the reference sorts 41 bits
+    b_bin = (20.0 * P * V + 12.0 * R_total + 24.0 * R_total * ((sort_bits + 7) // 8) + 8.0 * R_total + 8.0 * T * V) / nl
+    gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    prof = profiles_record(P, V, RES, args.views_per_call, args.render_mode)
+    result = {
+        "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)",
+        "value": world * V * args.steps / elapsed,
+        "unit": "views/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.render_mode == "fast" else "f32 (+f64 islands, as the reference)", "data": "synthetic",
+        "config": {"workload": "C2: 1 image/GPU, %d Gaussians (sigma0=%g), %d-view orbit @%dx%d, GOF forward raster only, "
+                               "compositing arithmetic: %s" % (P, args.sigma0, V, RES, RES, "fast (error-free float32 pairs; parity-gated at 1e-4)"
+                                                               if args.render_mode == "fast" else "exact (reference float32/float64 order)"),
+                   "gaussians": P, "views": V, "resolution": RES, "instances_per_step": R_total,
+                   "views_per_call": args.views_per_call, "render_mode": args.render_mode,
+                   "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "render2_fwd_kernel<SAVE_AUX=false, FAST=%s>" % ("true" if args.render_mode == "fast" else "false"),
+                     "achieved": gbs(b_render, per(stage_ms[2])), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs(b_render, per(stage_ms[2])) / HBM_PEAK_GBS,
+                     "traffic": None,      # HBM bytes need PMC counters: see traffic_from_profiles
+                     "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
+                     "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
+                     "algorithmic_bytes_per_launch": b_render, "ms_per_launch": per(stage_ms[2]),
+                     "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
+                                           "compositing": stage_ms[2] / args.steps}},
+        "rooflines_other": {
+            "preprocess_kernel": {"bound": "hbm", "algorithmic_bytes_per_launch": b_pre, "ms_per_launch": per(stage_ms[0]),
+                                  "achieved": gbs(b_pre, per(stage_ms[0])), "unit": "GB/s", "frac": gbs(b_pre, per(stage_ms[0])) / HBM_PEAK_GBS,
+                                  "formula": "207 B x P x views (92 read + 115 written per Gaussian and view)"},
+            "binning (scan + keys + sort + ranges, 16 kernels)": {
+                "bound": "hbm", "algorithmic_bytes_per_launch": b_bin, "ms_per_launch": per(stage_ms[1]),
+                "achieved": gbs(b_bin, per(stage_ms[1])), "unit": "GB/s", "frac": gbs(b_bin, per(stage_ms[1])) / HBM_PEAK_GBS,
+                "formula": "20 P + 12 R (keys) + 24 R x ceil(%d key bits / 8) (the reference's radix passes) + 8 R + 8 T (ranges)" % sort_bits}},
+    }
+    if d2h:
+        result["with_d2h"] = d2h
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(g, cams, shs, P, RES, args.cpu_sample_views)
+    return result
 
 
+# ---------------------------------------------------------------------------------------------------------------- C4
+def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
+    """BASELINE C4 per rank (C3 at N = 1): B images -> predictor -> 8 cycle views -> 8 re-predictions -> merged sets of 589,824
+    Gaussians -> their 8 orbit views -> 8-bit frames -> gather. Random weights (no checkpoint travels), synthetic images."""
+    from f3dgaus_amd import _lib, cameras
+    B, RES, V = args.images, args.res, 8
+    cfg = cameras.default_cfg(RES)
+    torch.manual_seed(0)
+    model = f3d.Unet_GS_gtunet(cfg, renderer=f3d.render_predicted_more_v2_gof).to(device).eval()
+    gen = torch.Generator().manual_seed(100 + rank)
+    images = torch.rand(B, 3, RES, RES, generator=gen).to(device)
+    depth = (torch.rand(B, 1, RES, RES, generator=gen) * 2 + 6.667).to(device)
+    rig = cameras.OrbitRig(cfg)
+    per_call = max(1, min(B, 8))
+    gat = Gatherer(dist, world, rank, (B * V, RES, RES, 3), comm_device)
+    t_cycle = [0.0, 0.0]
+
+    def step():
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        merged = f3d.cycle.cycle_aggregate(model, images, depth, cfg, rig=rig, num_views=V)
+        e1.record()
+        orbit = f3d.cycle.render_orbit(merged, cfg, rig=rig, num_views=V, views_per_call=V, epilogue=False, images_per_call=per_call)
+        frames = f3d.gaussian_renderer.pack_frames(orbit["render"].reshape(B * V, 3, RES, RES))
+        e2.record()
+        gat.submit(frames)
+        step.events.append((e0, e1, e2))
+    step.events = []
+
+    timed(step, gat.barrier, args.warmup, 0)
+    step.events.clear()
+    L.f3dg_profile_enable(1)
+    elapsed = timed(step, gat.barrier, 0, args.steps)
+    L.f3dg_profile_enable(0)
+    stage_ms = (C.c_double * 5)()
+    ncalls = C.c_int(0)
+    _lib.check(L.f3dg_profile_collect(stage_ms, C.byref(ncalls)), "f3dg_profile_collect")
+    for e0, e1, e2 in step.events:
+        t_cycle[0] += e0.elapsed_time(e1)
+        t_cycle[1] += e1.elapsed_time(e2)
+    elapsed = max_over_ranks(elapsed, dist, world, comm_device if world > 1 else device)
+    if rank != 0:
+        return None
+    calls_per_step = ncalls.value / max(args.steps, 1)
+    return {
+        "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)",
+        "value": world * B * V * args.steps / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C4 shape per rank (C3 at 1 GPU): %d images/GPU @%dx%d, predictor (SongUNet, random weights) + cycle "
+                               "aggregation (8 views, 8 re-predictions, merged sets of 589,824 Gaussians) + 8 orbit views of every merged set "
+                               "+ frame packing + gather" % (B, RES, RES),
+                   "images_per_gpu": B, "views_per_image": V, "resolution": RES,
+                   "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
+        "breakdown_ms_per_step": {"predictor + cycle aggregation": t_cycle[0] / args.steps, "orbit render + frame packing": t_cycle[1] / args.steps,
+                                  "rasterizer stages (HIP events)": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
+                                                                     "compositing": stage_ms[2] / args.steps}},
+        "launches": {"rasterizer_calls_per_step": calls_per_step, "rasterizer_calls_per_image": calls_per_step / B,
+                     "rasterizer_kernel_launches_per_image": RASTER_LAUNCHES_PER_CALL * calls_per_step / B,
+                     "reference_rasterizer_calls_per_image": 2 * V,
+                     "note": "the reference issues one rasterizer call (>= 10 launches + a blocking D2H) per (image, view): "
+                             "visualize.py:293-314 and :387-416"},
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------- helpers
 def measured_copy_bandwidth(device, nbytes=1 << 30, reps=5):
     """GB/s (read + write) of a plain device-to-device copy of 1 GiB on this box: the practical HBM ceiling next to the
     8 TB/s nominal peak the roofline fraction is quoted against."""
@@ -227,34 +354,25 @@ def measured_copy_bandwidth(device, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def measured_valu(P, V, RES, views_per_call):
-    """Vector-ALU figures of the compositing kernel from the committed SQ counter passes (profiles/r01_final/traffic.json,
-    same configuration only): busy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x kernel cycles), lanes = active lanes per VALU
-    instruction / 64. The kernel is VALU-bound (SURVEY 8d asks for this next to the HBM fraction)."""
-    path = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
-    try:
-        t = json.load(open(path))
-        c = t["config"]
-        if (c["gaussians"], c["views"], c["resolution"], c["views_per_call"]) == (P, V, RES, views_per_call):
-            return t.get("valu")
-    except Exception:
-        pass
-    return None
-
-
-def measured_traffic(P, V, RES, views_per_call):
-    """HBM bytes per compositing launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    runs of this same command; gfx950 FETCH_SIZE correction applied) -- only when they were taken on this exact
-    configuration, else null. PMC counters cannot be collected from inside the process."""
-    path = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
-    try:
-        t = json.load(open(path))
-        c = t["config"]
-        if (c["gaussians"], c["views"], c["resolution"], c["views_per_call"]) == (P, V, RES, views_per_call):
-            return t["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+def profiles_record(P, V, RES, views_per_call, mode):
+    """Counter-derived figures of the compositing kernel from the newest committed profile of THIS configuration
+    (profiles/*/traffic.json, written by tools/make_profile.py from separate rocprofv3 --pmc passes of this same command):
+    `traffic` = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md),
+    `valu` = SQ instruction counts / lane utilisation. Returned with their source path; {} when no profile matches."""
+    best = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+        try:
+            t = json.load(open(path))
+            c = t["config"]
+            if (c["gaussians"], c["views"], c["resolution"], c["views_per_call"]) == (P, V, RES, views_per_call) and \
+                    c.get("render_mode", "exact") == mode:
+                src = os.path.relpath(path, ROOT)
+                best = {"traffic": {"bytes_per_launch": t["traffic_bytes_per_launch"], "source": src,
+                                    "note": "builder-side PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run"},
+                        "valu": dict(t.get("valu") or {}, source=src)}
+        except Exception:
+            pass
+    return best
 
 
 def cpu_baseline(g, cams, shs, P, RES, n_sample):

@@ -53,3 +53,44 @@ def test_gather_frames_gloo_world2(n_items):
         assert p.exitcode == 0
     assert out.shape == (n_items, 3, 4, 4)
     assert torch.equal(out[:, 0, 0, 0], torch.arange(n_items, dtype=torch.float32))
+
+
+def _c4_worker(rank, world, port, n_images, q):
+    """The N > 1 step of bench.py --workload c4 with the renderer replaced by a formula: shard the batch of images, 'render' 8
+    frames per image, hand them to bench.Gatherer (asynchronous gather, one in flight, barrier inside the timed region)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fdist.init_from_env(backend="gloo")
+    s, e = fdist.shard_range(n_images, rank, world)
+    assert e - s == n_images // world                       # bench.py gives every rank the same number of images (weak scaling)
+    V = 8
+    gat = bench.Gatherer(dist, world, rank, ((e - s) * V, 4, 4, 3), torch.device("cpu"))
+    for step in range(3):                                   # three steps: the gathers overlap the next step's work
+        frames = torch.stack([torch.full((4, 4, 3), (img * V + v + step) % 251, dtype=torch.uint8) for img in range(s, e) for v in range(V)])
+        gat.submit(frames)
+    gat.barrier()
+    assert not gat.pending
+    if rank == 0:
+        q.put(torch.cat(gat.buf).clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_step_gather_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_images = 6
+    procs = [ctx.Process(target=_c4_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert out.shape == (n_images * 8, 4, 4, 3)
+    assert torch.equal(out[:, 0, 0, 0].long(), (torch.arange(n_images * 8) + 2) % 251)      # the last step's frames, in image order

@@ -62,7 +62,7 @@ def main():
             continue
         lanes = m["SQ_THREAD_CYCLES_VALU"] / (m["SQ_ACTIVE_INST_VALU"] * 64) if m["SQ_ACTIVE_INST_VALU"] else 0.0
         out.append(f"| `{k}` | " + " | ".join(f"{m[n]:.3g}" for n in names) + f" | {lanes:.2f} |")
-        if k.startswith("render_fwd_kernel") and valu is None:
+        if (k.startswith("render2_fwd_kernel") or k.startswith("render_fwd_kernel")) and valu is None:
             valu = {"lane_utilisation": round(lanes, 3), "SQ_INSTS_VALU": m["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": m["SQ_ACTIVE_INST_VALU"],
                     "SQ_BUSY_CYCLES": m["SQ_BUSY_CYCLES"], "SQ_WAVE_CYCLES": m["SQ_WAVE_CYCLES"],
                     "note": "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); issue_utilisation_lower_bound = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
@@ -73,18 +73,19 @@ def main():
     open(os.path.join(dst, "summary.md"), "w").write("\n".join(out) + "\n")
 
     cfg = json.loads(default_line)["config"]
-    rk = [k for k in fetch if k.startswith("render_fwd_kernel")][0]
+    rk = [k for k in fetch if k.startswith("render2_fwd_kernel") or k.startswith("render_fwd_kernel")][0]
     f_kb = sum(fetch[rk]["FETCH_SIZE"]) / len(fetch[rk]["FETCH_SIZE"])
     w_kb = sum(write[rk]["WRITE_SIZE"]) / len(write[rk]["WRITE_SIZE"])
-    kernel_us = [float(r["AverageNs"]) / 1e3 for r in rows if short(r["Name"]).startswith("render_fwd_kernel")][0]
+    kernel_us = [float(r["AverageNs"]) / 1e3 for r in rows if short(r["Name"]).startswith(("render2_fwd_kernel", "render_fwd_kernel"))][0]
     if valu:
         cycles = kernel_us * 1e-6 * 2.4e9          # 2.4 GHz peak engine clock
         # every wave64 VALU instruction occupies its SIMD for >= 2 cycles (32 lanes/cycle, MI355X_MICROARCH.md "Wave
         # scheduling"); float64 and transcendental ones for longer, so this is a LOWER bound of the issue-slot utilisation
         valu["issue_utilisation_lower_bound"] = round(valu["SQ_INSTS_VALU"] * 2 / (SIMDS * cycles), 3)
         valu["kernel_us_rocprof"] = kernel_us
-    t = {"kernel": "render_fwd_kernel",
-         "config": {"gaussians": cfg["gaussians"], "views": cfg["views"], "resolution": cfg["resolution"], "views_per_call": cfg["views_per_call"]},
+    t = {"kernel": rk,
+         "config": {"gaussians": cfg["gaussians"], "views": cfg["views"], "resolution": cfg["resolution"], "views_per_call": cfg["views_per_call"],
+                    "render_mode": cfg.get("render_mode", "exact")},
          "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
          "traffic_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024, "valu": valu,
          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncalibrated"}
