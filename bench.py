@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--render-mode", choices=["fast", "exact"], default=os.environ.get("F3DG_RENDER_MODE", "fast"),
                     help="compositing arithmetic: fast = error-free float32 pairs for the float64 island (default, parity-gated "
                          "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
+    ap.add_argument("--backbone", choices=["fp32", "bf16"], default="fp32",
+                    help="c4: precision of the SongUNet backbone (bf16 = the opt-in autocast option, SURVEY 8f-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the second timed loop (frame packing + device-to-host copy)")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
@@ -278,6 +280,8 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
     from f3dgaus_amd import _lib, cameras
     B, RES, V = args.images, args.res, 8
     cfg = cameras.default_cfg(RES)
+    cfg['model']['backbone_dtype'] = args.backbone
+    torch.backends.cudnn.benchmark = True               # MIOpen picks its convolution algorithms once per shape
     torch.manual_seed(0)
     model = f3d.Unet_GS_gtunet(cfg, renderer=f3d.render_predicted_more_v2_gof).to(device).eval()
     gen = torch.Generator().manual_seed(100 + rank)
@@ -319,11 +323,11 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
         "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)",
         "value": world * B * V * args.steps / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (rasterizer, splat head); backbone %s" % args.backbone, "data": "synthetic",
         "config": {"workload": "C4 shape per rank (C3 at 1 GPU): %d images/GPU @%dx%d, predictor (SongUNet, random weights) + cycle "
                                "aggregation (8 views, 8 re-predictions, merged sets of 589,824 Gaussians) + 8 orbit views of every merged set "
                                "+ frame packing + gather" % (B, RES, RES),
-                   "images_per_gpu": B, "views_per_image": V, "resolution": RES,
+                   "images_per_gpu": B, "views_per_image": V, "resolution": RES, "backbone": args.backbone,
                    "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
         "breakdown_ms_per_step": {"predictor + cycle aggregation": t_cycle[0] / args.steps, "orbit render + frame packing": t_cycle[1] / args.steps,
                                   "rasterizer stages (HIP events)": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,

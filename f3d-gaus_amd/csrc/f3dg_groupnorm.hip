@@ -12,28 +12,75 @@ namespace {
 
 constexpr int GN_THREADS = 1024;
 
-__global__ void __launch_bounds__(GN_THREADS)
-group_norm_silu_kernel(int C, int HW, int groups, const float* __restrict__ x, const float* __restrict__ weight,
-                       const float* __restrict__ bias, float eps, int apply_silu, float* __restrict__ y)
+// bf16 <-> f32 (round to nearest even; NaN kept quiet)
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f)
 {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// 16-byte packets: 4 floats or 8 bf16
+template <typename T> struct Packet;
+template <> struct Packet<float> {
+    static constexpr int N = 4;
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Packet<unsigned short> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const unsigned short* p)
+    {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u); }
+    }
+    __device__ __forceinline__ void store(unsigned short* p) const
+    {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(unsigned short x) { return bf16_to_f32(x); }
+__device__ __forceinline__ void from_f32(float& d, float x) { d = x; }
+__device__ __forceinline__ void from_f32(unsigned short& d, float x) { d = f32_to_bf16(x); }
+
+// T = float, or unsigned short holding bfloat16 (the bf16 option of the backbone: statistics and arithmetic stay float32 / float64)
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+group_norm_silu_kernel(int C, int HW, int groups, const T* __restrict__ x, const float* __restrict__ weight,
+                       const float* __restrict__ bias, float eps, int apply_silu, T* __restrict__ y)
+{
+    constexpr int PN = Packet<T>::N;
     const int g = blockIdx.x % groups;
     const int n = blockIdx.x / groups;
     const int Cg = C / groups;
     const size_t slab = (size_t)Cg * HW;
-    const float* xs = x + ((size_t)n * C + (size_t)g * Cg) * HW;
-    float* ys = y + ((size_t)n * C + (size_t)g * Cg) * HW;
+    const T* xs = x + ((size_t)n * C + (size_t)g * Cg) * HW;
+    T* ys = y + ((size_t)n * C + (size_t)g * Cg) * HW;
 
     // ---- moments: float partial sums per thread over short runs, folded into float64
     double s1 = 0.0, s2 = 0.0;
-    const size_t n4 = slab / 4;                                   // HW is a multiple of 4 for every layer of the backbone
-    const float4* x4 = reinterpret_cast<const float4*>(xs);
-    for (size_t i = threadIdx.x; i < n4; i += GN_THREADS) {
-        const float4 v = x4[i];
-        s1 += (double)((v.x + v.y) + (v.z + v.w));
-        s2 += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    const bool vec = HW % PN == 0;                                // true for every layer of the backbone at 256^2 / 32^2
+    const size_t np = vec ? slab / PN : 0;
+    for (size_t i = threadIdx.x; i < np; i += GN_THREADS) {
+        Packet<T> p;
+        p.load(xs + i * PN);
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PN; k++) { a += p.v[k]; b += p.v[k] * p.v[k]; }
+        s1 += (double)a;
+        s2 += (double)b;
     }
-    for (size_t i = n4 * 4 + threadIdx.x; i < slab; i += GN_THREADS) {
-        const float v = xs[i];
+    for (size_t i = np * PN + threadIdx.x; i < slab; i += GN_THREADS) {
+        const float v = to_f32(xs[i]);
         s1 += v; s2 += (double)(v * v);
     }
 #pragma unroll
@@ -59,30 +106,44 @@ group_norm_silu_kernel(int C, int HW, int groups, const float* __restrict__ x, c
     const float mean = s_mean, rstd = s_rstd;
 
     // ---- normalise, affine, (silu): the slab is re-read from L2
-    const int hw4 = HW / 4;
-    if (HW % 4 == 0) {
-        float4* y4 = reinterpret_cast<float4*>(ys);
-        for (size_t i = threadIdx.x; i < n4; i += GN_THREADS) {
-            const int c = g * Cg + (int)(i / hw4);
+    if (vec) {
+        const int hwp = HW / PN;
+        for (size_t i = threadIdx.x; i < np; i += GN_THREADS) {
+            const int c = g * Cg + (int)(i / hwp);
             const float sc = weight[c] * rstd;
             const float sh = bias[c] - mean * sc;
-            float4 v = x4[i];
-            v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
-            if (apply_silu) {
-                v.x = v.x / (1.0f + expf(-v.x)); v.y = v.y / (1.0f + expf(-v.y));
-                v.z = v.z / (1.0f + expf(-v.z)); v.w = v.w / (1.0f + expf(-v.w));
+            Packet<T> p;
+            p.load(xs + i * PN);
+#pragma unroll
+            for (int k = 0; k < PN; k++) {
+                float v = p.v[k] * sc + sh;
+                if (apply_silu) v = v / (1.0f + expf(-v));
+                p.v[k] = v;
             }
-            y4[i] = v;
+            p.store(ys + i * PN);
         }
     } else {
         for (size_t i = threadIdx.x; i < slab; i += GN_THREADS) {
             const int c = g * Cg + (int)(i / HW);
             const float sc = weight[c] * rstd;
-            float v = xs[i] * sc + (bias[c] - mean * sc);
+            float v = to_f32(xs[i]) * sc + (bias[c] - mean * sc);
             if (apply_silu) v = v / (1.0f + expf(-v));
-            ys[i] = v;
+            from_f32(ys[i], v);
         }
     }
+}
+
+template <typename T>
+int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const float* weight, const float* bias, float eps,
+              int apply_silu, T* y)
+{
+    if (N < 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0 || !x || !weight || !bias || !y) return F3DG_ERR_BAD_ARG;
+    if (N == 0) return F3DG_OK;
+    if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;       // 16-byte loads / stores
+    hipLaunchKernelGGL(group_norm_silu_kernel<T>, dim3((unsigned)(N * groups)), dim3(GN_THREADS), 0, (hipStream_t)stream, C, HW,
+                       groups, x, weight, bias, eps, apply_silu, y);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
 }
 
 } // namespace
@@ -90,11 +151,11 @@ group_norm_silu_kernel(int C, int HW, int groups, const float* __restrict__ x, c
 extern "C" int f3dg_group_norm_silu(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
                                     const float* bias, float eps, int apply_silu, float* y)
 {
-    if (N < 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0 || !x || !weight || !bias || !y) return F3DG_ERR_BAD_ARG;
-    if (N == 0) return F3DG_OK;
-    if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;       // 16-byte loads / stores
-    hipLaunchKernelGGL(group_norm_silu_kernel, dim3((unsigned)(N * groups)), dim3(GN_THREADS), 0, (hipStream_t)stream, C, HW,
-                       groups, x, weight, bias, eps, apply_silu, y);
-    F3DG_HIP_CHECK(hipGetLastError());
-    return F3DG_OK;
+    return launch_gn<float>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y);
+}
+
+extern "C" int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
+                                         const float* bias, float eps, int apply_silu, uint16_t* y)
+{
+    return launch_gn<unsigned short>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y);
 }

@@ -92,14 +92,14 @@ class GroupNorm(nn.Module):
         """``silu=True`` returns ``F.silu(group_norm(x))``: the pair the residual blocks always apply together. In
         inference on a HIP device the pair is ONE fused kernel (``f3dg_group_norm_silu``); with autograd
         or on the host (the CPU fixtures of the backbone) it is the two PyTorch ops."""
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and not (
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 3 and self.weight.dtype == torch.float32 and not (
                 torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
             xc = x.contiguous()
             y = torch.empty_like(xc)
             N, Cc = xc.shape[0], xc.shape[1]
-            rc = _lib.lib().f3dg_group_norm_silu(_stream(), N, Cc, xc.numel() // max(N * Cc, 1), self.num_groups,
-                                                 _lib.ptr(xc), _lib.ptr(self.weight), _lib.ptr(self.bias), float(self.eps),
-                                                 1 if silu else 0, _lib.ptr(y))
+            fn = _lib.lib().f3dg_group_norm_silu if x.dtype == torch.float32 else _lib.lib().f3dg_group_norm_silu_bf16
+            rc = fn(_stream(), N, Cc, xc.numel() // max(N * Cc, 1), self.num_groups, _lib.ptr(xc), _lib.ptr(self.weight),
+                    _lib.ptr(self.bias), float(self.eps), 1 if silu else 0, _lib.ptr(y))
             _lib.check(rc, "f3dg_group_norm_silu")
             return y
         y = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
@@ -286,6 +286,9 @@ class GaussianSplatPredictor_gtunet(nn.Module):
                 "network_with_offset, max_sh_degree 1, anisotropic, no origin_distances / uncertainty head)")
         split_dimensions, scale_inits, bias_inits = self.get_splits_and_inits(True, cfg)
         self.network_with_offset = networkCallBack(cfg, m['name'], split_dimensions, scale=scale_inits, bias=bias_inits)
+        # extension: "bf16" runs the backbone's convolutions under bfloat16 autocast with bf16 activations between
+        # the layers (GroupNorm statistics, attention and the splat head stay float32); "fp32" (default) is the reference's precision
+        self.backbone_dtype = str(m.get('backbone_dtype', 'fp32'))
         self.init_ray_dirs()
         self.init_sh_transform_matrices()
 
@@ -333,7 +336,14 @@ class GaussianSplatPredictor_gtunet(nn.Module):
         x = x.reshape(B * Nv, *x.shape[2:])
         v2w = source_cameras_view_to_world.reshape(B * Nv, 4, 4)
         quat = source_cv2wT_quat.reshape(B * Nv, 4)
-        net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)
+        if self.backbone_dtype == "bf16" and x.is_cuda and not torch.is_grad_enabled():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)
+            net_out = net_out.float()
+        elif self.backbone_dtype not in ("fp32", "bf16"):
+            raise ValueError("backbone_dtype must be 'fp32' or 'bf16'")
+        else:
+            net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)
         H, W = net_out.shape[-2:]
         depth = unet_depth.reshape(B * Nv, 1, H, W)
         if out is not None:

@@ -236,6 +236,10 @@ int f3dg_cycle_inputs(void* stream, int B, int V, int H, int W, const float* ras
  * x == y (in place) is allowed. SURVEY.md 8f-3. */
 int f3dg_group_norm_silu(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
                          const float* bias, float eps, int apply_silu, float* y);
+/* The same with bfloat16 activations in and out (the bf16 option of the backbone); weight / bias and all arithmetic float32,
+ * the moments float64. */
+int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
+                              const float* bias, float eps, int apply_silu, uint16_t* y);
 
 /* Runtime switches (process-wide). Known names: "render_pretest" (default 1): the compositing kernel first runs a
  * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;

@@ -20,14 +20,14 @@ x = torch.rand(B, 4, 256, 256, device=dev)
 mode = os.environ.get("MODE", "fp32")
 if os.environ.get("BENCHMARK"):
     torch.backends.cudnn.benchmark = True
-if mode == "channels_last":
+if mode in ("channels_last", "bf16_cl"):
     pred = pred.to(memory_format=torch.channels_last)
     x = x.contiguous(memory_format=torch.channels_last)
 
 
 def run():
     with torch.no_grad():
-        if mode == "bf16":
+        if mode in ("bf16", "bf16_cl"):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return pred.network_with_offset(x)
         return pred.network_with_offset(x)
@@ -41,4 +41,4 @@ n = 3
 for _ in range(n):
     y = run()
 torch.cuda.synchronize()
-print(f"SongUNet forward mode={mode} B={B}: {(time.perf_counter() - t0) / n * 1e3:.1f} ms, out {tuple(y.shape)} {y.dtype}")
+print(f"SongUNet forward mode={mode} benchmark={bool(os.environ.get('BENCHMARK'))} B={B}: {(time.perf_counter() - t0) / n * 1e3:.1f} ms, out {tuple(y.shape)} {y.dtype}")
