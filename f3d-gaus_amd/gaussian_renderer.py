@@ -44,6 +44,21 @@ def _epilogue(raster, world_view, W, H, FoVx, FoVy, want_normal=True, want_depth
     return nw, dn
 
 
+def _epilogue_autograd(rendered_image, world_view_transform, W, H, FoVx, FoVy):
+    """Differentiable counterpart of ``_epilogue`` for one [9,H,W] raster: the reference's own formulation (gr.py:898-909,
+    :1043-1053) in torch ops. Used only when gradients are required; inference takes the fused kernel."""
+    render_normal = torch.nn.functional.normalize(rendered_image[3:6], p=2, dim=0)
+    c2w = (world_view_transform.reshape(4, 4).T).inverse()
+    normal_world = (c2w[:3, :3] @ render_normal.reshape(3, -1)).reshape(3, *render_normal.shape[1:])
+    depth = rendered_image[6:7]
+    points = depths_to_points(world_view_transform.reshape(4, 4), W, H, FoVx, FoVy, depth).reshape(*depth.shape[1:], 3)
+    output = torch.zeros_like(points)
+    dx = points[2:, 1:-1] - points[:-2, 1:-1]
+    dy = points[1:-1, 2:] - points[1:-1, :-2]
+    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+    return normal_world, output.permute(2, 0, 1)
+
+
 def pack_frames(raster):
     """raster [n,C>=3,H,W] float32 on the HIP device -> uint8 [n,H,W,3] = (255 * clip(raster[:, :3], 0, 1)).astype(uint8),
     the frame format of visualize.py:416, in one kernel (f3dg_pack_frames)."""
@@ -137,11 +152,17 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
                                            cov3D_precomp=None, view2gaussian_precomp=None)
 
     wv = world_view_transform.reshape(1, 4, 4)
-    nw, dn = _epilogue(rendered_image.detach().unsqueeze(0), wv, image_width, image_height, FovX, FovY)
+    if torch.is_grad_enabled() and rendered_image.requires_grad:
+        # training: the two derived maps carry gradients in the reference (plain torch ops on the raster, gr.py:1043-1053), so a
+        # normal-consistency or depth-normal loss must reach the rasterizer's backward -- same ops here instead of the fused kernel
+        nw0, dn0 = _epilogue_autograd(rendered_image, wv[0], image_width, image_height, FovX, FovY)
+    else:
+        nw, dn = _epilogue(rendered_image.detach().unsqueeze(0), wv, image_width, image_height, FovX, FovY)
+        nw0, dn0 = nw[0], dn[0]
     res = {"render": rendered_image[:3, :, :],
-           "rendered_normal": nw[0],
+           "rendered_normal": nw0,
            "rendered_depth": rendered_image[6:7, :, :],
-           "depth_normal": dn[0],
+           "depth_normal": dn0,
            "rendered_alpha": rendered_image[7:8, :, :],
            "distortion_map": rendered_image[8:9, :, :],
            "viewspace_points": screenspace_points,

@@ -279,3 +279,25 @@ def test_backbone_bf16_option(gpu_device):
         out = p16(xin, rig.view_to_world_transforms.expand(2, 1, 4, 4).to(gpu_device), rig.source_cv2wT_quat.expand(2, 1, 4).to(gpu_device),
                   unet_depth=torch.full((2, 1, 32, 32), 7.0, device=gpu_device))
     assert out["xyz"].dtype == torch.float32 and out["xyz"].shape == (2, 1024, 3) and bool(torch.isfinite(out["scaling"]).all())
+
+
+def test_renderer_derived_maps_carry_gradients(gpu_device):
+    """rendered_normal / depth_normal are differentiable in the reference (gr.py:1043-1053). With gradients enabled
+    the wrapper takes the torch formulation (same values as the fused kernel) and a loss on them reaches the Gaussians."""
+    scene = make_scene(P=1500, res=(64, 64), s0=0.08, view="oblique")
+    cfg = cameras.default_cfg(64)
+    dev = lambda t: t.to(gpu_device)
+    pc = {"xyz": dev(scene["means3D"])[None].clone().requires_grad_(True), "opacity": dev(scene["opacities"])[None],
+          "scaling": dev(scene["scales"])[None].clone().requires_grad_(True), "rotation": dev(scene["rotations"])[None],
+          "features_dc": dev(scene["shs"][:, :1])[None], "features_rest": dev(scene["shs"][:, 1:])[None]}
+    args = (dev(scene["viewmatrix"][:1]), dev(scene["projmatrix"][:1]), dev(scene["campos"][:1]), torch.zeros(1, 3, device=gpu_device), cfg)
+    out = f3d.render_predicted_more_v2_gof(pc, 0, *args)
+    assert out["rendered_normal"].requires_grad and out["depth_normal"].requires_grad
+    with torch.no_grad():
+        ref = f3d.render_predicted_more_v2_gof({k: v.detach() for k, v in pc.items()}, 0, *args)      # fused kernel
+    assert (out["rendered_normal"] - ref["rendered_normal"]).abs().max().item() < 1e-5
+    d = (out["depth_normal"] - ref["depth_normal"]).abs()
+    assert (d <= 1e-3).float().mean().item() >= 0.999
+    (out["rendered_normal"].square().sum() + out["depth_normal"][:, 8:-8, 8:-8].sum()).backward()
+    assert pc["xyz"].grad is not None and float(pc["xyz"].grad.abs().max()) > 0 and bool(torch.isfinite(pc["xyz"].grad).all())
+    assert float(pc["scaling"].grad.abs().max()) > 0
