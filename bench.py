@@ -9,6 +9,8 @@ Workloads (`--workload`):
       rendered along a 120-view orbit at 256x256, forward only, all 120 views in one launch sequence. A "step" = those 120 views.
       With --gpus N every rank renders its own image (weak scaling: the batch of input images shards embarrassingly)
       and the RGB frames are gathered to rank 0 over RCCL inside the timed region.
+  c5 (BASELINE config C5): 1,000,000 Gaussians, 32 views @512x512, SAVE_AUX forward + backward (random dL/dpix on channels 0-6
+      and 8) per step; adds the roofline record of the compositing backward (80 R + 60 W H + 68 C bytes, C counted by the kernel).
   c4 (BASELINE config C4's shape per rank; C3 at N = 1): --images B input images per rank @256x256 through predictor (random
       weights) + cycle aggregation (8 novel views of all B images in one launch sequence, 8 re-predictions, in-place merge)
       + the 8 orbit views of every merged set + frame packing + the gather. A "step" = B x 8 final views.
@@ -44,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["c2", "c4"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c2")
     ap.add_argument("--gaussians", type=int, default=196608)
     ap.add_argument("--views", type=int, default=120)
     ap.add_argument("--res", type=int, default=256)
@@ -138,7 +140,7 @@ def main():
         _lib.check(L.f3dg_set_option(b"debug_skip_all", 1), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
-    result = (run_c4 if args.workload == "c4" else run_c2)(args, rank, world, dist, device, comm_device, f3d, L)
+    result = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, rank, world, dist, device, comm_device, f3d, L)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -337,6 +339,68 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
                      "reference_rasterizer_calls_per_image": 2 * V,
                      "note": "the reference issues one rasterizer call (>= 10 launches + a blocking D2H) per (image, view): "
                              "visualize.py:293-314 and :387-416"},
+    }
+
+
+
+# ---------------------------------------------------------------------------------------------------------------- C5
+def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
+    """BASELINE C5: 1 M Gaussians, 32 views @512x512, forward with the auxiliary planes + backward, one call each per step."""
+    from f3dgaus_amd import _lib, synthetic
+    from f3dgaus_amd.diff_gof_rasterization.backward import rasterize_backward_raw
+    P, V, RES = 1000000, 32, 512
+    g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)
+    cams = synthetic.orbit_cameras(V, resolution=RES, device=device)
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
+    bg = torch.zeros(3, device=device)
+    gen = torch.Generator().manual_seed(11)
+    dpix = torch.randn(V, 9, RES, RES, generator=gen).to(device)
+    dpix[:, 7] = 0
+    kw = dict(image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"],
+              rotations=g["rotation"], sh_degree=1, save_aux=True)
+    out, radii, ws = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, **kw)
+    R = ws.num_rendered
+
+    def step():
+        f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, workspace=ws,
+                            out=out, radii=radii, check=False, **kw)
+        rasterize_backward_raw(ws, g["xyz"], shs, None, g["scaling"], g["rotation"], radii, dpix, 1, cams["viewmatrix"],
+                               cams["projmatrix"], cams["campos"], bg, cams["tanfovx"], cams["tanfovy"], 0.0, 1.0)
+
+    sync = lambda: torch.cuda.synchronize()
+    timed(step, sync, args.warmup, 0)
+    L.f3dg_profile_enable(1)
+    elapsed = timed(step, sync, 0, args.steps)
+    L.f3dg_profile_enable(0)
+    stage_ms = (C.c_double * 5)()
+    ncalls = C.c_int(0)
+    _lib.check(L.f3dg_profile_collect(stage_ms, C.byref(ncalls)), "f3dg_profile_collect")
+    pairs = C.c_longlong(0)
+    _lib.check(L.f3dg_backward_pairs(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), C.byref(pairs)),
+               "f3dg_backward_pairs")
+    if rank != 0:
+        return None
+    T = ((RES + 15) // 16) ** 2
+    n = max(args.steps, 1)
+    gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    b_fwd = 72.0 * R + (60.0 * RES * RES + 8.0 * T) * V                       # with the auxiliary planes (SURVEY 8d)
+    b_bwd = 80.0 * R + 60.0 * RES * RES * V + 68.0 * pairs.value
+    return {
+        "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)", "value": world * V * args.steps / elapsed, "unit": "views/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (+f64 islands, as the reference)", "data": "synthetic",
+        "config": {"workload": "C5: %d Gaussians (sigma0=%g), %d views @%dx%d, forward with auxiliary planes + backward "
+                               "(random dL/dpix on channels 0-6, 8); views/s counts a forward + backward as one view" % (P, args.sigma0, V, RES, RES),
+                   "gaussians": P, "views": V, "resolution": RES, "instances_per_step": R, "contributing_pairs_per_step": pairs.value},
+        "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel", "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": stage_ms[3] / n,
+                     "achieved": gbs(b_bwd, stage_ms[3] / n), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(b_bwd, stage_ms[3] / n) / HBM_PEAK_GBS,
+                     "traffic": None, "formula": "80 R + 60 W H V + 68 C (C = contributing pairs, counted by the kernel)"},
+        "rooflines_other": {
+            "render2_fwd_kernel<SAVE_AUX=true, FAST=false>": {"bound": "hbm", "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": stage_ms[2] / n,
+                                                               "achieved": gbs(b_fwd, stage_ms[2] / n), "unit": "GB/s",
+                                                               "frac": gbs(b_fwd, stage_ms[2] / n) / HBM_PEAK_GBS}},
+        "stage_ms_per_step": {"preprocess": stage_ms[0] / n, "binning": stage_ms[1] / n, "compositing": stage_ms[2] / n,
+                              "compositing backward": stage_ms[3] / n, "per-Gaussian backward": stage_ms[4] / n},
     }
 
 

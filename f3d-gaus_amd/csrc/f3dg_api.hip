@@ -16,14 +16,14 @@ thread_local char g_last_error[512] = "";
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-__global__ void init_header_kernel(F3dgHeader* hdr, unsigned capacity)
+__global__ void init_header_kernel(F3dgHeader* hdr, unsigned capacity, unsigned alpha_fast = 0)
 {
     if (threadIdx.x < 64) {
         unsigned* w = reinterpret_cast<unsigned*>(hdr);
         w[threadIdx.x] = 0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) hdr->capacity = capacity;
+    if (threadIdx.x == 0) { hdr->capacity = capacity; hdr->alpha_fast = alpha_fast; }
 }
 
 __global__ void fill_background_kernel(int V, size_t HW, const float* __restrict__ bg, int bg_per_view,
@@ -38,11 +38,14 @@ __global__ void fill_background_kernel(int V, size_t HW, const float* __restrict
 
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's live roofline figure) ----
 enum { ST_PREPROCESS = 0, ST_BINNING, ST_RENDER, ST_COUNT };
+enum { BW_RENDER = 0, BW_GAUSSIAN, BW_COUNT };       // backward stages, recorded by f3dg_backward
 struct ProfCall { hipEvent_t ev[ST_COUNT + 1]; };
+struct ProfBwd { hipEvent_t ev[BW_COUNT + 1]; };
 struct Prof {
     bool enabled = false;
     std::vector<ProfCall> calls;     // events recorded since the last collect
     std::vector<ProfCall> pool;      // recycled events
+    std::vector<ProfBwd> bwd;        // backward calls recorded since the last collect
 };
 thread_local Prof g_prof;
 
@@ -59,6 +62,21 @@ ProfCall* prof_begin(hipStream_t s)
 inline void prof_mark(ProfCall* c, int stage_done, hipStream_t s) { if (c) (void)hipEventRecord(c->ev[stage_done + 1], s); }
 
 } // namespace
+
+// backward stage events (f3dg_backward.hip): begin returns a slot or -1; mark(slot, k) closes stage k
+int f3dg_prof_bwd_begin(hipStream_t s)
+{
+    if (!g_prof.enabled) return -1;
+    ProfBwd b;
+    for (int i = 0; i <= BW_COUNT; i++) if (hipEventCreate(&b.ev[i]) != hipSuccess) return -1;
+    g_prof.bwd.push_back(b);
+    (void)hipEventRecord(b.ev[0], s);
+    return (int)g_prof.bwd.size() - 1;
+}
+void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s)
+{
+    if (slot >= 0 && slot < (int)g_prof.bwd.size()) (void)hipEventRecord(g_prof.bwd[slot].ev[stage_done + 1], s);
+}
 
 int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
@@ -87,7 +105,8 @@ extern "C" int f3dg_profile_enable(int on)
 }
 
 // BLOCKING: waits for the recorded events, adds up per-stage milliseconds of every forward call recorded since
-// the previous collect: h_stage_ms[0] preprocess, [1] binning (scan + keys + sort + ranges), [2] compositing.
+// the previous collect: h_stage_ms[0] preprocess, [1] binning (scan + keys + sort + ranges), [2] compositing, and of every
+// f3dg_backward call: [3] compositing backward, [4] per-Gaussian backward. h_stage_ms holds FIVE doubles.
 extern "C" int f3dg_profile_collect(double* h_stage_ms, int* h_calls)
 {
     double sum[ST_COUNT] = { 0, 0, 0 };
@@ -100,9 +119,23 @@ extern "C" int f3dg_profile_collect(double* h_stage_ms, int* h_calls)
         }
         g_prof.pool.push_back(c);
     }
+    double bsum[BW_COUNT] = { 0, 0 };
+    for (ProfBwd& b : g_prof.bwd) {
+        F3DG_HIP_CHECK(hipEventSynchronize(b.ev[BW_COUNT]));
+        for (int i = 0; i < BW_COUNT; i++) {
+            float ms = 0;
+            F3DG_HIP_CHECK(hipEventElapsedTime(&ms, b.ev[i], b.ev[i + 1]));
+            bsum[i] += ms;
+        }
+        for (int i = 0; i <= BW_COUNT; i++) (void)hipEventDestroy(b.ev[i]);
+    }
+    g_prof.bwd.clear();
     if (h_calls) *h_calls = (int)g_prof.calls.size();
     g_prof.calls.clear();
-    if (h_stage_ms) for (int i = 0; i < ST_COUNT; i++) h_stage_ms[i] = sum[i];
+    if (h_stage_ms) {
+        for (int i = 0; i < ST_COUNT; i++) h_stage_ms[i] = sum[i];
+        for (int i = 0; i < BW_COUNT; i++) h_stage_ms[ST_COUNT + i] = bsum[i];
+    }
     return F3DG_OK;
 }
 
@@ -257,7 +290,9 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
     const size_t HW = (size_t)W * H;
 
-    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
+    const int save_aux = (flags & F3DG_FLAG_SAVE_AUX) ? 1 : 0;
+    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered,
+                       (unsigned)f3dg_render_uses_fast(save_aux));
 
     if (P == 0) {
         hipLaunchKernelGGL(fill_background_kernel, dim3(1024), dim3(256), 0, s, n_views, HW, background,
@@ -271,7 +306,6 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
 
     const float focal_y = H / (2.0f * tan_fovy);       // float32, rasterizer_impl.cu:274-275
     const float focal_x = W / (2.0f * tan_fovx);
-    const int save_aux = (flags & F3DG_FLAG_SAVE_AUX) ? 1 : 0;
     int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
 
     ProfCall* prof = prof_begin(s);
@@ -403,6 +437,16 @@ extern "C" int f3dg_read_status(void* stream, const void* workspace, long long* 
     F3DG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (h_num_rendered) *h_num_rendered = (long long)h.num_rendered;
     return h.overflow ? F3DG_ERR_OVERFLOW : F3DG_OK;
+}
+
+extern "C" int f3dg_backward_pairs(void* stream, const void* workspace, long long* h_pairs)
+{
+    if (!workspace || !h_pairs) return F3DG_ERR_BAD_ARG;
+    F3dgHeader h;
+    F3DG_HIP_CHECK(hipMemcpyAsync(&h, workspace, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    F3DG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *h_pairs = (long long)h.bwd_pairs;
+    return F3DG_OK;
 }
 
 extern "C" long long f3dg_forward(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,

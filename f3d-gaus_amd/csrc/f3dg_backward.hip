@@ -378,9 +378,12 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
 //     LDS accumulators (ds_add_f32 / ds_add_f64), then lanes 0..16 each swap one accumulator out and issue ONE global
 //     atomic in parallel. float64 accumulation of dL/dview2gaussian is kept.
 // The position of an entry from the front of the list is computed from its staged slot, so skipped entries need no counter.
-__global__ void __launch_bounds__(F3DG_BLOCK)
+#ifndef F3DG_BWD_OCC
+#define F3DG_BWD_OCC 5          // waves per SIMD the register allocation aims at (96 VGPRs): measured at C5, see DESIGN.md
+#endif
+__global__ void __launch_bounds__(F3DG_BLOCK, F3DG_BWD_OCC)
 render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
-                  const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                  F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
                   const float4* __restrict__ bbox,
                   const float2* __restrict__ means2D, const float4* __restrict__ conic,
@@ -420,6 +423,7 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     __shared__ int block_last_s;
     if (threadIdx.x == 0) block_last_s = 0;
 
+    const bool alpha_fast = hdr->alpha_fast != 0;
     const size_t vP = (size_t)view * P;
     const float4* vbox = bbox + vP;
     const float* fT = final_T + (size_t)view * 4 * HW;
@@ -460,6 +464,7 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     const int block_last = min(block_last_s, (int)(range.y - range.x));      // entries [0, block_last) can contribute
     const int rounds = (block_last + F3DG_BLOCK - 1) / F3DG_BLOCK;
     int toDo = block_last;
+    unsigned n_pairs = 0;                 // contributing (pixel, Gaussian) pairs of this wave
 
     for (int i = 0; i < rounds; i++, toDo -= F3DG_BLOCK) {
         __syncthreads();
@@ -521,23 +526,44 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             if (__ballot(active) == 0)
                 continue;
 
-            const double AA = aaf;
-            const double BB = 2 * bhalf;
             const float CC = q2.y;
             float t = 0, G = 0, alpha = 0;
             if (active) {
-                const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
-                t = (float)(-0.5 * q);
-                if (t <= F3DG_NEAR_PLANE) active = false;
-                const double min_value = -q * (BB / 4.) + CC;
-                float power = (float)(-0.5f * min_value);
-                if (power > 0.0f) power = 0.0f;
-                G = expf(power);
-                alpha = fminf(0.99f, q2.z * G);
+                if (alpha_fast) {
+                    // blend_entry_fast of f3dg_render.hip, operation for operation (the forward of this workspace used it)
+                    const float r = __builtin_amdgcn_rcpf(aaf);
+                    const float t0 = -bhalf * r;
+                    t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+                    if (t < 0.2f) active = false;
+                    const float p = bhalf * bhalf;
+                    const float e = fmaf(bhalf, bhalf, -p);
+                    const float q1 = p * r;
+                    const float q2_ = (fmaf(-q1, aaf, p) + e) * r;
+                    const float min_value = (CC - q1) - q2_;
+                    float power = -0.5f * min_value;
+                    if (power > 0.0f) power = 0.0f;
+                    G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                    alpha = fminf(0.99f, q2.z * G);
+                } else {
+                    const double AA = aaf;
+                    const double BB = 2 * bhalf;
+                    const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
+                    t = (float)(-0.5 * q);
+                    if (t <= F3DG_NEAR_PLANE) active = false;
+                    const double min_value = -q * (BB / 4.) + CC;
+                    float power = (float)(-0.5f * min_value);
+                    if (power > 0.0f) power = 0.0f;
+                    G = expf(power);
+                    alpha = fminf(0.99f, q2.z * G);
+                }
                 if (alpha < 1.0f / 255.0f) active = false;
             }
-            if (__ballot(active) == 0)
-                continue;
+            {
+                const unsigned long long act = __ballot(active);
+                if (act == 0)
+                    continue;
+                n_pairs += (unsigned)__popcll(act);
+            }
 
             float g_col0 = 0, g_col1 = 0, g_col2 = 0, g_mx = 0, g_my = 0, g_mz = 0, g_op = 0;
             float g_v0 = 0, g_v1 = 0, g_v2 = 0, g_v3 = 0, g_v4 = 0, g_v5 = 0, g_v6 = 0, g_v7 = 0, g_v8 = 0, g_v9 = 0;
@@ -547,10 +573,16 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 const float2 xy = staged_xy[j];
                 const float d_x = (float)(xy.x - (pixf_x - 0.5)), d_y = (float)(xy.y - (pixf_y - 0.5));
 
-                const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
-                const float dmax_t_dd = (float)((F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t * t));
-                const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
-                const float nn0 = -n0 / length, nn1 = -n1 / length, nn2 = -n2 / length;
+                // Only alpha has to repeat the forward to the bit (T is rebuilt by dividing by 1 - alpha): its float64 quotient q and
+                // min_value above are the forward's. Everything below is a gradient term that ends in a float32 sum, so the reference's
+                // remaining float64 divisions / square root (backward.cu:783-793, 923-928) are evaluated in float32 with one reciprocal
+                // each (<= 1 ulp; the tests hold the result to 1e-5 of the maximum against the oracle's float64 evaluation):
+                //   mapped = far/(far-near) - (far near/(far-near)) / t,   d mapped/dt = (far near/(far-near)) / t^2
+                const float inv_t = 1.0f / t;
+                const float mapped_max_t = fmaf(-0.20040080160320642f, inv_t, 1.0020040080160322f);
+                const float dmax_t_dd = 0.20040080160320642f * inv_t * inv_t;
+                const float inv_len = 1.0f / sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7f);
+                const float nn0 = -n0 * inv_len, nn1 = -n1 * inv_len, nn2 = -n2 * inv_len;
 
                 Tr = Tr / (1.f - alpha);
                 const float dchannel_dcolor = alpha * Tr;
@@ -582,10 +614,10 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 const float dnn2 = alpha * Tr * dn2;
 
                 float dL_dlength = (dnn0 * n0 + dnn1 * n1 + dnn2 * n2);
-                dL_dlength *= 1.f / (length * length);
-                float dLn0 = (-dnn0 + dL_dlength * n0) / length;
-                float dLn1 = (-dnn1 + dL_dlength * n1) / length;
-                float dLn2 = (-dnn2 + dL_dlength * n2) / length;
+                dL_dlength *= inv_len * inv_len;
+                float dLn0 = (-dnn0 + dL_dlength * n0) * inv_len;
+                float dLn1 = (-dnn1 + dL_dlength * n1) * inv_len;
+                float dLn2 = (-dnn2 + dL_dlength * n2) * inv_len;
 
                 float dL_dt = dL_dmax_t;
                 if (contributor == max_contributor - 1)
@@ -607,11 +639,13 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 
                 const float dL_dpower = dL_dG * G;
                 const float dL_dmin_value = dL_dpower * -0.5f;
-                double dL_dA = dL_dmin_value * (BB / AA) * (BB / AA) / 4.f;
-                double dL_dB = dL_dmin_value * -BB / (2 * AA);
-                const double dL_dC = dL_dmin_value * 1.0f;
-                dL_dA += dL_dt * BB / (2 * AA * AA);
-                dL_dB += dL_dt * -1.f / (2 * AA);
+                // dL/dA = dL/dmin (B/A)^2 / 4 + dL/dt B / (2 A^2),  dL/dB = -dL/dmin B / (2 A) - dL/dt / (2 A): with qf = B/A = -2 t
+                const float qf = -2.0f * t, inv_a = 1.0f / aaf;
+                float dL_dA = dL_dmin_value * qf * qf * 0.25f;
+                float dL_dB = dL_dmin_value * (-0.5f * qf);
+                const float dL_dC = dL_dmin_value;
+                dL_dA += dL_dt * (0.5f * qf * inv_a);
+                dL_dB += dL_dt * (-0.5f * inv_a);
                 dLn0 += dL_dA * ray_x;
                 dLn1 += dL_dA * ray_y;
                 dLn2 += dL_dA;
@@ -622,10 +656,10 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 g_v3 = dLn1 * ray_y;
                 g_v4 = dLn1 + dLn2 * ray_y;
                 g_v5 = dLn2;
-                g_v6 = (float)(dL_dB * 2 * ray_x);
-                g_v7 = (float)(dL_dB * 2 * ray_y);
-                g_v8 = (float)(dL_dB * 2);
-                g_v9 = (float)dL_dC;
+                g_v6 = dL_dB * 2 * ray_x;
+                g_v7 = dL_dB * 2 * ray_y;
+                g_v8 = dL_dB * 2;
+                g_v9 = dL_dC;
             }
 
             // sum the 17 partials over the wave's 64 pixels on the VALU: transposed across the rows (see pair32 / pair16), then
@@ -633,9 +667,11 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             //                     row 0          row 1          row 2          row 3
             const float f0 = row_total(pair16(pair32(g_col0, g_col1), pair32(g_col2, g_mx)));     // col0   col2   col1   mean2D.x
             const float f1 = row_total(pair16(pair32(g_my, g_mz), pair32(g_op, 0.0f)));           // m2D.y  opacity m2D.z  -
-            const double d0 = row_total(pair16(pair32((double)g_v0, (double)g_v1), pair32((double)g_v2, (double)g_v3)));   // v0 v2 v1 v3
-            const double d1 = row_total(pair16(pair32((double)g_v4, (double)g_v5), pair32((double)g_v6, (double)g_v7)));   // v4 v6 v5 v7
-            const double d2 = row_total(pair16(pair32((double)g_v8, (double)g_v9), 0.0));                                  // v8 -  v9 -
+            // (the 64 partials of a wave are summed in float32 -- a fixed order, 64 terms; across waves, tiles and views the sums are
+            // accumulated in float64, which is what keeps the per-Gaussian stage reproducible where the reference's float32 atomics are not)
+            const float d0 = row_total(pair16(pair32(g_v0, g_v1), pair32(g_v2, g_v3)));   // v0 v2 v1 v3
+            const float d1 = row_total(pair16(pair32(g_v4, g_v5), pair32(g_v6, g_v7)));   // v4 v6 v5 v7
+            const float d2 = row_total(pair16(pair32(g_v8, g_v9), 0.0f));                 // v8 -  v9 -
             if ((lane & 15u) == 15u) {
                 const unsigned row = lane >> 4;
                 const unsigned id = staged_id[j];
@@ -646,12 +682,14 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                 if (row < 3) unsafeAtomicAdd(row == 0 ? m + 1 : row == 1 ? dL_dopacity + id : m + 2, f1);
                 double* acc = dL_dv2g_acc + gi * 10;
                 const unsigned perm = row == 0 ? 0u : row == 1 ? 2u : row == 2 ? 1u : 3u;
-                unsafeAtomicAdd(acc + perm, d0);
-                unsafeAtomicAdd(acc + 4 + perm, d1);
-                if ((row & 1u) == 0) unsafeAtomicAdd(acc + 8 + (row >> 1), d2);
+                unsafeAtomicAdd(acc + perm, (double)d0);
+                unsafeAtomicAdd(acc + 4 + perm, (double)d1);
+                if ((row & 1u) == 0) unsafeAtomicAdd(acc + 8 + (row >> 1), (double)d2);
             }
         }
     }
+    if (lane == 0 && n_pairs)
+        atomicAdd(&hdr->bwd_pairs, (unsigned long long)n_pairs);
 }
 
 struct M3 { float m[3][3]; };
@@ -979,7 +1017,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
     if (workspace_bytes < L.total) return F3DG_ERR_WORKSPACE;
     char* ws = static_cast<char*>(workspace);
-    const F3dgHeader* hdr = reinterpret_cast<const F3dgHeader*>(ws + L.header);
+    F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
     const float focal_y = H / (2.0f * tan_fovy);
@@ -989,6 +1027,8 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     // float64 accumulator of dL/dview2gaussian (its own region of the workspace)
     double* acc = reinterpret_cast<double*>(ws + L.bwd_acc);
     F3DG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * 10 * (size_t)n_views * P, s));
+    F3DG_HIP_CHECK(hipMemsetAsync(&hdr->bwd_pairs, 0, sizeof(hdr->bwd_pairs), s));
+    const int prof = f3dg_prof_bwd_begin(s);
 
     const unsigned groups = (unsigned)((n_views + 7) / 8);
     if (g_f3dg_render_cull)
@@ -1008,10 +1048,12 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
                            background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
                            reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
                            acc);
+    f3dg_prof_bwd_mark(prof, 0, s);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, P,
                        D, M, means3D, radii_used, shs, reinterpret_cast<const unsigned char*>(ws + L.clamped), scales,
                        rotations, viewmatrix, cam_pos, acc, dL_dview2gaussian, dL_dcolor, dL_dmean3D, dL_dsh, dL_dscale,
                        dL_drot, n_views);
+    f3dg_prof_bwd_mark(prof, 1, s);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -26,7 +26,11 @@ struct F3dgHeader {
     unsigned int sort_cur;       // which ping-pong half holds the sorted result
     unsigned int n_mid_segments;  // (view, tile) groups of 4033..16320 entries / longer ones: the rare sort tiers return at
     unsigned int n_long_segments; // once when their count is 0
-    unsigned int reserved[58];
+    unsigned int alpha_fast;      // arithmetic the compositing forward of this call used for alpha (1: error-free float32 pairs): the
+                                  // backward must repeat it to the bit
+    unsigned int reserved0;
+    unsigned long long bwd_pairs; // contributing (pixel, Gaussian) pairs of the last f3dg_backward on this workspace ("C" of SURVEY 8d)
+    unsigned int reserved[54];
 };
 
 // Per-(view, Gaussian) record consumed by the compositing kernel: one 64-byte line.
@@ -114,6 +118,9 @@ extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the 
 extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
 extern int g_f3dg_render_kernel;       // 2 (default): render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+int f3dg_prof_bwd_begin(hipStream_t s);
+void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);
+int f3dg_render_uses_fast(int save_aux);       // the arithmetic mode a compositing launch with / without SAVE_AUX takes
 extern int g_f3dg_render_fast;         // 1 (default): float64 island of the blend replaced by error-free float32 pairs in inference
                                        // calls (no SAVE_AUX); 2: also with SAVE_AUX (tests); 0: the reference's float32/float64 order always
 

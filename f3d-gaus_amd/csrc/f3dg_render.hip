@@ -716,6 +716,8 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 
 } // namespace
 
+int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f3dg_render_fast == 1 && !save_aux); }
+
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
@@ -728,7 +730,7 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     // fast arithmetic is for inference calls. A SAVE_AUX forward feeds f3dg_backward, which rebuilds every pixel's transmittance
     // back to front by dividing final_T by (1 - alpha) with ITS alphas: they must be the forward's to the bit, or the 1e-6 relative
     // difference is amplified by 1 / (1 - alpha) per layer (measured at C5: compositing-stage gradients 2.5e-5 vs 1.8e-6 off the oracle).
-    const int g_f3dg_render_fast = ::g_f3dg_render_fast == 2 || (::g_f3dg_render_fast == 1 && !save_aux);
+    const int g_f3dg_render_fast = f3dg_render_uses_fast(save_aux);
     if (g_f3dg_render_kernel == 2) {
 #define F3DG_LAUNCH2(AUX, FST) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \

@@ -254,9 +254,14 @@ int f3dg_set_option(const char* name, int value);
  * bench.py uses for the live roofline figure). f3dg_profile_enable(1) makes every following
  * f3dg_forward_batched on this host thread record 4 events; f3dg_profile_collect() is BLOCKING, sums the
  * milliseconds of all calls recorded since the last collect into h_stage_ms[3] = {projection (preprocess),
- * binning (scan + key duplication + radix sort + tile ranges), compositing} and returns the call count. */
+ * binning (scan + key duplication + radix sort + tile ranges), compositing} and returns the call count; h_stage_ms holds FIVE
+ * doubles: [3] and [4] are the compositing backward and the per-Gaussian backward of the f3dg_backward calls in between. */
 int f3dg_profile_enable(int on);
 int f3dg_profile_collect(double* h_stage_ms, int* h_calls);
+
+/* BLOCKING: number of contributing (pixel, Gaussian) pairs the last f3dg_backward on this workspace blended back through --
+ * "C" of the byte formula 80 R + 60 W H + 68 C of the compositing backward. */
+int f3dg_backward_pairs(void* stream, const void* workspace, long long* h_pairs);
 
 /* Test/inspection hook: device-to-device copies of the library's internal per-call state into caller buffers
  * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the

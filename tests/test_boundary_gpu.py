@@ -161,7 +161,7 @@ def test_profile_and_timing_hooks(gpu_device):
     L.f3dg_profile_enable(1)
     _batched(d, save_aux=False); _batched(d, save_aux=False)
     L.f3dg_profile_enable(0)
-    ms = (C.c_double * 3)(); n = C.c_int(0)
-    assert L.f3dg_profile_collect(ms, C.byref(n)) == 0 and n.value == 2 and all(0 < m < 100 for m in ms)
+    ms = (C.c_double * 5)(); n = C.c_int(0)
+    assert L.f3dg_profile_collect(ms, C.byref(n)) == 0 and n.value == 2 and all(0 < m < 100 for m in ms[:3]) and ms[3] == ms[4] == 0
     t = (C.c_ulonglong * 8)(*([7] * 8))
     assert L.f3dg_debug_timing(t, 1) == 0 and list(t) == [0] * 8      # product build: the counters are compiled out
