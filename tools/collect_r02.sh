@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-2 evidence run on the GPU box (everything under gpurun_out/<tag>/): the default bench line, the same command under
+# rocprofv3 --kernel-trace --stats, separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ), the exact-mode line, C5 (forward + backward)
+# with its kernel stats and PMC passes, C4-shaped lines (fp32 / bf16 backbone), the parity report and the GPU test log.
+TAG=${1:-r02}
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp
+python $R/bench.py > $O/bench_default.log 2>&1
+python $R/bench.py --render-mode exact --no-cpu-baseline > $O/bench_exact.log 2>&1
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-d2h"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $O/pmc_sq -o bench -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_sq2 -o bench -- $B > /dev/null 2>&1
+rm -f $O/stats/bench_kernel_trace.csv
+# C5
+C5="python $R/bench.py --workload c5 --steps 3 --warmup 1"
+$C5 > $O/bench_c5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -o c5 -- $C5 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c5_pmc_fetch -o c5 -- $C5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c5_pmc_write -o c5 -- $C5 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $O/c5_pmc_sq -o c5 -- $C5 > /dev/null 2>&1
+rm -f $O/c5_stats/c5_kernel_trace.csv
+# C4 shape (C3 at one GPU)
+python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 > $O/bench_c4_fp32.log 2>&1
+python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone bf16 > $O/bench_c4_bf16.log 2>&1
+python $R/bench.py --workload c4 --images 64 --steps 1 --warmup 1 --backbone bf16 > $O/bench_c4_bf16_64.log 2>&1
+cd $R
+python tests/tools/parity_report.py > $O/parity_report.md 2>&1
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
+tail -3 $O/pytest_gpu.log
+for f in bench_default bench_exact bench_c5 bench_c4_fp32 bench_c4_bf16 bench_c4_bf16_64; do grep '^{' $O/$f.log | tail -1 | cut -c1-330; done
