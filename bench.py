@@ -138,6 +138,8 @@ def main():
     _lib.check(L.f3dg_set_option(b"render_fast", 1 if args.render_mode == "fast" else 0), "f3dg_set_option")
     if os.environ.get("F3DG_DEBUG_SKIP_ALL"):    # experiment: no Gaussian ever passes -> the compositing kernel only stages
         _lib.check(L.f3dg_set_option(b"debug_skip_all", 1), "f3dg_set_option")
+    if os.environ.get("F3DG_RENDER_ROUND"):       # A/B: list entries staged per round by render2 (256 / 192 / 128)
+        _lib.check(L.f3dg_set_option(b"render_round", int(os.environ["F3DG_RENDER_ROUND"])), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
     result = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, rank, world, dist, device, comm_device, f3d, L)

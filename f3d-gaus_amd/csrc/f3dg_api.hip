@@ -83,6 +83,7 @@ int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 2;
+int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
@@ -91,6 +92,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : 2; return F3DG_OK; }
+    if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
@@ -160,7 +162,9 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     const size_t C = (size_t)(cap > 0 ? cap : 1);
     L.sort_blocks = (unsigned)((C + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK);
     const size_t scan_a = (VP + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
-    const size_t scan_b = ((size_t)256 * L.sort_blocks + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
+    const size_t gsort_blocks = (size_t)V * (((size_t)(P > 0 ? P : 1) + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK);      // (view, chunk) blocks of the depth sort
+    const size_t hist_blocks = gsort_blocks > L.sort_blocks ? gsort_blocks : L.sort_blocks;
+    const size_t scan_b = ((size_t)256 * hist_blocks + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
     const size_t scan_c = ((size_t)V * T + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
     L.scan_tmp_elems = (unsigned)((scan_a > scan_b ? (scan_a > scan_c ? scan_a : scan_c) : (scan_b > scan_c ? scan_b : scan_c)) + 1);
 
@@ -177,18 +181,18 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.tiles = take(VP * sizeof(unsigned));
     L.offsets = take(VP * sizeof(unsigned));
     L.clamped = take(VP);
+    L.rects = take(VP * sizeof(uint2));
+    L.gsort = take(4 * VP * sizeof(unsigned));
     L.scan_tmp = take((size_t)L.scan_tmp_elems * sizeof(unsigned));
     L.keys[0] = take(C * 8);
     L.keys[1] = take(C * 8);
     L.vals[0] = take(C * 4);
     L.vals[1] = take(C * 4);
-    L.keys[2] = take(C * 8);
-    L.vals[2] = take(C * 4);
     L.gstart = take((size_t)2 * V * T * sizeof(unsigned));          // gstart[V*T] immediately followed by gend[V*T]
     L.gend = L.gstart + (size_t)V * T * sizeof(unsigned);
     L.gcount = take((size_t)V * T * sizeof(unsigned));
     {   // radix histograms [256][sort_blocks]; also reused for the inclusive scan of the V*T group sizes
-        const size_t h = (size_t)256 * L.sort_blocks, gseg = (size_t)V * T;
+        const size_t h = (size_t)256 * hist_blocks, gseg = (size_t)V * T;
         L.hist = take((h > gseg ? h : gseg) * sizeof(unsigned));
     }
     L.ranges = take((size_t)V * T * sizeof(uint2));
@@ -234,7 +238,8 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
                                     reinterpret_cast<F3dgRec*>(ws + L.rec), reinterpret_cast<float2*>(ws + L.means2D),
-                                    reinterpret_cast<float*>(ws + L.depths),
+                                    reinterpret_cast<float*>(ws + L.depths), reinterpret_cast<unsigned*>(ws + L.gsort),
+                                    reinterpret_cast<uint2*>(ws + L.rects),
                                     need_box ? reinterpret_cast<float4*>(ws + L.bbox) : nullptr,
                                     reinterpret_cast<float4*>(ws + L.cull),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
@@ -242,7 +247,7 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_PREPROCESS, s);
-    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, radii_used, save_aux);
+    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, save_aux);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_BINNING, s);
     return F3DG_OK;
@@ -487,6 +492,10 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
     const size_t VP = (size_t)n_views * P, HW = (size_t)W * H;
     const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
     const size_t C = (size_t)max_rendered;
+    if (keys_sorted && P > 0) {      // the 64-bit keys are not kept by the forward: rebuild them from the final list
+        const int rck = f3dg_launch_export_keys(s, n_views, P, W, H, L, const_cast<char*>(ws));
+        if (rck != F3DG_OK) return rck;
+    }
 #define CP(dst, off, bytes) if (dst && (bytes)) F3DG_HIP_CHECK(hipMemcpyAsync(dst, ws + (off), (bytes), hipMemcpyDeviceToDevice, s))
     CP(rec, L.rec, VP * sizeof(F3dgRec));
     CP(means2D, L.means2D, VP * 8);

@@ -23,9 +23,7 @@ struct F3dgHeader {
     unsigned int num_rendered;   // total (Gaussian, tile) instances of the call (all views)
     unsigned int overflow;       // 1 if num_rendered > capacity
     unsigned int capacity;       // instance capacity the workspace was carved for
-    unsigned int sort_cur;       // which ping-pong half holds the sorted result
-    unsigned int n_mid_segments;  // (view, tile) groups of 4033..16320 entries / longer ones: the rare sort tiers return at
-    unsigned int n_long_segments; // once when their count is 0
+    unsigned int reserved1[3];
     unsigned int alpha_fast;      // arithmetic the compositing forward of this call used for alpha (1: error-free float32 pairs): the
                                   // backward must repeat it to the bit
     unsigned int reserved0;
@@ -55,9 +53,13 @@ struct F3dgLayout {
     size_t tiles;          // [V*P] u32   tiles_touched
     size_t offsets;        // [V*P] u32   inclusive scan of tiles_touched
     size_t clamped;        // [V*P] u8    bit c set when SH colour channel c was clamped
+    size_t rects;          // [V*P] uint2: tile rectangle of every (view, Gaussian) (rminx | rmaxx << 16, rminy | rmaxy << 16)
+    size_t gsort;          // [4][V*P] u32: ping-pong (key, id) buffers of the per-view depth sort of the Gaussians; reused for the
+                           // tiles_touched / prefix sum in sorted order
     size_t scan_tmp;       // u32 block sums for the scans
-    size_t keys[3];        // [cap] u64: [0] final (tile, depth)-sorted, [1] tile-grouped / ping-pong, [2] scratch of long tile sorts
-    size_t vals[3];        // [cap] u32, same roles; vals[0] is the compositing kernel's point list
+    size_t keys[2];        // [cap] 8 B: group stream (u16 / u32 per instance) of the two ping-pong halves; [0] also holds the
+                           // rebuilt 64-bit keys of the debug export
+    size_t vals[2];        // [cap] u32 Gaussian ids of the halves; vals[0] ends as the compositing kernel's point list
     size_t gstart, gend, gcount;   // [V*T] u32 each: (view, tile) group bounds in the tile-grouped buffer and sizes
     size_t hist;           // [256 * sort_blocks] u32
     size_t ranges;         // [V*T] uint2
@@ -102,16 +104,16 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox /* may be null */, float4* cull, float4* conic,
+                           F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox /* may be null */, float4* cull, float4* conic,
                            int* radii, unsigned* tiles, unsigned char* clamped, int save_aux);
 
 int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out, unsigned long long n,
                                unsigned* tmp, unsigned tmp_elems, int exclusive,
                                F3dgHeader* hdr_total /* if not null: write total + overflow */);
 
-// keep_keys: also write the final u64 sort keys (only the debug export reads them; the inference path skips 8 B/instance)
-int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, const int* radii,
-                        int keep_keys);
+// export_offsets: also compute the reference's (view, Gaussian)-ordered prefix sum of tiles_touched (debug export only)
+int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws, int export_offsets);
+int f3dg_launch_export_keys(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws);
 
 extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test enabled; 0: plain path (A/B, tests)
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
@@ -121,6 +123,7 @@ extern int g_f3dg_render_kernel;       // 2 (default): render2 (Gaussians across
 int f3dg_prof_bwd_begin(hipStream_t s);
 void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);
 int f3dg_render_uses_fast(int save_aux);       // the arithmetic mode a compositing launch with / without SAVE_AUX takes
+extern int g_f3dg_render_round;        // list entries render2 stages per round in fast arithmetic: 192 (default, 7 workgroups per CU) or 256 (6)
 extern int g_f3dg_render_fast;         // 1 (default): float64 island of the blend replaced by error-free float32 pairs in inference
                                        // calls (no SAVE_AUX); 2: also with SAVE_AUX (tests); 0: the reference's float32/float64 order always
 

@@ -195,6 +195,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                   const float* __restrict__ cam_positions, int W, int H, int grid_x, int grid_y,
                   float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                   F3dgRec* __restrict__ rec, float2* __restrict__ means2D, float* __restrict__ depths_out,
+                  unsigned* __restrict__ sort_keys, uint2* __restrict__ rects,
                   float4* __restrict__ bbox_out, float4* __restrict__ cull_out,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
@@ -219,6 +220,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
     float cec = 1.0e30f;
     unsigned char clamp_bits = 0;
     float depth = 0.0f;
+    uint2 rect = make_uint2(0u, 0u);          // tile rectangle (rminx | rmaxx << 16, rminy | rmaxy << 16): empty unless visible
 
     const float px_ = means3D[3 * gs], py_ = means3D[3 * gs + 1], pz_ = means3D[3 * gs + 2];
 
@@ -414,6 +416,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                 const float opac = opacities[gs] * coef;
                 my_radii = max_radius;
                 my_tiles = (unsigned)area;
+                rect = make_uint2((unsigned)rminx | ((unsigned)rmaxx << 16), (unsigned)rminy | ((unsigned)rmaxy << 16));
                 xy = make_float2(pix_x, pix_y);
                 con = make_float4(conic_x, conic_y, conic_z, opac);
                 r0 = make_float4(vg[0], vg[1], vg[2], vg[3]);
@@ -444,6 +447,8 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
     tiles_touched[idx] = my_tiles;
     means2D[idx] = xy;
     depths_out[idx] = depth;
+    rects[idx] = rect;
+    sort_keys[idx] = my_tiles ? __float_as_uint(depth) : 0xFFFFFFFFu;      // key of the per-view depth sort (f3dg_binning.hip)
     if (bbox_out) bbox_out[idx] = box;
     cull_out[idx] = ce;
     r3.w = cec;                             // record slot 15: the ellipse's c (the depth lives in depths_out)
@@ -472,7 +477,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* cov3D_precomp, const float* colors_precomp, const float* v2g_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                           F3dgRec* rec, float2* means2D, float* depths, float4* bbox, float4* cull, float4* conic, int* radii,
+                           F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox, float4* cull, float4* conic, int* radii,
                            unsigned* tiles, unsigned char* clamped, int save_aux)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
@@ -480,7 +485,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
-                       depths, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
+                       depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -514,8 +514,8 @@ __device__ __forceinline__ void ellipse_ballots(int& stage, float Ep, const floa
     }
 }
 
-template <bool SAVE_AUX, bool FAST>
-__global__ void __launch_bounds__(F3DG_BLOCK, 6)
+template <bool SAVE_AUX, bool FAST, int ROUND, int OCC>
+__global__ void __launch_bounds__(F3DG_BLOCK, OCC)
 render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
@@ -545,16 +545,16 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 
     uint2 range = ranges[(size_t)view * T + tile];
     if (hdr->overflow) range = make_uint2(0, 0);
-    const int rounds = (int)((range.y - range.x + F3DG_BLOCK - 1) / F3DG_BLOCK);
+    const int rounds = (int)((range.y - range.x + ROUND - 1) / ROUND);      // ROUND list entries are staged per round
 
-    __shared__ float4 sA[F3DG_BLOCK];            // v0 v1 v2 v3
-    __shared__ float4 sB[F3DG_BLOCK];            // v4 v5 v6 v7
-    __shared__ float4 sC[F3DG_BLOCK];            // v8 v9 opacity r
-    __shared__ float2 sD[F3DG_BLOCK];            // g b
-    __shared__ float4 sE[F3DG_BLOCK];            // ellipse: cx cy a b
-    __shared__ float sF[F3DG_BLOCK];             //          c
-    __shared__ unsigned short sM[F3DG_BLOCK];    // which of the tile's 16 4x4 blocks the ellipse's box touches
-    __shared__ __align__(16) unsigned char lists[F3DG_BLOCK / 64][4][F3DG_BLOCK];     // per wave, per 16-lane group
+    __shared__ float4 sA[ROUND];            // v0 v1 v2 v3
+    __shared__ float4 sB[ROUND];            // v4 v5 v6 v7
+    __shared__ float4 sC[ROUND];            // v8 v9 opacity r
+    __shared__ float2 sD[ROUND];            // g b
+    __shared__ float4 sE[ROUND];            // ellipse: cx cy a b
+    __shared__ float sF[ROUND];             //          c
+    __shared__ unsigned short sM[ROUND];    // which of the tile's 16 4x4 blocks the ellipse's box touches
+    __shared__ __align__(16) unsigned char lists[F3DG_BLOCK / 64][4][ROUND];     // per wave, per 16-lane group
     __shared__ int done_cnt[2];
     if (threadIdx.x < 2) done_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -587,9 +587,9 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
         if (num_done == F3DG_BLOCK)
             break;
 
-        const unsigned progress = (unsigned)i * F3DG_BLOCK + threadIdx.x;
+        const unsigned progress = (unsigned)i * ROUND + threadIdx.x;
         unsigned short m16 = 0;
-        if (range.x + progress < range.y) {
+        if (threadIdx.x < ROUND && range.x + progress < range.y) {
             const unsigned id = point_list[range.x + progress];
             const float4* src = reinterpret_cast<const float4*>(vrec + id);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
@@ -602,7 +602,7 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             sF[threadIdx.x] = d.w;
             m16 = (unsigned short)ellipse_block_mask(e0, d.w, tile_px0, tile_py0);
         }
-        sM[threadIdx.x] = m16;
+        if (threadIdx.x < ROUND) sM[threadIdx.x] = m16;
         F3DG_T_MARK(1);
         __syncthreads();
         F3DG_T_MARK(0);
@@ -614,7 +614,7 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             const bool g0 = (alive & 0xFFFFull) != 0, g1 = (alive & 0xFFFF0000ull) != 0, g2 = (alive & 0xFFFF00000000ull) != 0,
                        g3 = (alive >> 48) != 0;
 #pragma unroll
-            for (int c = 0; c < F3DG_BLOCK / 64; c++) {
+            for (int c = 0; c < ROUND / 64; c++) {
                 const unsigned e = c * 64 + lane;
                 const unsigned m = sM[e];
                 const bool b0 = g0 && ((m >> ((qy2 + 0u) * 4u + qx2 + 0u)) & 1u), b1 = g1 && ((m >> ((qy2 + 0u) * 4u + qx2 + 1u)) & 1u);
@@ -633,7 +633,7 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
         F3DG_T_MARK(2);
         const int count = max(max(c0, c1), max(c2, c3));
         const int my_len = grp == 0 ? c0 : grp == 1 ? c1 : grp == 2 ? c2 : c3;
-        const unsigned round_base = (unsigned)i * F3DG_BLOCK;
+        const unsigned round_base = (unsigned)i * ROUND;
 
         for (int w0 = 0; w0 < count; w0 += 64) {
             // ---- phase 1: lane (g, e) tests entry w0 + 16 sub + e of group g's list against the 16 pixels of g's block
@@ -732,11 +732,15 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     // difference is amplified by 1 / (1 - alpha) per layer (measured at C5: compositing-stage gradients 2.5e-5 vs 1.8e-6 off the oracle).
     const int g_f3dg_render_fast = f3dg_render_uses_fast(save_aux);
     if (g_f3dg_render_kernel == 2) {
-#define F3DG_LAUNCH2(AUX, FST) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
+#define F3DG_LAUNCH2R(AUX, FST, RND, OCC) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST, RND, OCC>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \
                                                   out_color, final_T, n_contrib)
+        // fast arithmetic fits 72 VGPRs: 192-entry rounds (18 KB of LDS) run 7 workgroups per CU, 2.53 vs 2.66 ms at C2; the exact
+        // arithmetic needs 80: 256-entry rounds, 6 per CU. (8 per CU spill at 64 VGPRs and measure 2.55 ms; 128-entry rounds 2.64 ms.)
+#define F3DG_LAUNCH2(AUX, FST) do { if (FST && g_f3dg_render_round == 192) F3DG_LAUNCH2R(AUX, FST, 192, 7); else F3DG_LAUNCH2R(AUX, FST, 256, 6); } while (0)
         if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH2(true, true); else F3DG_LAUNCH2(true, false); }
         else { if (g_f3dg_render_fast) F3DG_LAUNCH2(false, true); else F3DG_LAUNCH2(false, false); }
+#undef F3DG_LAUNCH2R
 #undef F3DG_LAUNCH2
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
