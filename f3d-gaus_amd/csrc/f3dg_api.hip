@@ -85,6 +85,7 @@ int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 2;
 int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
+int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
 extern "C" int f3dg_set_option(const char* name, int value)
@@ -96,6 +97,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
     return F3DG_ERR_BAD_ARG;
 }
@@ -232,7 +234,7 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* cam_pos, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                 int* radii_used, int save_aux, int need_box, ProfCall* prof)
+                 int* radii_used, int save_aux, int need_box, int tile_cull, ProfCall* prof)
 {
     int rc = f3dg_launch_preprocess(s, n_views, views_per_set, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
@@ -244,7 +246,7 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     reinterpret_cast<float4*>(ws + L.cull),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
-                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux);
+                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux, tile_cull);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_PREPROCESS, s);
     rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, save_aux);
@@ -317,7 +319,7 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     rc = run_geometry(s, ws, L, n_views, views_per_set, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                       tan_fovy, focal_x, focal_y, kernel_size, radii_used, save_aux,
-                      save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, prof);
+                      save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, g_f3dg_tile_cull, prof);
     if (rc != F3DG_OK) return rc;
 
     rc = f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
@@ -367,7 +369,8 @@ extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_
     int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
     rc = run_geometry(s, ws, L, 1, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, 1 /* pass 1 culls by the box */, nullptr);
+                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, 1 /* pass 1 culls by the box */,
+                      0 /* the points of a tile are not its pixel centres: the reference's tile lists */, nullptr);
     if (rc != F3DG_OK) return rc;
     rc = f3dg_launch_integrate_pass1(s, W, H, focal_x, focal_y, L, I, ws, background, out_color);
     if (rc != F3DG_OK) return rc;

@@ -105,7 +105,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox /* may be null */, float4* cull, float4* conic,
-                           int* radii, unsigned* tiles, unsigned char* clamped, int save_aux);
+                           int* radii, unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull);
 
 int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out, unsigned long long n,
                                unsigned* tmp, unsigned tmp_elems, int exclusive,

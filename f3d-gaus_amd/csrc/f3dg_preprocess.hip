@@ -199,7 +199,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                   float4* __restrict__ bbox_out, float4* __restrict__ cull_out,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
-                  unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all)
+                  unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all, int tile_cull)
 {
     const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
@@ -436,6 +436,30 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                         box = conservative_box(cq, thr, have_scale, W, H, focal_x, focal_y);
                     conservative_ellipse(cq, thr, have_scale, W, H, focal_x, focal_y, ce, cec);
                 }
+                if (tile_cull) {
+                    // Tile culling (option "tile_cull"): the reference instantiates the Gaussian in every tile of the square around
+                    // its 3-sigma circle (rect above); only tiles that the axis-aligned box of the conservative ellipse reaches can
+                    // hold a pixel with alpha >= 1/255, the others would be a bare `continue` for each of their pixels.
+                    const float edet = fmaf(ce.z, cec, -0.25f * ce.w * ce.w);
+                    if (edet > 0.0f) {
+                        const float hx = sqrtf(cec / edet) * 1.0005f + 2e-3f, hy = sqrtf(ce.z / edet) * 1.0005f + 2e-3f;
+                        // tile t holds the pixel centres 16 t .. 16 t + 15
+                        const float inv_tile = 1.0f / (float)F3DG_TILE;
+                        const float lx = ceilf((ce.x - hx - (float)(F3DG_TILE - 1)) * inv_tile), ux = floorf((ce.x + hx) * inv_tile) + 1.0f;
+                        const float ly = ceilf((ce.y - hy - (float)(F3DG_TILE - 1)) * inv_tile), uy = floorf((ce.y + hy) * inv_tile) + 1.0f;
+                        const int cminx = max(rminx, (int)fminf(fmaxf(lx, 0.0f), (float)grid_x));
+                        const int cmaxx = min(rmaxx, (int)fminf(fmaxf(ux, 0.0f), (float)grid_x));
+                        const int cminy = max(rminy, (int)fminf(fmaxf(ly, 0.0f), (float)grid_y));
+                        const int cmaxy = min(rmaxy, (int)fminf(fmaxf(uy, 0.0f), (float)grid_y));
+                        if (cmaxx > cminx && cmaxy > cminy) {
+                            my_tiles = (unsigned)((cmaxx - cminx) * (cmaxy - cminy));
+                            rect = make_uint2((unsigned)cminx | ((unsigned)cmaxx << 16), (unsigned)cminy | ((unsigned)cmaxy << 16));
+                        } else {
+                            my_tiles = 0;
+                            rect = make_uint2(0u, 0u);
+                        }
+                    }
+                }
                 r2 = make_float4(vg[8], vg[9], opac, Kpre);
                 r3 = make_float4(cr, cg, cb, 0.0f);
                 depth = pvz;
@@ -478,14 +502,14 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox, float4* cull, float4* conic, int* radii,
-                           unsigned* tiles, unsigned char* clamped, int save_aux)
+                           unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
-                       depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all);
+                       depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all, tile_cull);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -247,7 +247,18 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
  * of a tile walks only the staged Gaussians whose conservative alpha >= 1/255 box touches it; also bit-identical.
  * "render_queue" (default 1): two-phase compositing loop (cheap test for 64 entries, then per-pixel queues of the passing
  * ones); also bit-identical. "sort_wide_groups" (default 0): forces the 32-bit (view, tile) stream of the binning stage, which
- * is otherwise only used when views << tile_bits exceeds 16 bits (tests). Returns F3DG_ERR_BAD_ARG for unknown names. */
+ * is otherwise only used when views << tile_bits exceeds 16 bits (tests).
+ * "render_kernel" (default 2): 2 = Gaussians across the lanes + conservative ellipse (render2), 1 = the round-1 pixel-lane kernel.
+ * "render_round" (default 192): list entries a workgroup of render2 stages per round (192 at 7 waves/SIMD or 256 at 6).
+ * "render_fast" (default 1): arithmetic of the compositing forward: 0 = the reference's float32 / float64 operation order,
+ * 1 = error-free float32 pairs in inference calls (no auxiliary planes; within 3e-7 of mode 0), exact in calls a backward follows,
+ * 2 = fast in every call.
+ * "tile_cull" (default 1): a Gaussian is instantiated only in the tiles that the box of its conservative alpha >= 1/255 ellipse
+ * reaches instead of every tile of the reference's 3-sigma square (forward.cu:364-374). The dropped (Gaussian, tile) pairs are a
+ * bare `continue` for every pixel of the tile, so all outputs and gradients are unchanged (asserted by the tests on every
+ * scene); num_rendered and the exported lists are then SHORTER than the reference's. 0 = the reference's lists, bit for bit.
+ * f3dg_integrate always uses the reference's lists.
+ * Returns F3DG_ERR_BAD_ARG for unknown names. */
 int f3dg_set_option(const char* name, int value);
 
 /* Optional per-stage timing of the forward path with HIP events recorded on the caller's stream (this is what

@@ -64,6 +64,28 @@ def run_oracle(scene, view=0):
 def run_hip(scene, device, save_aux=True, max_rendered=None):
     """All views of the scene through f3dg_forward_batched; returns outputs + exported internal state (numpy)."""
     dev = lambda t: None if t is None else t.to(device)
+    # The exported lists are compared with the reference's, so they are built without tile culling (option "tile_cull" = 0). The
+    # default (culled lists: a Gaussian is instantiated only in the tiles its conservative ellipse reaches) must give the same
+    # images to the bit with no more instances: checked here on every scene that goes through this helper.
+    culled = None
+    if max_rendered is None:
+        culled = f3d.rasterize_views(
+            dev(scene["means3D"]), dev(scene["opacities"]), dev(scene["viewmatrix"]), dev(scene["projmatrix"]),
+            dev(scene["campos"]), dev(scene["bg"]), image_height=scene["H"], image_width=scene["W"],
+            tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], sh=dev(scene["shs"]),
+            colors_precomp=dev(scene["colors_precomp"]), scales=dev(scene["scales"]), rotations=dev(scene["rotations"]),
+            sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"], kernel_size=scene["kernel_size"],
+            save_aux=save_aux)
+        culled = (culled[0].clone(), culled[1].clone(), culled[2].num_rendered)
+    assert _lib.lib().f3dg_set_option(b"tile_cull", 0) == 0
+    try:
+        return _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled)
+    finally:
+        _lib.lib().f3dg_set_option(b"tile_cull", 1)
+
+
+def _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled):
+    dev = lambda t: None if t is None else t.to(device)
     out, radii, ws = f3d.rasterize_views(
         dev(scene["means3D"]), dev(scene["opacities"]), dev(scene["viewmatrix"]), dev(scene["projmatrix"]),
         dev(scene["campos"]), dev(scene["bg"]), image_height=scene["H"], image_width=scene["W"],
@@ -95,6 +117,8 @@ def run_hip(scene, device, save_aux=True, max_rendered=None):
                                                      "point_list", "ranges", "final_T", "n_contrib", "depths")])
         assert rc == 0
     torch.cuda.synchronize()
+    if culled is not None:
+        assert torch.equal(culled[0], out) and torch.equal(culled[1], radii) and culled[2] <= R, "tile culling changed the result"
     rec = e["rec"].cpu().numpy().reshape(V, max(P, 1), 16)
     res = dict(
         out_color=out.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R,

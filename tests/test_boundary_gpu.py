@@ -86,7 +86,16 @@ def test_integration_md_C_shim_verbatim(gpu_device):
     n2, out2, alpha_i, color_i, radii2, *_ = shim_C.integrate_gaussians_to_points(*iargs)
     c, a, ci, r = f3d.GaussianRasterizer_GOF(rs).integrate(pts, d["means3D"], None, d["opacities"], shs=d["shs"], scales=d["scales"],
                                                             rotations=d["rotations"])
-    assert torch.equal(out2, c) and torch.equal(alpha_i, a) and torch.equal(color_i, ci) and torch.equal(radii2, r) and n2 == n
+    assert torch.equal(out2, c) and torch.equal(alpha_i, a) and torch.equal(color_i, ci) and torch.equal(radii2, r)
+    # integrate always walks the reference's tile lists; the forward's default lists are tile-culled (f3dg.h "tile_cull")
+    assert n2 >= n
+    L = _lib.lib()
+    L.f3dg_set_option(b"tile_cull", 0)
+    try:
+        n0, color0, *_ = shim_C.rasterize_gaussians(*args)
+    finally:
+        L.f3dg_set_option(b"tile_cull", 1)
+    assert n0 == n2 and torch.equal(color0, color)
 
 
 def test_debug_true_dumps_arguments_on_failure(gpu_device, tmp_path, monkeypatch):
