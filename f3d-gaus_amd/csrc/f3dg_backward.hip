@@ -141,12 +141,8 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
                   float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
                   double* __restrict__ dL_dv2g_acc)
 {
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned slot = blockIdx.x >> 3;
-    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
-    const unsigned tile = slot % (unsigned)T;
-    if (view >= (unsigned)V)
-        return;
+    unsigned view, tile;                      // all tiles of a view share one XCD's L2 for the record gather
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, (unsigned)T, view, tile);
 
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
     const unsigned lx = threadIdx.x & 15u, ly = threadIdx.x >> 4;
@@ -393,12 +389,8 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                   float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
                   double* __restrict__ dL_dv2g_acc)
 {
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned slot = blockIdx.x >> 3;
-    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
-    const unsigned tile = slot % (unsigned)T;
-    if (view >= (unsigned)V)
-        return;
+    unsigned view, tile;                      // all tiles of a view share one XCD's L2 for the record gather
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, (unsigned)T, view, tile);
 
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1030,9 +1022,8 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     F3DG_HIP_CHECK(hipMemsetAsync(&hdr->bwd_pairs, 0, sizeof(hdr->bwd_pairs), s));
     const int prof = f3dg_prof_bwd_begin(s);
 
-    const unsigned groups = (unsigned)((n_views + 7) / 8);
     if (g_f3dg_render_cull)
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(groups * 8u * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
+        hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
                            reinterpret_cast<const float4*>(ws + L.bbox),
@@ -1041,7 +1032,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
                            reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
                            acc);
     else     // option render_cull = 0: the lock-step kernel (every lane visits every entry, wave butterflies), kept for A/B
-        hipLaunchKernelGGL(render_bwd_lockstep_kernel, dim3(groups * 8u * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
+        hipLaunchKernelGGL(render_bwd_lockstep_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
                            reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),

@@ -162,7 +162,8 @@ radix2_hist_kernel(const K* __restrict__ keys, const F3dgHeader* __restrict__ hd
 #pragma unroll
     for (int w = 0; w < F3DG_BLOCK / 64; w++) h[w][threadIdx.x] = 0;
     __syncthreads();
-    const u32 seg = blockIdx.x / cps, c = blockIdx.x % cps;
+    u32 seg = 0, c = blockIdx.x;
+    if (!hdr) f3dg_xcd_map(blockIdx.x, gridDim.x / cps, cps, seg, c);      // a view's chunks on one XCD: its key segment stays in that L2
     const u32 n = hdr ? (hdr->overflow ? 0u : hdr->num_rendered) : seg_len;
     const u64 seg_base = (u64)seg * seg_len;
     const u64 base = (u64)c * F3DG_SORT_CHUNK;
@@ -201,7 +202,8 @@ radix2_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ val
     __shared__ u32 wtot[F3DG_BLOCK / 64];
     __shared__ K skey[F3DG_SORT_CHUNK];
     __shared__ u32 sval[F3DG_SORT_CHUNK];
-    const u32 seg = blockIdx.x / cps, c = blockIdx.x % cps;
+    u32 seg = 0, c = blockIdx.x;
+    if (!hdr) f3dg_xcd_map(blockIdx.x, gridDim.x / cps, cps, seg, c);      // the scattered writes of a view merge in one XCD's L2
     const u32 n = hdr ? (hdr->overflow ? 0u : hdr->num_rendered) : seg_len;
     const u64 seg_base = (u64)seg * seg_len;
     const u64 block_base = (u64)c * F3DG_SORT_CHUNK;
@@ -292,9 +294,12 @@ __global__ void __launch_bounds__(F3DG_BLOCK)
 gsort_gather_rects_kernel(int P, const u32* __restrict__ perm, const uint2* __restrict__ rects, u32* __restrict__ tiles_sorted,
                           u32* __restrict__ rx, u32* __restrict__ ry)
 {
-    const int k = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    unsigned view, chunk;                     // a view's rectangles (8 P bytes) are gathered through one XCD's L2
+    const unsigned cpv = (unsigned)((P + F3DG_BLOCK - 1) / F3DG_BLOCK);
+    f3dg_xcd_map(blockIdx.x, gridDim.x / cpv, cpv, view, chunk);
+    const int k = (int)(chunk * F3DG_BLOCK + threadIdx.x);
     if (k >= P) return;
-    const size_t vb = (size_t)blockIdx.y * P;
+    const size_t vb = (size_t)view * P;
     const uint2 r = rects[vb + perm[vb + k]];
     tiles_sorted[vb + k] = ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));
     rx[vb + k] = r.x;
@@ -479,7 +484,7 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
     u32* ry = gv[cur ^ 1];
 
     // 2. instances in (view, depth, id) order
-    hipLaunchKernelGGL(gsort_gather_rects_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, P, perm, reinterpret_cast<const uint2*>(ws + L.rects),
+    hipLaunchKernelGGL(gsort_gather_rects_kernel, dim3(pgrid.x * pgrid.y), dim3(F3DG_BLOCK), 0, s, P, perm, reinterpret_cast<const uint2*>(ws + L.rects),
                        offsets_sorted, rx, ry);
     rc = f3dg_launch_scan_inclusive(s, offsets_sorted, offsets_sorted, (unsigned long long)VP, scan_tmp, L.scan_tmp_elems, 0, hdr);
     if (rc != F3DG_OK) return rc;

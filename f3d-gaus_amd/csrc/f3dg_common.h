@@ -18,6 +18,23 @@
 #define F3DG_SCAN_ITEMS 16
 #define F3DG_SCAN_CHUNK (F3DG_BLOCK * F3DG_SCAN_ITEMS)
 
+// XCD-aware (view, unit) of workgroup b of a V * U grid. Consecutive workgroup ids land on different XCDs (id % 8); the views are
+// handed out in groups of 8, one view per XCD, so that all units (tiles, sort chunks) of a view share one XCD's L2. The last
+// V % 8 views are spread over all XCDs unit by unit (a single-view call uses the whole chip).
+__device__ __forceinline__ void f3dg_xcd_map(unsigned b, unsigned V, unsigned U, unsigned& view, unsigned& unit)
+{
+    const unsigned full = (V & ~7u) * U;
+    if (b < full) {
+        const unsigned slot = b >> 3;
+        view = (slot / U) * 8u + (b & 7u);
+        unit = slot % U;
+    } else {
+        const unsigned r = b - full;
+        view = (V & ~7u) + r / U;
+        unit = r % U;
+    }
+}
+
 // Workspace header (device memory, first 256 bytes of the workspace)
 struct F3dgHeader {
     unsigned int num_rendered;   // total (Gaussian, tile) instances of the call (all views)

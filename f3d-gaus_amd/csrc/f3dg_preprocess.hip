@@ -468,9 +468,6 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
     }
 
     radii[idx] = my_radii;
-    tiles_touched[idx] = my_tiles;
-    means2D[idx] = xy;
-    depths_out[idx] = depth;
     rects[idx] = rect;
     sort_keys[idx] = my_tiles ? __float_as_uint(depth) : 0xFFFFFFFFu;      // key of the per-view depth sort (f3dg_binning.hip)
     if (bbox_out) bbox_out[idx] = box;
@@ -478,7 +475,10 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
     r3.w = cec;                             // record slot 15: the ellipse's c (the depth lives in depths_out)
     float4* dst = reinterpret_cast<float4*>(rec + idx);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-    if (save_aux) {
+    if (save_aux) {                         // planes only the backward and the debug export read
+        tiles_touched[idx] = my_tiles;
+        means2D[idx] = xy;
+        depths_out[idx] = depth;
         conic_out[idx] = con;
         clamped[idx] = clamp_bits;
     }

@@ -186,19 +186,8 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                   const float4* __restrict__ bbox, const float* __restrict__ background, int bg_per_view,
                   float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
 {
-    // XCD-aware placement: consecutive workgroup ids land on different XCDs (id % 8), so give every XCD its
-    // own views: all tiles of a view then share one XCD's L2 for the record gather.
-#ifdef F3DG_PLAIN_MAP
-    const unsigned view = blockIdx.x / (unsigned)T;
-    const unsigned tile = blockIdx.x % (unsigned)T;
-#else
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned slot = blockIdx.x >> 3;
-    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
-    const unsigned tile = slot % (unsigned)T;
-#endif
-    if (view >= (unsigned)V)
-        return;
+    unsigned view, tile;                      // all tiles of a view share one XCD's L2 for the record gather
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, (unsigned)T, view, tile);
 
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
     // each wave owns an 8x8 pixel quadrant of the tile and each of its four 16-lane groups a 4x4 block of it: the culled
@@ -522,12 +511,8 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
 {
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned slot = blockIdx.x >> 3;
-    const unsigned view = (slot / (unsigned)T) * 8u + xcd;
-    const unsigned tile = slot % (unsigned)T;
-    if (view >= (unsigned)V)
-        return;
+    unsigned view, tile;                      // all tiles of a view share one XCD's L2 for the record gather
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, (unsigned)T, view, tile);
 
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -725,8 +710,7 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
-    const unsigned groups = (unsigned)((V + 7) / 8);
-    dim3 grid(groups * 8u * (unsigned)T);
+    dim3 grid((unsigned)V * (unsigned)T);
     // fast arithmetic is for inference calls. A SAVE_AUX forward feeds f3dg_backward, which rebuilds every pixel's transmittance
     // back to front by dividing final_T by (1 - alpha) with ITS alphas: they must be the forward's to the bit, or the 1e-6 relative
     // difference is amplified by 1 / (1 - alpha) per layer (measured at C5: compositing-stage gradients 2.5e-5 vs 1.8e-6 off the oracle).

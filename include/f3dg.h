@@ -277,8 +277,8 @@ int f3dg_backward_pairs(void* stream, const void* workspace, long long* h_pairs)
 /* Test/inspection hook: device-to-device copies of the library's internal per-call state into caller buffers
  * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the
  * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
- *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], culling-ellipse c), depths [V*P], means2D [V*P*2], conic [V*P*4] (SAVE_AUX),
- *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped; SAVE_AUX), keys_sorted [cap] u64 (SAVE_AUX),
+ *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], culling-ellipse c); depths [V*P], means2D [V*P*2], conic [V*P*4],
+ *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped), keys_sorted [cap] u64 (all SAVE_AUX: an inference call does not write them),
  *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX). */
 int f3dg_debug_export(void* stream, const void* workspace, int P, int W, int H, int n_views,
                       long long max_rendered, float* rec, float* means2D, float* conic, unsigned* tiles,

@@ -13,10 +13,10 @@ import f3dgaus_amd as f3d  # noqa: E402
 from f3dgaus_amd import synthetic  # noqa: E402
 
 dev = torch.device("cuda:0")
-RES, V = 256, 8
-cams = synthetic.orbit_cameras(V, resolution=RES, device=dev)
+RES = 256
 bg = torch.zeros(3, device=dev)
-for P in (65536, 196608, 589824):
+for V, P in ((1, 65536), (1, 196608), (3, 196608), (8, 65536), (8, 196608), (8, 589824), (12, 196608)):
+    cams = synthetic.orbit_cameras(V, resolution=RES, device=dev)
     g = synthetic.make_gaussians(P, s0=0.01, seed=0, device=dev)
     shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
     kw = dict(image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"],
