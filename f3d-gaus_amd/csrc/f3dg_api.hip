@@ -165,10 +165,10 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.sort_blocks = (unsigned)((C + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK);
     const size_t scan_a = (VP + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
     const size_t gsort_blocks = (size_t)V * (((size_t)(P > 0 ? P : 1) + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK);      // (view, chunk) blocks of the depth sort
-    const size_t hist_blocks = gsort_blocks > L.sort_blocks ? gsort_blocks : L.sort_blocks;
+    const size_t tile_blocks = (size_t)L.sort_blocks + (size_t)V;      // (view, chunk) blocks of the tile pass: every view rounds up
+    const size_t hist_blocks = gsort_blocks > tile_blocks ? gsort_blocks : tile_blocks;
     const size_t scan_b = ((size_t)256 * hist_blocks + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
-    const size_t scan_c = ((size_t)V * T + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK;
-    L.scan_tmp_elems = (unsigned)((scan_a > scan_b ? (scan_a > scan_c ? scan_a : scan_c) : (scan_b > scan_c ? scan_b : scan_c)) + 1);
+    L.scan_tmp_elems = (unsigned)((scan_a > scan_b ? scan_a : scan_b) + 1);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -187,16 +187,12 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.gsort = take(4 * VP * sizeof(unsigned));
     L.scan_tmp = take((size_t)L.scan_tmp_elems * sizeof(unsigned));
     L.keys[0] = take(C * 8);
-    L.keys[1] = take(C * 8);
+    L.keys[1] = take(C * 4);
     L.vals[0] = take(C * 4);
     L.vals[1] = take(C * 4);
-    L.gstart = take((size_t)2 * V * T * sizeof(unsigned));          // gstart[V*T] immediately followed by gend[V*T]
-    L.gend = L.gstart + (size_t)V * T * sizeof(unsigned);
-    L.gcount = take((size_t)V * T * sizeof(unsigned));
-    {   // radix histograms [256][sort_blocks]; also reused for the inclusive scan of the V*T group sizes
-        const size_t h = (size_t)256 * hist_blocks, gseg = (size_t)V * T;
-        L.hist = take((h > gseg ? h : gseg) * sizeof(unsigned));
-    }
+    L.segtab_minmax = (unsigned)((size_t)2 * (V + 1) + (size_t)8 * (V / 8 + 2));      // followed by minmax[2 V], chunk_minmax[2 V cps]
+    L.segtab = take(((size_t)L.segtab_minmax + (size_t)2 * V + 2 * gsort_blocks) * sizeof(unsigned));   // + the chunks' ranges
+    L.hist = take((size_t)256 * hist_blocks * sizeof(unsigned));
     L.ranges = take((size_t)V * T * sizeof(uint2));
     L.final_T = take((size_t)V * 4 * HW * sizeof(float));
     L.n_contrib = take((size_t)V * 2 * HW * sizeof(unsigned));

@@ -4,8 +4,8 @@
 //   cub::DeviceScan::InclusiveSum      :332      -> scan_* kernels (hand-written reduce / scan / propagate)
 //   the blocking D2H of num_rendered   :336      -> count stays on the device (workspace header)
 //   duplicateWithKeys                  :70-111   -> duplicate_sorted_kernel
-//   cub::DeviceRadixSort::SortPairs    :358-363  -> radix2_hist_kernel + scan + radix2_scatter_kernel (8 bits/pass)
-//   cudaMemset(ranges) + identifyTileRanges :365, :149-171 -> group_bounds / group_counts / scan / group_ranges kernels
+//   cub::DeviceRadixSort::SortPairs    :358-363  -> gsort_* (depth, per Gaussian) and radix2_*_var (tile, per instance) passes of 8 bits
+//   cudaMemset(ranges) + identifyTileRanges :365, :149-171 -> memset + group_bounds_kernel
 //
 // The final list is the reference's: per view, ascending (tile, depth bits, Gaussian id) -- what a stable sort of its 64-bit keys
 // (tile << 32 | float_bits(depth)) gives. It is built depth-first (see "depth-first binning" below): the Gaussians of every view are
@@ -140,78 +140,128 @@ scan_apply_kernel(const u32* in, u32* out /* may alias in */, u64 n, const u32* 
 
 // ================================================================================================ depth-first binning
 // Round 1 grouped the instances by tile first and then sorted every (view, tile) group by depth in LDS; that per-tile sort was the
-// largest binning kernel (1.0 of 2.3 ms at C2, 4.9 of 12 ms at C5: latency-bound), and it sorted every INSTANCE (R = 3-7 per Gaussian). A Gaussian's depth is the same in all its tiles, so the depth order is established once per
-// (view, Gaussian) instead:
+// largest binning kernel (1.0 of 2.3 ms at C2, 4.9 of 12 ms at C5: latency-bound), and it sorted every INSTANCE (R = 3-7 per
+// Gaussian). A Gaussian's depth is the same in all its tiles, so the depth order is established once per (view, Gaussian) instead:
 //   1. gsort: stable LSD radix sort of each view's P Gaussians by their depth bits (4 passes of 8 bits over V*P keys; culled
 //      Gaussians get the key ~0 and produce no instances) -> perm[V][P], ascending (depth, Gaussian id);
-//   2. tiles_touched gathered in that order, prefix sum, and the instances are GENERATED in (view, depth, id) order;
-//   3. the stable tile-digit pass(es) of the old path (two streams now: group u16/u32 + Gaussian id, no depth stream);
-//      afterwards every (tile, view) group is contiguous and already in its final (depth, id) order;
-//   4. group bounds -> ranges as before, and a copy of every group to its place in the (view, tile)-ordered list.
+//   2. the tile rectangles gathered in that order, prefix sum of their areas, and the instances are GENERATED in (view, depth, id)
+//      order, as two streams: group (view << tile_bits | tile, u16 or u32) and Gaussian id;
+//   3. stable pass(es) over the tile bits INSIDE every view's segment of the instance arrays: the result is in (view, tile, depth,
+//      id) order, i.e. the final list, and a view's instances never leave one XCD's L2;
+//   4. identifyTileRanges on the final group stream.
 // Same final list as a stable 64-bit sort of (tile << 32 | depth) keys, i.e. the reference's.
 
-// two-stream stable radix pass over `nseg` segments of seg_len keys each (hdr != null: ONE segment of hdr->num_rendered keys).
-// Block b = (segment, chunk): counts of its digit d go to hist[(segment * 256 + d) * cps + chunk], so that one exclusive scan of
-// the whole array yields global output positions (every segment owns exactly seg_len consecutive outputs).
-template <typename K>
-__global__ void __launch_bounds__(F3DG_BLOCK)
-radix2_hist_kernel(const K* __restrict__ keys, const F3dgHeader* __restrict__ hdr, u32 seg_len, u32 cps, int shift,
-                   u32* __restrict__ hist)
+// ------------------------------------------------------------------------------------------------ segmented radix passes
+// Two-stream (key, payload) stable 8-bit radix pass over SEGMENTS of the arrays (a segment = one view): elements never leave their
+// segment, so the arrays stay view-major and a view's data stays in one XCD's L2 (f3dg_xcd_map / the per-XCD work lists below).
+// A workgroup takes one chunk of F3DG_SORT_CHUNK elements of one segment. The counts of digit d of chunk c go to
+// hist[obase + d * cps + c] (obase = 256 * chunks of all earlier segments), so that ONE exclusive scan of the whole array yields the
+// global output positions: every segment owns exactly its own index range of the output.
+struct SegChunk {
+    u64 seg_base;   // first element of the segment in the key / payload arrays
+    u64 obase;      // first entry of the segment's [256][cps] block of the histogram
+    u32 n;          // elements of the segment
+    u32 cps;        // chunks of the segment
+    u32 c;          // the chunk
+    u32 seg;        // the segment (fixed segments only)
+};
+
+// Variable-length segments (the instances of every view): built on the device by view_segments_kernel
+struct SegTable {
+    const u32* vstart;      // [V + 1] first instance of every view
+    const u32* bglob;       // [V + 1] chunks of all earlier views
+    const u32* xprefix;     // [8][xstride] XCD x works on the views x, x + 8, ...: chunks of its earlier views
+    u32 xstride;            // V / 8 + 2
+    u32 V;
+};
+
+// digit of a key in one pass
+struct ShiftDigit {
+    int shift;
+    __device__ __forceinline__ u32 operator()(u32 k) const { return (k >> shift) & 255u; }
+};
+// third and LAST pass of a view's depth sort when all its keys lie within 2^24 of kbase (a multiple of 2^16: the low 16 bits of
+// key - kbase are the key's own, which passes 0 and 1 sorted). Keys of Gaussians that touch no tile (~0) land in digit 255; they
+// produce no instances, so their place in the order is irrelevant.
+struct CompactDigit {
+    u32 kbase;
+    __device__ __forceinline__ u32 operator()(u32 k) const { const u32 d = (k - kbase) >> 16; return d < 255u ? d : 255u; }
+};
+
+template <typename K, typename DIGIT, bool MINMAX = false>
+__device__ __forceinline__ void hist_chunk(const K* __restrict__ keys, const SegChunk& ck, const DIGIT digit, u32* __restrict__ hist,
+                                           u32 (*h)[256], u32* __restrict__ minmax = nullptr)
 {
-    __shared__ u32 h[F3DG_BLOCK / 64][256];
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;        // MINMAX: range of the keys other than ~0 (Gaussians that touch no tile)
 #pragma unroll
     for (int w = 0; w < F3DG_BLOCK / 64; w++) h[w][threadIdx.x] = 0;
     __syncthreads();
-    u32 seg = 0, c = blockIdx.x;
-    if (!hdr) f3dg_xcd_map(blockIdx.x, gridDim.x / cps, cps, seg, c);      // a view's chunks on one XCD: its key segment stays in that L2
-    const u32 n = hdr ? (hdr->overflow ? 0u : hdr->num_rendered) : seg_len;
-    const u64 seg_base = (u64)seg * seg_len;
-    const u64 base = (u64)c * F3DG_SORT_CHUNK;
+    const u32 n = ck.n;
+    const u64 base = (u64)ck.c * F3DG_SORT_CHUNK;
     u32* hw = h[threadIdx.x >> 6];
-    if (base < n) {
-        constexpr int VEC = 16 / (int)sizeof(K);                   // keys per 16-byte load
-        typedef K __attribute__((ext_vector_type(VEC))) KV;
-        const bool aligned = ((seg_base + base) % VEC) == 0;       // (chunks are multiples of VEC keys; segments need not be)
+    constexpr int VEC = 16 / (int)sizeof(K);                   // keys per 16-byte load
+    typedef K __attribute__((ext_vector_type(VEC))) KV;
+    const bool aligned = ((ck.seg_base + base) % VEC) == 0;    // (chunks are multiples of VEC keys; segments need not be)
 #pragma unroll
-        for (int i = 0; i < F3DG_SORT_ITEMS / VEC; i++) {
-            const u64 k = base + ((u64)i * F3DG_BLOCK + threadIdx.x) * VEC;
-            if (aligned && k + VEC <= n) {
-                const KV w = *reinterpret_cast<const KV*>(keys + seg_base + k);
+    for (int i = 0; i < F3DG_SORT_ITEMS / VEC; i++) {
+        const u64 k = base + ((u64)i * F3DG_BLOCK + threadIdx.x) * VEC;
+        if (aligned && k + VEC <= n) {
+            const KV w = *reinterpret_cast<const KV*>(keys + ck.seg_base + k);
 #pragma unroll
-                for (int q = 0; q < VEC; q++) atomicAdd(&hw[((u32)w[q] >> shift) & 255u], 1u);
-            } else {
-                for (int q = 0; q < VEC; q++)
-                    if (k + q < n) atomicAdd(&hw[((u32)keys[seg_base + k + q] >> shift) & 255u], 1u);
+            for (int q = 0; q < VEC; q++) {
+                const u32 key = (u32)w[q];
+                atomicAdd(&hw[digit(key)], 1u);
+                if (MINMAX && key != 0xFFFFFFFFu) { kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
             }
+        } else {
+            for (int q = 0; q < VEC; q++)
+                if (k + q < n) {
+                    const u32 key = (u32)keys[ck.seg_base + k + q];
+                    atomicAdd(&hw[digit(key)], 1u);
+                    if (MINMAX && key != 0xFFFFFFFFu) { kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
+                }
         }
-        __syncthreads();
     }
-    hist[((size_t)seg * 256 + threadIdx.x) * cps + c] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    __shared__ u32 wmm[2][F3DG_BLOCK / 64];
+    if (MINMAX) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u32 a = __shfl_down(kmin, off, 64), b = __shfl_down(kmax, off, 64);
+            kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+        }
+        if ((threadIdx.x & 63) == 0) { wmm[0][threadIdx.x >> 6] = kmin; wmm[1][threadIdx.x >> 6] = kmax; }
+    }
+    __syncthreads();
+    if (MINMAX && threadIdx.x == 0) {       // the chunk's range (kmin > kmax: no key other than ~0); reduced per view by gsort_range_kernel
+        u32 a = wmm[0][0], b = wmm[1][0];
+#pragma unroll
+        for (int w = 1; w < F3DG_BLOCK / 64; w++) { a = wmm[0][w] < a ? wmm[0][w] : a; b = wmm[1][w] > b ? wmm[1][w] : b; }
+        minmax[0] = a; minmax[1] = b;
+    }
+    hist[ck.obase + (u64)threadIdx.x * ck.cps + ck.c] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
 }
 
-template <typename K, bool IOTA = false>      // IOTA: the payload of the input is its position inside the segment (first pass)
-__global__ void __launch_bounds__(F3DG_BLOCK)
-radix2_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in, K* __restrict__ keys_out,
-                      u32* __restrict__ vals_out, const F3dgHeader* __restrict__ hdr, u32 seg_len, u32 cps, int shift,
-                      const u32* __restrict__ offsets /* exclusive scan of hist */)
+struct ScatterShared {
+    u32 cnt[F3DG_BLOCK / 64][256];
+    u32 lbase[256];
+    u32 gdelta[256];
+    u32 wtot[F3DG_BLOCK / 64];
+    u32 sval[F3DG_SORT_CHUNK];
+};
+
+// IOTA: the payload of the input is its position inside the segment (first pass of the depth sort)
+template <typename K, bool IOTA, typename DIGIT>
+__device__ __forceinline__ void scatter_chunk(const K* __restrict__ keys_in, const u32* __restrict__ vals_in, K* __restrict__ keys_out,
+                                              u32* __restrict__ vals_out, const SegChunk& ck, const DIGIT digit,
+                                              const u32* __restrict__ offsets /* exclusive scan of hist */, ScatterShared& sh, K* skey)
 {
-    // as radix_scatter_kernel: the chunk is digit-sorted inside LDS (stable), then written out in coalesced runs
-    __shared__ u32 cnt[F3DG_BLOCK / 64][256];
-    __shared__ u32 lbase[256];
-    __shared__ u32 gdelta[256];
-    __shared__ u32 wtot[F3DG_BLOCK / 64];
-    __shared__ K skey[F3DG_SORT_CHUNK];
-    __shared__ u32 sval[F3DG_SORT_CHUNK];
-    u32 seg = 0, c = blockIdx.x;
-    if (!hdr) f3dg_xcd_map(blockIdx.x, gridDim.x / cps, cps, seg, c);      // the scattered writes of a view merge in one XCD's L2
-    const u32 n = hdr ? (hdr->overflow ? 0u : hdr->num_rendered) : seg_len;
-    const u64 seg_base = (u64)seg * seg_len;
-    const u64 block_base = (u64)c * F3DG_SORT_CHUNK;
-    if (block_base >= n) return;
+    // the chunk is digit-sorted inside LDS (stable), then written out in coalesced runs
+    const u32 n = ck.n;
+    const u64 block_base = (u64)ck.c * F3DG_SORT_CHUNK;
     const u32 in_block = (u32)((n - block_base) < (u64)F3DG_SORT_CHUNK ? (n - block_base) : (u64)F3DG_SORT_CHUNK);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int w = 0; w < F3DG_BLOCK / 64; w++) cnt[w][threadIdx.x] = 0;
+    for (int w = 0; w < F3DG_BLOCK / 64; w++) sh.cnt[w][threadIdx.x] = 0;
     __syncthreads();
 
     const u64 wave_base = block_base + (u64)wave * (64 * F3DG_SORT_ITEMS);
@@ -223,14 +273,14 @@ radix2_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ val
     for (int r = 0; r < F3DG_SORT_ITEMS; r++) {          // all loads first
         const u64 i = wave_base + (u64)r * 64 + lane;
         const bool valid = i < n;
-        key[r] = valid ? (u32)keys_in[seg_base + i] : 0u;
-        val[r] = IOTA ? (u32)i : (valid ? vals_in[seg_base + i] : 0u);
+        key[r] = valid ? (u32)keys_in[ck.seg_base + i] : 0u;
+        val[r] = IOTA ? (u32)i : (valid ? vals_in[ck.seg_base + i] : 0u);
     }
 #pragma unroll
     for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
         const u64 i = wave_base + (u64)r * 64 + lane;
         const bool valid = i < n;
-        const u32 d = (key[r] >> shift) & 255u;
+        const u32 d = digit(key[r]);
         u64 same = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -239,16 +289,16 @@ radix2_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ val
             same &= bit ? bal : ~bal;
         }
         const u32 below = (u32)__popcll(same & lane_lt);
-        const u32 prev = cnt[wave][d];
+        const u32 prev = sh.cnt[wave][d];
         rank[r] = prev + below;
         __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0) cnt[wave][d] = prev + (u32)__popcll(same);
+        if (valid && below == 0) sh.cnt[wave][d] = prev + (u32)__popcll(same);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     {
         const u32 d = threadIdx.x;
-        const u32 c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        const u32 c0 = sh.cnt[0][d], c1 = sh.cnt[1][d], c2 = sh.cnt[2][d], c3 = sh.cnt[3][d];
         const u32 tot = c0 + c1 + c2 + c3;
         u32 x = tot;
 #pragma unroll
@@ -256,67 +306,273 @@ radix2_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ val
             const u32 y = __shfl_up(x, off, 64);
             if (lane >= off) x += y;
         }
-        if (lane == 63) wtot[wave] = x;
+        if (lane == 63) sh.wtot[wave] = x;
         __syncthreads();
         u32 excl = x - tot;
-        for (int w = 0; w < wave; w++) excl += wtot[w];
-        lbase[d] = excl;
-        gdelta[d] = offsets[((size_t)seg * 256 + d) * cps + c] - excl;
-        cnt[0][d] = excl;
-        cnt[1][d] = excl + c0;
-        cnt[2][d] = excl + c0 + c1;
-        cnt[3][d] = excl + c0 + c1 + c2;
+        for (int w = 0; w < wave; w++) excl += sh.wtot[w];
+        sh.lbase[d] = excl;
+        sh.gdelta[d] = offsets[ck.obase + (u64)d * ck.cps + ck.c] - excl;
+        sh.cnt[0][d] = excl;
+        sh.cnt[1][d] = excl + c0;
+        sh.cnt[2][d] = excl + c0 + c1;
+        sh.cnt[3][d] = excl + c0 + c1 + c2;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < F3DG_SORT_ITEMS; r++) {
         const u64 i = wave_base + (u64)r * 64 + lane;
         if (i < n) {
-            const u32 d = (key[r] >> shift) & 255u;
-            const u32 slot = cnt[wave][d] + rank[r];
+            const u32 d = digit(key[r]);
+            const u32 slot = sh.cnt[wave][d] + rank[r];
             skey[slot] = (K)key[r];
-            sval[slot] = val[r];
+            sh.sval[slot] = val[r];
         }
     }
     __syncthreads();
     for (u32 slot = threadIdx.x; slot < in_block; slot += F3DG_BLOCK) {
         const K k = skey[slot];
-        const u32 d = ((u32)k >> shift) & 255u;
-        const u32 pos = gdelta[d] + slot;          // global position (the scan spans all segments)
-        keys_out[pos] = k;
-        vals_out[pos] = sval[slot];
+        const u32 d = digit((u32)k);
+        const u32 pos = sh.gdelta[d] + slot;          // global position (the scan spans all segments)
+        if (keys_out) keys_out[pos] = k;
+        vals_out[pos] = sh.sval[slot];
+    }
+}
+
+// ---- equal segments of seg_len elements (the per-view depth sort of the Gaussians): one chunk per workgroup.
+// Pass 1 also finds every chunk's key range, reduced to every view's [kmin, kmax] (minmax[2 v], [2 v + 1]) by gsort_range_kernel. A view whose
+// range fits 2^24 above kbase = kmin & ~0xFFFF is "compact": its third pass sorts by (key - kbase) >> 16 and is its last, the fourth
+// returns at once (its histogram is a stand-in with the right sum so that the scan keeps the other views' positions), and the
+// view's order is the OUTPUT OF PASS 2 (see gsort_perm_is_pass2). Depth ranges within a factor of 2-4 -- object-centric cameras --
+// are compact; others take the four plain passes.
+__device__ __forceinline__ SegChunk fixed_chunk(u32 seg_len, u32 cps)
+{
+    u32 seg, c;
+    f3dg_xcd_map(blockIdx.x, gridDim.x / cps, cps, seg, c);
+    SegChunk ck;
+    ck.seg_base = (u64)seg * seg_len; ck.obase = (u64)seg * 256u * cps; ck.n = seg_len; ck.cps = cps; ck.c = c; ck.seg = seg;
+    return ck;
+}
+
+__device__ __forceinline__ bool gsort_compact(const u32* __restrict__ minmax, u32 view, u32& kbase)
+{
+    const u32 kmin = minmax[2 * view], kmax = minmax[2 * view + 1];
+    kbase = kmin & 0xFFFF0000u;
+    return kmin <= kmax && ((kmax - kbase) >> 24) == 0u;
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(F3DG_BLOCK)
+gsort_hist_kernel(const u32* __restrict__ keys, u32 seg_len, u32 cps, u32* __restrict__ hist, const u32* __restrict__ minmax,
+                  u32* __restrict__ chunk_minmax)
+{
+    __shared__ u32 h[F3DG_BLOCK / 64][256];
+    const SegChunk ck = fixed_chunk(seg_len, cps);
+    if constexpr (PASS == 0) {
+        hist_chunk<u32, ShiftDigit>(keys, ck, ShiftDigit{0}, hist, h);
+    } else if constexpr (PASS == 1) {        // (pass 1 reads the keys from the cache; pass 0 reads them cold)
+        hist_chunk<u32, ShiftDigit, true>(keys, ck, ShiftDigit{8}, hist, h, chunk_minmax + 2 * ((size_t)ck.seg * cps + ck.c));
+    } else {
+        u32 kbase;
+        const bool compact = gsort_compact(minmax, ck.seg, kbase);
+        if (!compact) {
+            hist_chunk<u32, ShiftDigit>(keys, ck, ShiftDigit{8 * PASS}, hist, h);
+        } else if constexpr (PASS == 2) {
+            hist_chunk<u32, CompactDigit>(keys, ck, CompactDigit{kbase}, hist, h);
+        } else {
+            const u64 base = (u64)ck.c * F3DG_SORT_CHUNK;
+            const u32 in_chunk = (u32)((ck.n - base) < (u64)F3DG_SORT_CHUNK ? (ck.n - base) : (u64)F3DG_SORT_CHUNK);
+            hist[ck.obase + (u64)threadIdx.x * ck.cps + ck.c] = threadIdx.x == 0 ? in_chunk : 0u;
+        }
+    }
+}
+
+// key range of every view from the ranges of its chunks (one wave per view)
+__global__ void __launch_bounds__(64)
+gsort_range_kernel(u32 cps, const u32* __restrict__ chunk_minmax, u32* __restrict__ minmax)
+{
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (u32 c = threadIdx.x; c < cps; c += 64) {
+        const u32 a = chunk_minmax[2 * ((size_t)blockIdx.x * cps + c)], b = chunk_minmax[2 * ((size_t)blockIdx.x * cps + c) + 1];
+        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u32 a = __shfl_down(kmin, off, 64), b = __shfl_down(kmax, off, 64);
+        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+    }
+    if (threadIdx.x == 0) { minmax[2 * blockIdx.x] = kmin; minmax[2 * blockIdx.x + 1] = kmax; }
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(F3DG_BLOCK)
+gsort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, u32* __restrict__ keys_out,
+                     u32* __restrict__ vals_out, u32 seg_len, u32 cps, const u32* __restrict__ offsets, const u32* __restrict__ minmax)
+{
+    __shared__ ScatterShared sh;
+    __shared__ u32 skey[F3DG_SORT_CHUNK];
+    const SegChunk ck = fixed_chunk(seg_len, cps);
+    if constexpr (PASS == 0) {           // the payload of the input is its position inside the segment
+        scatter_chunk<u32, true, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{0}, offsets, sh, skey);
+    } else if constexpr (PASS == 1) {
+        scatter_chunk<u32, false, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{8}, offsets, sh, skey);
+    } else {
+        u32 kbase;
+        const bool compact = gsort_compact(minmax, ck.seg, kbase);
+        if (!compact)
+            scatter_chunk<u32, false, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{8 * PASS}, offsets, sh, skey);
+        else if constexpr (PASS == 2)
+            scatter_chunk<u32, false, CompactDigit>(keys_in, vals_in, keys_out, vals_out, ck, CompactDigit{kbase}, offsets, sh, skey);
+    }
+}
+
+// ---- the instances of every view (variable segments): persistent workgroups. Workgroup b belongs to XCD b % 8 and walks that
+// XCD's list of (view, chunk) pairs -- views x, x + 8, ... chunk by chunk -- with stride gridDim.x / 8.
+// vstart / bglob / xprefix from the prefix sum of tiles_touched in (view, depth) order; all zero chunks on overflow.
+__global__ void __launch_bounds__(512)
+view_segments_kernel(int V, int P, const u32* __restrict__ offsets_sorted, const F3dgHeader* __restrict__ hdr, u32* __restrict__ vstart,
+                     u32* __restrict__ bglob, u32* __restrict__ xprefix, u32 xstride)
+{
+    __shared__ u32 carry;
+    __shared__ u32 wtot[8];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool dead = hdr->overflow != 0;
+    auto start_of = [&](u32 v) -> u32 {
+        const u64 i = (u64)v * (u64)P;
+        return (dead || i == 0) ? 0u : offsets_sorted[i - 1];
+    };
+    auto chunks_of = [&](u32 v) -> u32 {
+        const u32 n = start_of(v + 1) - start_of(v);
+        return (n + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK;
+    };
+    // global chunk prefix, view order
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 v0 = 0; v0 < (u32)V; v0 += 512) {
+        const u32 v = v0 + threadIdx.x;
+        const u32 c = v < (u32)V ? chunks_of(v) : 0u;
+        u32 x = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 y = __shfl_up(x, off, 64);
+            if (lane >= (u32)off) x += y;
+        }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        u32 woff = carry;
+        for (u32 w = 0; w < wave; w++) woff += wtot[w];
+        if (v < (u32)V) { vstart[v] = start_of(v); bglob[v] = woff + x - c; }
+        __syncthreads();
+        if (threadIdx.x == 511) carry = woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { vstart[V] = start_of((u32)V); bglob[V] = carry; }
+    // per-XCD prefix: wave x scans the chunks of the views x, x + 8, ...
+    const u32 nk = ((u32)V > wave) ? ((u32)V - wave + 7u) / 8u : 0u;
+    u32 run = 0;
+    for (u32 k0 = 0; k0 < nk; k0 += 64) {
+        const u32 k = k0 + lane;
+        const u32 c = k < nk ? chunks_of(wave + 8u * k) : 0u;
+        u32 x = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 y = __shfl_up(x, off, 64);
+            if (lane >= (u32)off) x += y;
+        }
+        if (k < nk) xprefix[wave * xstride + k] = run + x - c;
+        run += __shfl(x, 63, 64);
+    }
+    if (lane == 0) xprefix[wave * xstride + nk] = run;
+}
+
+// next (view, chunk) of this workgroup's XCD list; false when the list is exhausted. k is the cursor into the XCD's views.
+__device__ __forceinline__ bool var_chunk(const SegTable& st, u32 f, u32& k, SegChunk& ck)
+{
+    const u32 x = blockIdx.x & 7u;
+    const u32* xp = st.xprefix + x * st.xstride;
+    const u32 nk = (st.V > x) ? (st.V - x + 7u) / 8u : 0u;
+    while (k < nk && f >= xp[k + 1]) k++;
+    if (k >= nk) return false;
+    const u32 v = x + 8u * k;
+    const u32 s0 = st.vstart[v], b0 = st.bglob[v];
+    ck.seg_base = s0; ck.n = st.vstart[v + 1] - s0; ck.cps = st.bglob[v + 1] - b0; ck.obase = 256ull * b0; ck.c = f - xp[k];
+    return true;
+}
+
+template <typename K>
+__global__ void __launch_bounds__(F3DG_BLOCK)
+radix2_hist_var_kernel(const K* __restrict__ keys, SegTable st, int shift, u32* __restrict__ hist)
+{
+    __shared__ u32 h[F3DG_BLOCK / 64][256];
+    u32 k = 0;
+    SegChunk ck;
+    for (u32 f = blockIdx.x >> 3; var_chunk(st, f, k, ck); f += gridDim.x >> 3)
+        hist_chunk<K, ShiftDigit>(keys, ck, ShiftDigit{shift}, hist, h);
+}
+
+template <typename K>
+__global__ void __launch_bounds__(F3DG_BLOCK)
+radix2_scatter_var_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in, K* __restrict__ keys_out,
+                          u32* __restrict__ vals_out, SegTable st, int shift, const u32* __restrict__ offsets)
+{
+    __shared__ ScatterShared sh;
+    __shared__ K skey[F3DG_SORT_CHUNK];
+    u32 k = 0;
+    SegChunk ck;
+    for (u32 f = blockIdx.x >> 3; var_chunk(st, f, k, ck); f += gridDim.x >> 3) {
+        scatter_chunk<K, false, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{shift}, offsets, sh, skey);
+        __syncthreads();          // the LDS staging area is reused by the next chunk
     }
 }
 
 // tile rectangles (written by the projection kernel: x = rminx | rmaxx << 16, y = rminy | rmaxy << 16) gathered into sorted order,
 // with their areas = tiles_touched as the input of the prefix sum that places the instances: the one random gather of the path
 __global__ void __launch_bounds__(F3DG_BLOCK)
-gsort_gather_rects_kernel(int P, const u32* __restrict__ perm, const uint2* __restrict__ rects, u32* __restrict__ tiles_sorted,
-                          u32* __restrict__ rx, u32* __restrict__ ry)
+gsort_gather_rects_kernel(int P, u32* __restrict__ gv0, u32* __restrict__ gv1, const u32* __restrict__ minmax,
+                          const uint2* __restrict__ rects, u32* __restrict__ tiles_sorted, u32* __restrict__ rx)
 {
+    constexpr int ITEMS = 4;                  // four independent gathers in flight per thread
     unsigned view, chunk;                     // a view's rectangles (8 P bytes) are gathered through one XCD's L2
-    const unsigned cpv = (unsigned)((P + F3DG_BLOCK - 1) / F3DG_BLOCK);
+    const unsigned cpv = (unsigned)((P + F3DG_BLOCK * ITEMS - 1) / (F3DG_BLOCK * ITEMS));
     f3dg_xcd_map(blockIdx.x, gridDim.x / cpv, cpv, view, chunk);
-    const int k = (int)(chunk * F3DG_BLOCK + threadIdx.x);
-    if (k >= P) return;
     const size_t vb = (size_t)view * P;
-    const uint2 r = rects[vb + perm[vb + k]];
-    tiles_sorted[vb + k] = ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));
-    rx[vb + k] = r.x;
-    ry[vb + k] = r.y;
+    // the view's order is in gv1 after three passes (compact key range) or in gv0 after four; the other one takes ry
+    u32 kbase;
+    const bool pass2 = gsort_compact(minmax, view, kbase);
+    const u32* perm = pass2 ? gv1 : gv0;
+    u32* ry = pass2 ? gv0 : gv1;
+    const int k0 = (int)(chunk * F3DG_BLOCK * ITEMS + threadIdx.x);
+    u32 id[ITEMS];
+    uint2 r[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) { const int k = k0 + i * F3DG_BLOCK; id[i] = k < P ? perm[vb + k] : 0u; }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) { const int k = k0 + i * F3DG_BLOCK; r[i] = k < P ? rects[vb + id[i]] : make_uint2(0u, 0u); }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const int k = k0 + i * F3DG_BLOCK;
+        if (k < P) {
+            tiles_sorted[vb + k] = ((r[i].x >> 16) - (r[i].x & 0xFFFFu)) * ((r[i].y >> 16) - (r[i].y & 0xFFFFu));
+            rx[vb + k] = r[i].x;
+            ry[vb + k] = r[i].y;
+        }
+    }
 }
 
 // duplicateWithKeys in (view, depth, id) order: sorted position k of view v emits the tiles of Gaussian perm[v][k]
 template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
-duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict__ perm, const u32* __restrict__ rx,
-                        const u32* __restrict__ ry, const u32* __restrict__ offsets_sorted, const F3dgHeader* __restrict__ hdr,
-                        G* __restrict__ kgrp, u32* __restrict__ vals)
+duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict__ gv0, const u32* __restrict__ gv1,
+                        const u32* __restrict__ minmax, const u32* __restrict__ rx, const u32* __restrict__ offsets_sorted,
+                        const F3dgHeader* __restrict__ hdr, G* __restrict__ kgrp, u32* __restrict__ vals)
 {
     if (hdr->overflow) return;
     const int k = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
     if (k >= P) return;
+    u32 kbase;
+    const bool pass2 = gsort_compact(minmax, (u32)v, kbase);      // as in gsort_gather_rects_kernel
+    const u32* perm = pass2 ? gv1 : gv0;
+    const u32* ry = pass2 ? gv0 : gv1;
     const size_t pos = (size_t)v * P + k;
     const u32 x = rx[pos], y = ry[pos];
     const u32 rminx = x & 0xFFFFu, rmaxx = x >> 16, rminy = y & 0xFFFFu, rmaxy = y >> 16;
@@ -330,21 +586,6 @@ duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict_
                 vals[off] = g;
                 off++;
             }
-    }
-}
-
-// every (view, tile) group from where the tile pass left it to its place in the (view, tile)-ordered list
-__global__ void __launch_bounds__(F3DG_BLOCK)
-regroup_kernel(u32 nseg, const uint2* __restrict__ ranges, const u32* __restrict__ gstart, const F3dgHeader* __restrict__ hdr,
-               const u32* __restrict__ vals_in, u32* __restrict__ vals_out)
-{
-    if (hdr->overflow) return;
-    for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint2 r = ranges[seg];
-        const u32 n = r.y - r.x;
-        const u32 src = gstart[seg];
-        for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK)
-            vals_out[r.x + i] = vals_in[src + i];
     }
 }
 
@@ -363,11 +604,10 @@ export_keys_kernel(u32 nseg, int P, int tile_bits, int T, const uint2* __restric
     }
 }
 
-// (view, tile) groups of the tile-sorted buffer: first / one-past-last index of every group, indexed view * T + tile
+// identifyTileRanges: first / one-past-last index of every (view, tile) group of the final list, ranges[view * T + tile] (zeroed before)
 template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
-group_bounds_kernel(const G* __restrict__ kgrp, const F3dgHeader* __restrict__ hdr, int tile_bits, int T,
-                    u32* __restrict__ gstart, u32* __restrict__ gend)
+group_bounds_kernel(const G* __restrict__ kgrp, const F3dgHeader* __restrict__ hdr, int tile_bits, int T, u32* __restrict__ ranges)
 {
     // every thread looks at 8 consecutive entries (one or two 16-byte loads) plus the entry on either side
     const u32 L = hdr->overflow ? 0u : hdr->num_rendered;
@@ -392,29 +632,11 @@ group_bounds_kernel(const G* __restrict__ kgrp, const F3dgHeader* __restrict__ h
                 const u32 cur = (u32)v[i];
                 const u32 nxt = i < 7 ? (u32)v[i + 1] : next;
                 const u32 seg = (cur >> tile_bits) * (u32)T + (cur & tmask);
-                if (idx == 0 || prev != cur) gstart[seg] = (u32)idx;
-                if (idx == L - 1 || nxt != cur) gend[seg] = (u32)idx + 1u;
+                if (idx == 0 || prev != cur) ranges[2u * seg] = (u32)idx;
+                if (idx == L - 1 || nxt != cur) ranges[2u * seg + 1u] = (u32)idx + 1u;
                 prev = cur;
             }
         }
-    }
-}
-
-__global__ void __launch_bounds__(F3DG_BLOCK)
-group_counts_kernel(u32 nseg, const u32* __restrict__ gstart, const u32* __restrict__ gend, u32* __restrict__ gcount)
-{
-    const u32 i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
-    if (i < nseg) gcount[i] = gend[i] - gstart[i];
-}
-
-__global__ void __launch_bounds__(F3DG_BLOCK)
-group_ranges_kernel(u32 nseg, const u32* __restrict__ gcount, const u32* __restrict__ gcum /* inclusive scan */,
-                    uint2* __restrict__ ranges)
-{
-    const u32 i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
-    if (i < nseg) {
-        const u32 c = gcount[i];
-        ranges[i] = c ? make_uint2(gcum[i] - c, gcum[i]) : make_uint2(0u, 0u);
     }
 }
 
@@ -451,69 +673,74 @@ int f3dg_sort_passes(int V, int T)
 }
 
 template <typename G>
-static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile_bits, const F3dgLayout& L, char* ws, F3dgHeader* hdr,
-                        u32* scan_tmp, u64** keys, u32** vals, u32* hist, uint2* ranges, u32* gstart, u32* gend, u32* gcount, u32 nseg)
+static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile_bits, const F3dgLayout& L, char* ws, F3dgHeader* hdr)
 {
     int rc = F3DG_OK;
     const size_t VP = (size_t)V * P;
+    u32* scan_tmp = reinterpret_cast<u32*>(ws + L.scan_tmp);
+    u32* hist = reinterpret_cast<u32*>(ws + L.hist);
     u32* gk[2] = { reinterpret_cast<u32*>(ws + L.gsort), reinterpret_cast<u32*>(ws + L.gsort) + VP };
     u32* gv[2] = { reinterpret_cast<u32*>(ws + L.gsort) + 2 * VP, reinterpret_cast<u32*>(ws + L.gsort) + 3 * VP };
+    G* kgrp[2] = { reinterpret_cast<G*>(ws + L.keys[0]), reinterpret_cast<G*>(ws + L.keys[1]) };   // (view << tile_bits | tile) per instance
+    u32* vals[2] = { reinterpret_cast<u32*>(ws + L.vals[0]), reinterpret_cast<u32*>(ws + L.vals[1]) };
     const dim3 pgrid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V);
 
     // 1. per-view stable sort of the Gaussians by their sort keys (written by the projection kernel into gk[0]: the depth bits,
     //    ~0 for Gaussians that touch no tile); the first pass takes the Gaussian id from the position
     const u32 cps = (u32)((P + F3DG_SORT_CHUNK - 1) / F3DG_SORT_CHUNK);
     const u32 gblocks = (u32)V * cps;
-    int cur = 0;
-    for (int pass = 0; pass < 4; pass++) {
-        hipLaunchKernelGGL((radix2_hist_kernel<u32>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[cur], (const F3dgHeader*)nullptr, (u32)P, cps,
-                           8 * pass, hist);
-        rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * gblocks, scan_tmp, L.scan_tmp_elems, 1, nullptr);
-        if (rc != F3DG_OK) return rc;
-        if (pass == 0)
-            hipLaunchKernelGGL((radix2_scatter_kernel<u32, true>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[cur], (const u32*)nullptr, gk[cur ^ 1],
-                               gv[cur ^ 1], (const F3dgHeader*)nullptr, (u32)P, cps, 8 * pass, hist);
-        else
-            hipLaunchKernelGGL((radix2_scatter_kernel<u32, false>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[cur], gv[cur], gk[cur ^ 1], gv[cur ^ 1],
-                               (const F3dgHeader*)nullptr, (u32)P, cps, 8 * pass, hist);
-        cur ^= 1;
-    }
-    const u32* perm = gv[cur];            // cur == 0 after four passes; the three other buffers are free now
-    u32* offsets_sorted = gk[cur ^ 1];    // tiles_touched in sorted order, then its inclusive prefix sum (in place)
-    u32* rx = gk[cur];
-    u32* ry = gv[cur ^ 1];
+    u32* minmax = reinterpret_cast<u32*>(ws + L.segtab) + L.segtab_minmax;
+    u32* chunk_minmax = minmax + 2 * (size_t)V;
+#define F3DG_GSORT_PASS(PASS, IN, OUT)                                                                                                     \
+    hipLaunchKernelGGL((gsort_hist_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], (u32)P, cps, hist, minmax, chunk_minmax); \
+    rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * gblocks, scan_tmp, L.scan_tmp_elems, 1, nullptr);            \
+    if (rc != F3DG_OK) return rc;                                                                                                          \
+    hipLaunchKernelGGL((gsort_scatter_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], gv[IN], gk[OUT], gv[OUT], (u32)P, cps, \
+                       hist, minmax)
+    F3DG_GSORT_PASS(0, 0, 1);
+    F3DG_GSORT_PASS(1, 1, 0);
+    hipLaunchKernelGGL(gsort_range_kernel, dim3(V), dim3(64), 0, s, cps, chunk_minmax, minmax);
+    F3DG_GSORT_PASS(2, 0, 1);
+    F3DG_GSORT_PASS(3, 1, 0);
+#undef F3DG_GSORT_PASS
+    // a view's order (perm) is gv[1] after pass 2 if its key range is compact, gv[0] after pass 3 otherwise; the other one takes ry
+    u32* offsets_sorted = gk[1];          // tiles_touched in sorted order, then its inclusive prefix sum (in place)
+    u32* rx = gk[0];
 
     // 2. instances in (view, depth, id) order
-    hipLaunchKernelGGL(gsort_gather_rects_kernel, dim3(pgrid.x * pgrid.y), dim3(F3DG_BLOCK), 0, s, P, perm, reinterpret_cast<const uint2*>(ws + L.rects),
-                       offsets_sorted, rx, ry);
+    hipLaunchKernelGGL(gsort_gather_rects_kernel, dim3((unsigned)V * (unsigned)((P + 4 * F3DG_BLOCK - 1) / (4 * F3DG_BLOCK))), dim3(F3DG_BLOCK), 0, s, P, gv[0], gv[1], minmax,
+                       reinterpret_cast<const uint2*>(ws + L.rects), offsets_sorted, rx);
     rc = f3dg_launch_scan_inclusive(s, offsets_sorted, offsets_sorted, (unsigned long long)VP, scan_tmp, L.scan_tmp_elems, 0, hdr);
     if (rc != F3DG_OK) return rc;
-    auto kgrp = [&](int h) { return reinterpret_cast<G*>(keys[h]); };         // group stream of a half (the old depth stream's place)
     const int passes = f3dg_sort_passes(V, T);
-    int src = (passes & 1) ? 0 : 1;                                            // so that the tile pass(es) end in half 1
-    hipLaunchKernelGGL((duplicate_sorted_kernel<G>), pgrid, dim3(F3DG_BLOCK), 0, s, P, tile_bits, grid_x, perm, rx, ry, offsets_sorted, hdr,
-                       kgrp(src), vals[src]);
+    int src = passes & 1;                                                      // so that the tile pass(es) end in half 0
+    hipLaunchKernelGGL((duplicate_sorted_kernel<G>), pgrid, dim3(F3DG_BLOCK), 0, s, P, tile_bits, grid_x, gv[0], gv[1], minmax, rx, offsets_sorted, hdr,
+                       kgrp[src], vals[src]);
 
-    // 3. stable pass(es) over the tile bits
-    const u32 nb = L.sort_blocks;
-    for (int p = 0; p < passes; p++) {
-        hipLaunchKernelGGL((radix2_hist_kernel<G>), dim3(nb), dim3(F3DG_BLOCK), 0, s, kgrp(src), hdr, 0u, nb, 8 * p, hist);
-        rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * nb, scan_tmp, L.scan_tmp_elems, 1, nullptr);
-        if (rc != F3DG_OK) return rc;
-        hipLaunchKernelGGL((radix2_scatter_kernel<G, false>), dim3(nb), dim3(F3DG_BLOCK), 0, s, kgrp(src), vals[src], kgrp(src ^ 1), vals[src ^ 1],
-                           hdr, 0u, nb, 8 * p, hist);
-        src ^= 1;
+    // 3. stable pass(es) over the tile bits inside every view's segment of the instance arrays: (view, tile, depth, id) order
+    if (passes > 0) {
+        SegTable st;
+        u32* segtab = reinterpret_cast<u32*>(ws + L.segtab);
+        const u32 xstride = (u32)V / 8u + 2u;
+        st.vstart = segtab; st.bglob = segtab + (V + 1); st.xprefix = segtab + 2 * (V + 1); st.xstride = xstride; st.V = (u32)V;
+        hipLaunchKernelGGL(view_segments_kernel, dim3(1), dim3(512), 0, s, V, P, offsets_sorted, hdr, segtab, segtab + (V + 1),
+                           segtab + 2 * (V + 1), xstride);
+        const size_t nbmax = (size_t)L.sort_blocks + (size_t)V;                // >= sum over the views of ceil(instances / chunk)
+        const u32 per_xcd = (u32)((nbmax + 7) / 8 < 160 ? (nbmax + 7) / 8 : 160);   // 5 workgroups per CU of the scatter's LDS
+        const u32 per_xcd_h = (u32)((nbmax + 7) / 8 < 512 ? (nbmax + 7) / 8 : 512);
+        for (int p = 0; p < passes; p++) {
+            F3DG_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(u32) * 256 * nbmax, s));
+            hipLaunchKernelGGL((radix2_hist_var_kernel<G>), dim3(8 * per_xcd_h), dim3(F3DG_BLOCK), 0, s, kgrp[src], st, 8 * p, hist);
+            rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * nbmax, scan_tmp, L.scan_tmp_elems, 1, nullptr);
+            if (rc != F3DG_OK) return rc;
+            hipLaunchKernelGGL((radix2_scatter_var_kernel<G>), dim3(8 * per_xcd), dim3(F3DG_BLOCK), 0, s, kgrp[src], vals[src], kgrp[src ^ 1],
+                               vals[src ^ 1], st, 8 * p, hist);
+            src ^= 1;
+        }
     }
-    if (passes == 0) src = 1;
-    // 4. group bounds -> ranges; copy every group to its final place
-    F3DG_HIP_CHECK(hipMemsetAsync(gstart, 0, sizeof(u32) * 2 * (size_t)nseg, s));
-    hipLaunchKernelGGL((group_bounds_kernel<G>), dim3(2048), dim3(F3DG_BLOCK), 0, s, kgrp(1), hdr, tile_bits, T, gstart, gend);
-    hipLaunchKernelGGL(group_counts_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gstart, gend, gcount);
-    rc = f3dg_launch_scan_inclusive(s, gcount, hist /* reuse as gcum */, nseg, scan_tmp, L.scan_tmp_elems, 0, nullptr);
-    if (rc != F3DG_OK) return rc;
-    hipLaunchKernelGGL(group_ranges_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, nseg, gcount, hist, ranges);
-    const u32 rg = nseg < 65535u * 4u ? nseg : 65535u * 4u;
-    hipLaunchKernelGGL(regroup_kernel, dim3(rg), dim3(F3DG_BLOCK), 0, s, nseg, ranges, gstart, hdr, vals[1], vals[0]);
+    // 4. identifyTileRanges on the final list
+    F3DG_HIP_CHECK(hipMemsetAsync(ws + L.ranges, 0, sizeof(uint2) * (size_t)V * T, s));
+    hipLaunchKernelGGL((group_bounds_kernel<G>), dim3(2048), dim3(F3DG_BLOCK), 0, s, kgrp[0], hdr, tile_bits, T, reinterpret_cast<u32*>(ws + L.ranges));
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
@@ -524,28 +751,19 @@ int f3dg_launch_binning(hipStream_t s, int V, int P, int W, int H, const F3dgLay
     const int T = grid_x * grid_y;
     const int tile_bits = f3dg_tile_bits(T);
     F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
-    u32* scan_tmp = reinterpret_cast<u32*>(ws + L.scan_tmp);
-    u64* keys[2] = { reinterpret_cast<u64*>(ws + L.keys[0]), reinterpret_cast<u64*>(ws + L.keys[1]) };
-    u32* vals[2] = { reinterpret_cast<u32*>(ws + L.vals[0]), reinterpret_cast<u32*>(ws + L.vals[1]) };
-    u32* hist = reinterpret_cast<u32*>(ws + L.hist);
-    uint2* ranges = reinterpret_cast<uint2*>(ws + L.ranges);
-    u32* gstart = reinterpret_cast<u32*>(ws + L.gstart);
-    u32* gend = reinterpret_cast<u32*>(ws + L.gend);
-    u32* gcount = reinterpret_cast<u32*>(ws + L.gcount);
-    const u32 nseg = (u32)V * (u32)T;
 
     int rc = F3DG_OK;
     if (export_offsets) {
         // the (view, Gaussian)-ordered prefix sum of the reference (point_offsets) is only an exported intermediate here
         rc = f3dg_launch_scan_inclusive(s, reinterpret_cast<const u32*>(ws + L.tiles), reinterpret_cast<u32*>(ws + L.offsets),
-                                        (unsigned long long)V * P, scan_tmp, L.scan_tmp_elems, 0, nullptr);
+                                        (unsigned long long)V * P, reinterpret_cast<u32*>(ws + L.scan_tmp), L.scan_tmp_elems, 0, nullptr);
         if (rc != F3DG_OK) return rc;
     }
     // group stream type that fits (view << tile_bits | tile)
     const bool small = !g_f3dg_sort_wide_groups &&
                        (((unsigned long long)(V > 0 ? V - 1 : 0) << tile_bits) | ((1ull << tile_bits) - 1ull)) <= 0xFFFFull;
-    rc = small ? binning_tail<unsigned short>(s, V, P, grid_x, T, tile_bits, L, ws, hdr, scan_tmp, keys, vals, hist, ranges, gstart, gend, gcount, nseg)
-               : binning_tail<u32>(s, V, P, grid_x, T, tile_bits, L, ws, hdr, scan_tmp, keys, vals, hist, ranges, gstart, gend, gcount, nseg);
+    rc = small ? binning_tail<unsigned short>(s, V, P, grid_x, T, tile_bits, L, ws, hdr)
+               : binning_tail<u32>(s, V, P, grid_x, T, tile_bits, L, ws, hdr);
     if (rc != F3DG_OK) return rc;
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

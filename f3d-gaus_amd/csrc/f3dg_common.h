@@ -74,11 +74,11 @@ struct F3dgLayout {
     size_t gsort;          // [4][V*P] u32: ping-pong (key, id) buffers of the per-view depth sort of the Gaussians; reused for the
                            // tiles_touched / prefix sum in sorted order
     size_t scan_tmp;       // u32 block sums for the scans
-    size_t keys[2];        // [cap] 8 B: group stream (u16 / u32 per instance) of the two ping-pong halves; [0] also holds the
-                           // rebuilt 64-bit keys of the debug export
+    size_t keys[2];        // group stream (u16 / u32 per instance) of the two ping-pong halves, [cap] 4 B; [0] is [cap] 8 B: it also
+                           // holds the rebuilt 64-bit keys of the debug export
     size_t vals[2];        // [cap] u32 Gaussian ids of the halves; vals[0] ends as the compositing kernel's point list
-    size_t gstart, gend, gcount;   // [V*T] u32 each: (view, tile) group bounds in the tile-grouped buffer and sizes
-    size_t hist;           // [256 * sort_blocks] u32
+    size_t segtab;         // per-view segments of the instance arrays (vstart[V+1], bglob[V+1], xprefix[8][V/8+2]; f3dg_binning.hip)
+    size_t hist;           // [256 * max((view, chunk) blocks of the depth sort, of the tile pass)] u32
     size_t ranges;         // [V*T] uint2
     size_t final_T;        // [V][4][H*W] float
     size_t n_contrib;      // [V][2][H*W] u32
@@ -86,6 +86,7 @@ struct F3dgLayout {
     size_t total;
     unsigned int sort_blocks;
     unsigned int scan_tmp_elems;
+    unsigned int segtab_minmax;   // element offset inside segtab of the per-view key range of the depth sort (minmax[2 V])
 };
 
 F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap);

@@ -8,5 +8,5 @@ python - <<PY
 import csv, glob
 for r in list(csv.DictReader(open(glob.glob("$O/*kernel_stats.csv")[0])))[:22]:
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:52]
-    print(f"{n:54s} {r['Calls']:>4s} {float(r['AverageNs'])/1e3:10.1f} us  {float(r['Percentage']):6.2f} %")
+    print(f"{n:54s} {r['Calls']:>4s} {float(r['AverageNs'])/1e3:10.1f} us  min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f} {float(r['Percentage']):6.2f} %")
 PY
