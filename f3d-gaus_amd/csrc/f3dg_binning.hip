@@ -196,30 +196,23 @@ __device__ __forceinline__ void hist_chunk(const K* __restrict__ keys, const Seg
 #pragma unroll
     for (int w = 0; w < F3DG_BLOCK / 64; w++) h[w][threadIdx.x] = 0;
     __syncthreads();
-    const u32 n = ck.n;
-    const u64 base = (u64)ck.c * F3DG_SORT_CHUNK;
     u32* hw = h[threadIdx.x >> 6];
     constexpr int VEC = 16 / (int)sizeof(K);                   // keys per 16-byte load
     typedef K __attribute__((ext_vector_type(VEC))) KV;
-    const bool aligned = ((ck.seg_base + base) % VEC) == 0;    // (chunks are multiples of VEC keys; segments need not be)
+    // the chunk's elements [g0, g1) of the array, read as ALIGNED 16-byte vectors (a segment may start anywhere): the first and the
+    // last vector are masked. (The few bytes read outside the chunk are inside the array, whose regions are padded to 256 bytes.)
+    const u64 base = (u64)ck.c * F3DG_SORT_CHUNK;
+    const u64 g0 = ck.seg_base + base;
+    const u64 g1 = ck.seg_base + ((u64)ck.n - base < (u64)F3DG_SORT_CHUNK ? (u64)ck.n : base + F3DG_SORT_CHUNK);
+    for (u64 a = (g0 & ~(u64)(VEC - 1)) + (u64)threadIdx.x * VEC; a < g1; a += (u64)F3DG_BLOCK * VEC) {
+        const KV w = *reinterpret_cast<const KV*>(keys + a);
 #pragma unroll
-    for (int i = 0; i < F3DG_SORT_ITEMS / VEC; i++) {
-        const u64 k = base + ((u64)i * F3DG_BLOCK + threadIdx.x) * VEC;
-        if (aligned && k + VEC <= n) {
-            const KV w = *reinterpret_cast<const KV*>(keys + ck.seg_base + k);
-#pragma unroll
-            for (int q = 0; q < VEC; q++) {
+        for (int q = 0; q < VEC; q++) {
+            if (a + q >= g0 && a + q < g1) {
                 const u32 key = (u32)w[q];
                 atomicAdd(&hw[digit(key)], 1u);
                 if (MINMAX && key != 0xFFFFFFFFu) { kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
             }
-        } else {
-            for (int q = 0; q < VEC; q++)
-                if (k + q < n) {
-                    const u32 key = (u32)keys[ck.seg_base + k + q];
-                    atomicAdd(&hw[digit(key)], 1u);
-                    if (MINMAX && key != 0xFFFFFFFFu) { kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
-                }
         }
     }
     __shared__ u32 wmm[2][F3DG_BLOCK / 64];
@@ -386,6 +379,41 @@ gsort_hist_kernel(const u32* __restrict__ keys, u32 seg_len, u32 cps, u32* __res
     }
 }
 
+// exclusive scan of one view's [256][cps] histogram block in place, starting from the view's first output position: the views'
+// position ranges are known in advance (seg_len each), so every view is scanned by its own workgroup -- one launch per pass
+// instead of the three of the general scan
+__global__ void __launch_bounds__(1024)
+gsort_scan_kernel(u32 n_per_seg /* 256 cps */, u32 seg_len, u32* __restrict__ hist)
+{
+    __shared__ u32 wtot[16];
+    __shared__ u32 carry_s;
+    u32* h = hist + (size_t)blockIdx.x * n_per_seg;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = blockIdx.x * seg_len;
+    __syncthreads();
+    for (u32 base = 0; base < n_per_seg; base += 4096u) {
+        const u32 i = base + 4u * threadIdx.x;                 // n_per_seg is a multiple of 256: whole uint4s
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < n_per_seg) v = *reinterpret_cast<const uint4*>(h + i);
+        const u32 tot = v.x + v.y + v.z + v.w;
+        u32 x = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 y = __shfl_up(x, off, 64);
+            if (lane >= (u32)off) x += y;
+        }
+        if (lane == 63u) wtot[wave] = x;
+        __syncthreads();
+        u32 before = carry_s + x - tot;
+        for (u32 w = 0; w < wave; w++) before += wtot[w];
+        if (i < n_per_seg)
+            *reinterpret_cast<uint4*>(h + i) = make_uint4(before, before + v.x, before + v.x + v.y, before + v.x + v.y + v.z);
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry_s = before + tot;
+        __syncthreads();
+    }
+}
+
 // key range of every view from the ranges of its chunks (one wave per view)
 __global__ void __launch_bounds__(64)
 gsort_range_kernel(u32 cps, const u32* __restrict__ chunk_minmax, u32* __restrict__ minmax)
@@ -482,6 +510,25 @@ view_segments_kernel(int V, int P, const u32* __restrict__ offsets_sorted, const
         run += __shfl(x, 63, 64);
     }
     if (lane == 0) xprefix[wave * xstride + nk] = run;
+}
+
+// identifyTileRanges when ONE pass sorted the tile bits: the scanned histogram already holds the first position of every
+// (view, tile) group -- hist[256 bglob[v] + digit * chunks_v] -- and the next entry in scan order is where it ends
+__global__ void __launch_bounds__(F3DG_BLOCK)
+ranges_from_offsets_kernel(u32 V, u32 T, int tile_bits, const u32* __restrict__ bglob, const u32* __restrict__ offsets,
+                           const F3dgHeader* __restrict__ hdr, uint2* __restrict__ ranges)
+{
+    const u32 i = blockIdx.x * F3DG_BLOCK + threadIdx.x;
+    if (i >= V * T) return;
+    const u32 v = i / T, t = i % T;
+    const u32 b0 = bglob[v], cpv = bglob[v + 1] - b0;
+    uint2 r = make_uint2(0u, 0u);
+    if (cpv != 0u && !hdr->overflow) {
+        const u32 d = ((v << tile_bits) | t) & 255u;           // the digit of the group: below 8 tile bits it holds view bits too
+        const u32 lo = offsets[256ull * b0 + (u64)d * cpv], hi = offsets[256ull * b0 + (u64)(d + 1u) * cpv];
+        if (hi > lo) r = make_uint2(lo, hi);
+    }
+    ranges[i] = r;
 }
 
 // next (view, chunk) of this workgroup's XCD list; false when the list is exhausted. k is the cursor into the XCD's views.
@@ -691,10 +738,15 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
     const u32 gblocks = (u32)V * cps;
     u32* minmax = reinterpret_cast<u32*>(ws + L.segtab) + L.segtab_minmax;
     u32* chunk_minmax = minmax + 2 * (size_t)V;
+    const bool view_scan = cps <= 64;      // one workgroup per view (<= 4 rounds of 4096 entries) or the general three-kernel scan
 #define F3DG_GSORT_PASS(PASS, IN, OUT)                                                                                                     \
     hipLaunchKernelGGL((gsort_hist_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], (u32)P, cps, hist, minmax, chunk_minmax); \
-    rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * gblocks, scan_tmp, L.scan_tmp_elems, 1, nullptr);            \
-    if (rc != F3DG_OK) return rc;                                                                                                          \
+    if (view_scan)                                                                                                                         \
+        hipLaunchKernelGGL(gsort_scan_kernel, dim3(V), dim3(1024), 0, s, 256u * cps, (u32)P, hist);                                       \
+    else {                                                                                                                                 \
+        rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * gblocks, scan_tmp, L.scan_tmp_elems, 1, nullptr);        \
+        if (rc != F3DG_OK) return rc;                                                                                                      \
+    }                                                                                                                                      \
     hipLaunchKernelGGL((gsort_scatter_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], gv[IN], gk[OUT], gv[OUT], (u32)P, cps, \
                        hist, minmax)
     F3DG_GSORT_PASS(0, 0, 1);
@@ -733,9 +785,17 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
             hipLaunchKernelGGL((radix2_hist_var_kernel<G>), dim3(8 * per_xcd_h), dim3(F3DG_BLOCK), 0, s, kgrp[src], st, 8 * p, hist);
             rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * nbmax, scan_tmp, L.scan_tmp_elems, 1, nullptr);
             if (rc != F3DG_OK) return rc;
-            hipLaunchKernelGGL((radix2_scatter_var_kernel<G>), dim3(8 * per_xcd), dim3(F3DG_BLOCK), 0, s, kgrp[src], vals[src], kgrp[src ^ 1],
-                               vals[src ^ 1], st, 8 * p, hist);
+            // (a single pass: the group stream is not needed again, the ranges come from the scanned histogram)
+            hipLaunchKernelGGL((radix2_scatter_var_kernel<G>), dim3(8 * per_xcd), dim3(F3DG_BLOCK), 0, s, kgrp[src], vals[src],
+                               passes == 1 ? (G*)nullptr : kgrp[src ^ 1], vals[src ^ 1], st, 8 * p, hist);
             src ^= 1;
+        }
+        if (passes == 1) {
+            const u32 nseg = (u32)V * (u32)T;
+            hipLaunchKernelGGL(ranges_from_offsets_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, (u32)V, (u32)T, tile_bits,
+                               segtab + (V + 1), hist, hdr, reinterpret_cast<uint2*>(ws + L.ranges));
+            F3DG_HIP_CHECK(hipGetLastError());
+            return F3DG_OK;
         }
     }
     // 4. identifyTileRanges on the final list

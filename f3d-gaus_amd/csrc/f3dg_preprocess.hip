@@ -141,8 +141,11 @@ __device__ __forceinline__ float4 conservative_box(const CullConic& q, float thr
 //   "everything" (nothing can be proven): a = b = c = 0 (E = 0 passes everywhere, no box);
 //   "never" (alpha < 1/255 everywhere: opacity <= 0, or the level set is empty): a tiny ellipse far outside any image.
 __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float thr, bool have_scale, int W, int H,
-                                                     float focal_x, float focal_y, float4& e, float& ec)
+                                                     float focal_x, float focal_y, double ifx, double ify, float4& e, float& ec)
 {
+    // (the kernel is VALU-bound and a float64 division costs ~15 float64 instructions: reciprocals are formed once and multiplied;
+    // every rounding this introduces is far inside the 0.1 % inflation below, and the two square roots, which only feed that
+    // inflation and the aspect limit, are float32 and rounded UP)
     e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     ec = 0.0f;
     const float4 never = make_float4(-1.0e9f, -1.0e9f, 1.0e30f, 0.0f);
@@ -151,21 +154,24 @@ __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float t
     const double m00 = q.m00, m01 = q.m01, m02 = q.m02, m11 = q.m11, m12 = q.m12, m22 = q.m22;
     const double D22 = m00 * m11 - m01 * m01;
     if (!(m00 > 0.0) || !(m11 > 0.0) || !(D22 > 1e-9 * fabs(m00 * m11))) return;
-    const double cx = (m01 * m12 - m02 * m11) / D22, cy = (m01 * m02 - m00 * m12) / D22;
+    const double inv_D22 = 1.0 / D22;
+    const double cx = (m01 * m12 - m02 * m11) * inv_D22, cy = (m01 * m02 - m00 * m12) * inv_D22;
     const double Qc = m22 + m02 * cx + m12 * cy;            // value of the conic at its centre; the quadratic part is positive definite
     if (!(Qc == Qc) || !(cx == cx) || !(cy == cy)) return;
     if (Qc > 0.0 && Qc < 1.0e300) { e = never; ec = 1.0e30f; return; }      // empty level set: never visible
     if (!(Qc < 0.0)) return;
-    double a = m00 / (-Qc) / ((double)focal_x * focal_x), b = 2.0 * m01 / (-Qc) / ((double)focal_x * focal_y),
-           c = m11 / (-Qc) / ((double)focal_y * focal_y);
+    const double k = -1.0 / Qc;
+    double a = m00 * k * (ifx * ifx), b = 2.0 * m01 * k * (ifx * ify), c = m11 * k * (ify * ify);
     const double det = a * c - 0.25 * b * b, tr = a + c;
     if (!(det > 0.0) || !(tr < 1.0e300)) return;
-    const double disc = sqrt(fmax(0.25 * tr * tr - det, 0.0));
+    // larger eigenvalue, rounded up (it sets the inflation and the aspect limit: a larger value only enlarges the ellipse)
+    const double disc = (double)(sqrtf((float)fmax(0.25 * tr * tr - det, 0.0)) * 1.000001f);
     double lmax = 0.5 * tr + disc;
-    const double lmin = det / lmax;
-    if (!(lmin > 0.0)) return;
-    if (lmax > 1000.0 * lmin) {
+    if (!(lmax > 0.0) || !(lmax < 1.0e300)) return;
+    if (lmax * lmax > 1000.0 * det) {                        // lmax > 1000 lmin with lmin = det / lmax
         // [[a, b/2], [b/2, c]] - (lmax - 1000 lmin) v v^T, v = unit eigenvector of lmax
+        const double lmin = det / lmax;
+        if (!(lmin > 0.0)) return;
         double vx = 0.5 * b, vy = lmax - a;
         if (fabs(vx) + fabs(vy) < 1e-300 * lmax || a > c) { vx = lmax - c; vy = 0.5 * b; }
         const double n2 = vx * vx + vy * vy;
@@ -175,7 +181,7 @@ __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float t
         lmax = 1000.0 * lmin;
         if (!(a > 0.0) || !(c > 0.0) || !(a * c - 0.25 * b * b > 0.0)) return;
     }
-    const double s = 1.001 + 0.05 * sqrt(lmax);              // 0.05 px / semi-minor axis (= 1/sqrt(lmax))
+    const double s = 1.001 + 0.05 * (double)(sqrtf((float)lmax) * 1.000001f);   // 0.05 px / semi-minor axis (= 1/sqrt(lmax))
     const double px = cx * focal_x + W / 2. - 0.5, py = cy * focal_y + H / 2. - 0.5;      // pixel-index coordinates
     if (!(fabs(px) < 8192.0) || !(fabs(py) < 8192.0)) return;
     const double is2 = 1.0 / (s * s);
@@ -199,7 +205,8 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                   float4* __restrict__ bbox_out, float4* __restrict__ cull_out,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
-                  unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all, int tile_cull)
+                  unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all, int tile_cull,
+                  double inv_focal_x, double inv_focal_y)
 {
     const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
@@ -434,7 +441,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                         cq = cull_conic(vg, thr, tan_fovx, tan_fovy);
                     if (bbox_out)
                         box = conservative_box(cq, thr, have_scale, W, H, focal_x, focal_y);
-                    conservative_ellipse(cq, thr, have_scale, W, H, focal_x, focal_y, ce, cec);
+                    conservative_ellipse(cq, thr, have_scale, W, H, focal_x, focal_y, inv_focal_x, inv_focal_y, ce, cec);
                 }
                 if (tile_cull) {
                     // Tile culling (option "tile_cull"): the reference instantiates the Gaussian in every tile of the square around
@@ -509,7 +516,8 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
-                       depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all, tile_cull);
+                       depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all, tile_cull,
+                       1.0 / (double)focal_x, 1.0 / (double)focal_y);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
