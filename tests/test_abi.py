@@ -38,7 +38,8 @@ def test_workspace_arithmetic_and_host_side_errors(f3d):
     b = L.f3dg_workspace_bytes(65536, 256, 256, 1, 400000)
     c = L.f3dg_workspace_bytes(65536, 256, 256, 8, 400000)
     assert 0 < a < b < c
-    assert b - a >= 200000 * 24                       # 2 x (u64 key + u32 value) per instance
+    assert b - a >= 200000 * 20                       # per instance: two u32 id halves, a 4-byte group half and the 8-byte half that
+                                                      # also holds the exported 64-bit keys
     assert L.f3dg_workspace_bytes(-1, 256, 256, 1, 10) == 0
     assert L.f3dg_workspace_bytes(10, 0, 256, 1, 10) == 0
     # argument validation happens before any HIP call, so it is testable without a GPU
