@@ -58,6 +58,9 @@ def parse():
                          "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
     ap.add_argument("--backbone", choices=["fp32", "bf16"], default="fp32",
                     help="c4: precision of the SongUNet backbone (bf16 = the opt-in autocast option, SURVEY 8f-3)")
+    ap.add_argument("--tile-cull", type=int, choices=[0, 1], default=1,
+                    help="1 (library default): a Gaussian is instantiated only in the tiles its alpha >= 1/255 ellipse reaches; "
+                         "0: the reference's tile lists (every tile of the 3-sigma square)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the second timed loop (frame packing + device-to-host copy)")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
@@ -142,6 +145,7 @@ def main():
         _lib.check(L.f3dg_set_option(b"render_round", int(os.environ["F3DG_RENDER_ROUND"])), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
+    _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
     result = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, rank, world, dist, device, comm_device, f3d, L)
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -171,7 +175,12 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
             radii=radii[a:b], save_aux=False, check=check)
         return ws
 
-    # calibration pass: sizes every chunk's workspace (capacity = max over chunks, +25 %), counts instances
+    # calibration passes (untimed). First with the reference's tile lists: R_total = the reference's num_rendered, the unit count of
+    # SURVEY 8d's byte formulas (the workload's size, whatever the implementation then skips). Then in the benched configuration:
+    # sizes every chunk's workspace (capacity = max over chunks, +25 %) and counts the instances the launches really process.
+    _lib.check(L.f3dg_set_option(b"tile_cull", 0), "f3dg_set_option")
+    R_total = sum(render_chunk(a, b, check=True).num_rendered for a, b in chunks)
+    _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
     counts = []
     for a, b in chunks:
         ws = render_chunk(a, b, check=True)
@@ -179,7 +188,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     for n in set(c[0] for c in counts):
         cap = int(max(c[1] for c in counts if c[0] == n) * 1.25) + 4096
         workspaces[n] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
-    R_total = sum(c[1] for c in counts)
+    R_proc = sum(c[1] for c in counts)
 
     gat = Gatherer(dist, world, rank, (V, RES, RES, 3), comm_device)
 
@@ -233,11 +242,12 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     # algorithmic bytes per launch, summed over the views of a launch
     nl = len(chunks)
     b_render = (72.0 * R_total + (36.0 * RES * RES + 8.0 * T) * V) / nl      # inference mode: the aux planes are not written
+    b_render_proc = (72.0 * R_proc + (36.0 * RES * RES + 8.0 * T) * V) / nl  # the same formula on the instances the launch is handed
     b_pre = 207.0 * P * V / nl
     sort_bits = 32 + T.bit_length()       # getHigherMsb(T) of rasterizer_impl.cu:35-50 (9 for 256 tiles): the reference sorts 41 bits
     b_bin = (20.0 * P * V + 12.0 * R_total + 24.0 * R_total * ((sort_bits + 7) // 8) + 8.0 * R_total + 8.0 * T * V) / nl
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    prof = profiles_record(P, V, RES, args.views_per_call, args.render_mode)
+    prof = profiles_record(P, V, RES, args.views_per_call, args.render_mode, args.tile_cull)
     result = {
         "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)",
         "value": world * V * args.steps / elapsed,
@@ -250,6 +260,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                                "compositing arithmetic: %s" % (P, args.sigma0, V, RES, RES, "fast (error-free float32 pairs; parity-gated at 1e-4)"
                                                                if args.render_mode == "fast" else "exact (reference float32/float64 order)"),
                    "gaussians": P, "views": V, "resolution": RES, "instances_per_step": R_total,
+                   "instances_processed_per_step": R_proc, "tile_cull": args.tile_cull,
                    "views_per_call": args.views_per_call, "render_mode": args.render_mode,
                    "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "render2_fwd_kernel<SAVE_AUX=false, FAST=%s>" % ("true" if args.render_mode == "fast" else "false"),
@@ -259,16 +270,23 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                      "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
                      "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
                      "algorithmic_bytes_per_launch": b_render, "ms_per_launch": per(stage_ms[2]),
+                     "units": "72 B x instances_per_step (the reference's num_rendered for this input: the workload's size) + 36 B x pixels "
+                              "+ 8 B x tiles; with tile culling the launch is handed instances_processed_per_step of them -- "
+                              "on that count the same formula gives achieved_on_processed_instances",
+                     "achieved_on_processed_instances": gbs(b_render_proc, per(stage_ms[2])),
+                     "frac_on_processed_instances": gbs(b_render_proc, per(stage_ms[2])) / HBM_PEAK_GBS,
                      "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
                                            "compositing": stage_ms[2] / args.steps}},
         "rooflines_other": {
             "preprocess_kernel": {"bound": "hbm", "algorithmic_bytes_per_launch": b_pre, "ms_per_launch": per(stage_ms[0]),
                                   "achieved": gbs(b_pre, per(stage_ms[0])), "unit": "GB/s", "frac": gbs(b_pre, per(stage_ms[0])) / HBM_PEAK_GBS,
                                   "formula": "207 B x P x views (92 read + 115 written per Gaussian and view)"},
-            "binning (scan + keys + sort + ranges, 16 kernels)": {
+            "binning (depth sort per Gaussian, instance generation, tile pass, ranges)": {
                 "bound": "hbm", "algorithmic_bytes_per_launch": b_bin, "ms_per_launch": per(stage_ms[1]),
                 "achieved": gbs(b_bin, per(stage_ms[1])), "unit": "GB/s", "frac": gbs(b_bin, per(stage_ms[1])) / HBM_PEAK_GBS,
-                "formula": "20 P + 12 R (keys) + 24 R x ceil(%d key bits / 8) (the reference's radix passes) + 8 R + 8 T (ranges)" % sort_bits}},
+                "formula": "20 P + 12 R (keys) + 24 R x ceil(%d key bits / 8) (the reference's radix passes) + 8 R + 8 T (ranges): the bytes of "
+                           "the REFERENCE's algorithm (a %d-bit sort of every instance); this stage sorts the Gaussians by depth once per view "
+                           "and the instances by tile only, so it moves fewer bytes and frac can exceed 1" % (sort_bits, sort_bits)}},
     }
     if d2h:
         result["with_d2h"] = d2h
@@ -360,8 +378,11 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
     dpix[:, 7] = 0
     kw = dict(image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"],
               rotations=g["rotation"], sh_degree=1, save_aux=True)
+    _lib.check(L.f3dg_set_option(b"tile_cull", 0), "f3dg_set_option")       # the reference's num_rendered: unit count of the byte formulas
+    R = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, **kw)[2].num_rendered
+    _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
     out, radii, ws = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, **kw)
-    R = ws.num_rendered
+    R_proc = ws.num_rendered
 
     def step():
         f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, workspace=ws,
@@ -393,10 +414,13 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (+f64 islands, as the reference)", "data": "synthetic",
         "config": {"workload": "C5: %d Gaussians (sigma0=%g), %d views @%dx%d, forward with auxiliary planes + backward "
                                "(random dL/dpix on channels 0-6, 8); views/s counts a forward + backward as one view" % (P, args.sigma0, V, RES, RES),
-                   "gaussians": P, "views": V, "resolution": RES, "instances_per_step": R, "contributing_pairs_per_step": pairs.value},
+                   "gaussians": P, "views": V, "resolution": RES, "instances_per_step": R, "instances_processed_per_step": R_proc,
+                   "tile_cull": args.tile_cull, "contributing_pairs_per_step": pairs.value},
         "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel", "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": stage_ms[3] / n,
                      "achieved": gbs(b_bwd, stage_ms[3] / n), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(b_bwd, stage_ms[3] / n) / HBM_PEAK_GBS,
-                     "traffic": None, "formula": "80 R + 60 W H V + 68 C (C = contributing pairs, counted by the kernel)"},
+                     "traffic": None, "formula": "80 R + 60 W H V + 68 C (R = instances_per_step, the reference's num_rendered; C = contributing "
+                                                 "pairs, counted by the kernel)",
+                     "frac_on_processed_instances": gbs(80.0 * R_proc + 60.0 * RES * RES * V + 68.0 * pairs.value, stage_ms[3] / n) / HBM_PEAK_GBS},
         "rooflines_other": {
             "render2_fwd_kernel<SAVE_AUX=true, FAST=false>": {"bound": "hbm", "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": stage_ms[2] / n,
                                                                "achieved": gbs(b_fwd, stage_ms[2] / n), "unit": "GB/s",
@@ -424,7 +448,7 @@ def measured_copy_bandwidth(device, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def profiles_record(P, V, RES, views_per_call, mode):
+def profiles_record(P, V, RES, views_per_call, mode, tile_cull=1):
     """Counter-derived figures of the compositing kernel from the newest committed profile of THIS configuration
     (profiles/*/traffic.json, written by tools/make_profile.py from separate rocprofv3 --pmc passes of this same command):
     `traffic` = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md),
@@ -435,7 +459,7 @@ def profiles_record(P, V, RES, views_per_call, mode):
             t = json.load(open(path))
             c = t["config"]
             if (c["gaussians"], c["views"], c["resolution"], c["views_per_call"]) == (P, V, RES, views_per_call) and \
-                    c.get("render_mode", "exact") == mode:
+                    c.get("render_mode", "exact") == mode and c.get("tile_cull", 0) == tile_cull:
                 src = os.path.relpath(path, ROOT)
                 best = {"traffic": {"bytes_per_launch": t["traffic_bytes_per_launch"], "source": src,
                                     "note": "builder-side PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run"},

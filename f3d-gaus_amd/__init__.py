@@ -23,4 +23,12 @@ from .gaussian_renderer import (render_predicted_more_v2_gof, render_predicted_m
 from .gaussian_predictor import GaussianSplatPredictor_gtunet, splat_head  # noqa: E402,F401
 from .unet_gs import Unet_GS_gtunet  # noqa: E402,F401
 
+
+
+def set_option(name, value):
+    """Process-wide runtime switch of the HIP library (include/f3dg.h, f3dg_set_option): e.g. ``set_option("tile_cull", 0)`` for the
+    reference's tile lists bit for bit, ``set_option("render_fast", 0)`` for the reference's float32/float64 compositing order."""
+    _lib.check(_lib.lib().f3dg_set_option(name.encode() if isinstance(name, str) else name, int(value)), "f3dg_set_option")
+
+
 __version__ = "0.1.0"

@@ -6,6 +6,8 @@ TAG=${1:-r02}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp
 python $R/bench.py > $O/bench_default.log 2>&1
 python $R/bench.py --render-mode exact --no-cpu-baseline > $O/bench_exact.log 2>&1
+python $R/bench.py --tile-cull 0 --no-cpu-baseline > $O/bench_nocull.log 2>&1
+python $R/tools/bench_small_calls.py > $O/small_calls.log 2>&1
 B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-d2h"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B > /dev/null 2>&1
@@ -29,4 +31,4 @@ cd $R
 python tests/tools/parity_report.py > $O/parity_report.md 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
-for f in bench_default bench_exact bench_c5 bench_c4_fp32 bench_c4_bf16 bench_c4_bf16_64; do grep '^{' $O/$f.log | tail -1 | cut -c1-330; done
+for f in bench_default bench_exact bench_nocull bench_c5 bench_c4_fp32 bench_c4_bf16 bench_c4_bf16_64; do grep '^{' $O/$f.log | tail -1 | cut -c1-330; done

@@ -85,7 +85,7 @@ def main():
         valu["kernel_us_rocprof"] = kernel_us
     t = {"kernel": rk,
          "config": {"gaussians": cfg["gaussians"], "views": cfg["views"], "resolution": cfg["resolution"], "views_per_call": cfg["views_per_call"],
-                    "render_mode": cfg.get("render_mode", "exact")},
+                    "render_mode": cfg.get("render_mode", "exact"), "tile_cull": cfg.get("tile_cull", 0)},
          "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
          "traffic_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024, "valu": valu,
          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncalibrated"}
