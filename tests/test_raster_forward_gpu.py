@@ -31,10 +31,11 @@ SCENES = {
     "F5_odd_size": dict(P=4000, res=(100, 72), s0=0.04, view="oblique"),
     "F6_small_splats": dict(P=30000, res=(128, 128), s0=0.01, view="oblique"),
     "F8_sh0": dict(P=1500, res=(64, 64), s0=0.05, view="oblique", sh_degree=0),
-    "F9_long_tile_lists": dict(P=30000, res=(128, 128), s0=0.05, view="oblique"),      # lists of 4k..16k: 512-thread LDS tile sort
+    "F9_long_tile_lists": dict(P=30000, res=(128, 128), s0=0.05, view="oblique"),      # tile lists of 4k..16k entries
     "F11_wide_radix": dict(P=20000, res=(320, 272), s0=0.02, view="oblique"),         # 340 tiles: two 8-bit tile passes
     "F12_depth_spread": dict(P=800, res=(64, 64), s0=0.3, view="canonical", depth_range=(1.0, 30.0)),   # distortion values > 1e-4: rel 1e-3 applies
-    "F10_huge_tile_lists": dict(P=50000, res=(32, 32), s0=0.05, view="canonical"),     # lists > 16320: global-memory tile sort path
+    "F10_huge_tile_lists": dict(P=50000, res=(32, 32), s0=0.05, view="canonical"),     # 4 tiles with lists > 16320 entries
+    "F13_single_tile": dict(P=300, res=(16, 12), s0=0.05, view="canonical"),          # one tile: no tile pass at all
 }
 
 
@@ -83,8 +84,14 @@ def test_forward_without_aux_matches_with_aux(gpu_device):
     assert np.array_equal(a["out_color"], b["out_color"])
 
 
-def test_forward_batched_views_equal_single_views(gpu_device):
-    scene = make_scene(P=8000, res=(128, 128), s0=0.03, view=[0, 1, 3, 5, 6, 2, 4, 7, 8])   # 9 views: two XCD groups
+@pytest.mark.parametrize("kw", [
+    dict(P=8000, res=(128, 128), s0=0.03, view=[0, 1, 3, 5, 6, 2, 4, 7, 8]),       # 9 views: one XCD group of 8 + one spread view
+    # odd P (a view's key segment starts at any address), depths over 1..30 (key ranges beyond 2^24: the four-pass depth sort)
+    dict(P=4001, res=(96, 80), s0=0.2, view=[0, 3, 5], depth_range=(1.0, 30.0)),
+    dict(P=12289, res=(320, 272), s0=0.02, view=[1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 2]),  # 340 tiles: two tile passes, 11 views, odd P
+], ids=["orbit9", "odd_P_depth_spread", "two_tile_passes_11_views"])
+def test_forward_batched_views_equal_single_views(gpu_device, kw):
+    scene = make_scene(**kw)
     h = run_hip(scene, gpu_device)
     T = h["ranges"].shape[1]
     total = 0
