@@ -26,6 +26,7 @@
 // Arithmetic: the reference's float32 / float64 operation order, no contraction (-ffp-contract=off); only expf differs
 // (device libm vs glibc), as in the compositing kernel.
 #include "f3dg_common.h"
+#include "f3dg_ellipse.h"
 
 namespace {
 
@@ -229,6 +230,196 @@ integrate_pass1_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, 
                 st.nloc += 1;
                 if (st.nloc >= F3DG_MAX_CONTRIB)
                     done = true;                                    // "Maximal contributors are met", forward.cu:972-976
+            }
+        }
+    }
+
+    if (inside) {                                                  // forward.cu:984-996
+        final_T[pix_id] = st.Ts[0];
+        n_contrib[pix_id] = st.last_contributor;
+        contrib_n[pix_id] = st.nloc;
+        out_color[0 * HW + pix_id] = st.C0 + st.Ts[0] * background[0];
+        out_color[1 * HW + pix_id] = st.C1 + st.Ts[0] * background[1];
+        out_color[2 * HW + pix_id] = st.C2 + st.Ts[0] * background[2];
+        out_color[3 * HW + pix_id] = 0.0f;                         // the caller's zero fill, rasterize_points.cu:273
+        out_color[4 * HW + pix_id] = 0.0f;
+        out_color[5 * HW + pix_id] = 0.0f;
+        out_color[6 * HW + pix_id] = st.C6;
+        out_color[7 * HW + pix_id] = st.C7;
+    }
+}
+
+// The same pass with the culling machinery of the compositing forward (f3dg_render.hip: render2): the per-ray K pre-test above costs
+// ~25 instructions per (ray, Gaussian) = 125 per (pixel, list entry), and no pixel ever leaves the loop early here (a saturated ray
+// `continue`s), so the pass was 60-90 % of an integrate call. A list entry is instead tested ONCE per pixel against the record's
+// conservative alpha >= 1/255 ellipse, Gaussians across the lanes (two FMAs per pixel, one comparison = one wave ballot), and only
+// the passing (pixel, entry) pairs go through the five rays. The corner rays leave the pixel centre by (+-0.5, +-0.5) px: the ellipse
+// is scaled uniformly about its centre by 1 + 0.7072 px / semi-minor axis, which contains its Minkowski sum with that square
+// (a >= b: (a + r, b + r) fits inside (a, b) (b + r) / b). As everywhere, this only removes pairs the reference `continue`s on.
+__global__ void __launch_bounds__(F3DG_BLOCK)
+integrate_pass1_cull_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
+                            const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
+                            const F3dgRec* __restrict__ rec, const float4* __restrict__ cull,
+                            const float* __restrict__ background, float* __restrict__ out_color,
+                            float* __restrict__ final_T, unsigned* __restrict__ n_contrib,
+                            unsigned short* __restrict__ contrib_ids, unsigned* __restrict__ contrib_n)
+{
+    constexpr int ROUND = F3DG_BLOCK;             // staged entries per round (byte indices 0..255)
+    const unsigned tile = blockIdx.x;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned grp = lane >> 4, gi = lane & 15u;
+    const unsigned blk_x = (wave & 1u) * 2u + (grp & 1u), blk_y = (wave >> 1) * 2u + (grp >> 1);
+    const unsigned lx = blk_x * 4u + (gi & 3u), ly = blk_y * 4u + (gi >> 2);
+    const unsigned pix_x = tile_x * F3DG_TILE + lx, pix_y = tile_y * F3DG_TILE + ly;
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float rx0 = (float)((pixf_x + 0.0f - W / 2.) / focal_x), ry0 = (float)((pixf_y + 0.0f - H / 2.) / focal_y);
+    const float rxm = (float)((pixf_x + -0.5f - W / 2.) / focal_x), rym = (float)((pixf_y + -0.5f - H / 2.) / focal_y);
+    const float rxp = (float)((pixf_x + 0.5f - W / 2.) / focal_x), ryp = (float)((pixf_y + 0.5f - H / 2.) / focal_y);
+    const float blk_px0 = (float)(tile_x * F3DG_TILE + blk_x * 4u), blk_py0 = (float)(tile_y * F3DG_TILE + blk_y * 4u);
+    const float tile_px0 = (float)(tile_x * F3DG_TILE), tile_py0 = (float)(tile_y * F3DG_TILE);
+
+    uint2 range = ranges[tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const int rounds = (int)((range.y - range.x + ROUND - 1) / ROUND);
+
+    __shared__ float4 sq0[ROUND], sq1[ROUND], sq2[ROUND], sq3[ROUND];      // v0..v3 | v4..v7 | v8 v9 opac K | r g b -
+    __shared__ float4 sE[ROUND];                  // inflated ellipse: cx cy a b
+    __shared__ float sF[ROUND];                   //                    c
+    __shared__ unsigned short sM[ROUND];          // which of the tile's 16 4x4 blocks its box touches
+    __shared__ __align__(16) unsigned char lists[F3DG_BLOCK / 64][4][ROUND];
+    __shared__ int done_cnt[2];
+    if (threadIdx.x < 2) done_cnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned pull = (gi + 16u * (grp >> 1)) * 4u;       // ds_bpermute source of this pixel's ballot half
+    const unsigned pull_shift = 16u * (grp & 1u);
+    const unsigned char* my_list = lists[wave][grp];
+
+    bool done = !inside;
+    Pass1State st;
+#pragma unroll
+    for (int k = 0; k < 5; k++) st.Ts[k] = 1.0f;
+    st.C0 = st.C1 = st.C2 = st.C6 = st.C7 = 0;
+    st.last_contributor = 0; st.nloc = 0;
+    unsigned short* my_ids = contrib_ids + pix_id * F3DG_MAX_CONTRIB;
+
+    for (int i = 0; i < rounds; i++) {
+        const unsigned long long alive = __ballot(!done);
+        if (lane == 0)
+            atomicAdd(&done_cnt[i & 1], 64 - __popcll(alive));
+        __syncthreads();
+        const int num_done = done_cnt[i & 1];
+        if (threadIdx.x == 0)
+            done_cnt[(i + 1) & 1] = 0;
+        if (num_done == F3DG_BLOCK)
+            break;
+
+        const unsigned progress = (unsigned)i * ROUND + threadIdx.x;
+        unsigned short m16 = 0;
+        if (range.x + progress < range.y) {
+            const unsigned id = point_list[range.x + progress];
+            const float4* src = reinterpret_cast<const float4*>(rec + id);
+            const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+            float4 e = cull[id];
+            float ec = d.w;
+            // scale about the centre by s = 1 + 0.7072 sqrt(lmax) (lmax = 1 / semi-minor axis^2), rounded outwards; "everything"
+            // records (a = b = c = 0) stay what they are, an overflowing lmax ends as a = b = c = 0 = "everything"
+            const float hd = 0.5f * (e.z - ec);
+            const float lmax = 0.5f * (e.z + ec) + sqrtf(hd * hd + 0.25f * e.w * e.w);
+            const float sc = 1.0f + 0.70715f * sqrtf(lmax) * 1.0001f;
+            const float inv = (1.0f / (sc * sc)) * 0.99999f;
+            e.z *= inv; e.w *= inv; ec *= inv;
+            if (!(e.z == e.z) || !(e.w == e.w) || !(ec == ec)) { e.z = 0.0f; e.w = 0.0f; ec = 0.0f; }
+            sq0[threadIdx.x] = a; sq1[threadIdx.x] = b; sq2[threadIdx.x] = c; sq3[threadIdx.x] = d;
+            sE[threadIdx.x] = e;
+            sF[threadIdx.x] = ec;
+            m16 = (unsigned short)ellipse_block_mask(e, ec, tile_px0, tile_py0);
+        }
+        sM[threadIdx.x] = m16;
+        __syncthreads();
+
+        // four compacted lists per wave, one per 16-lane group (4x4 block), in list order
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        {
+            const unsigned qx2 = (wave & 1u) * 2u, qy2 = (wave >> 1) * 2u;
+            const bool g0 = (alive & 0xFFFFull) != 0, g1 = (alive & 0xFFFF0000ull) != 0, g2 = (alive & 0xFFFF00000000ull) != 0,
+                       g3 = (alive >> 48) != 0;
+#pragma unroll
+            for (int c = 0; c < ROUND / 64; c++) {
+                const unsigned e = c * 64 + lane;
+                const unsigned m = sM[e];
+                const bool b0 = g0 && ((m >> ((qy2 + 0u) * 4u + qx2 + 0u)) & 1u), b1 = g1 && ((m >> ((qy2 + 0u) * 4u + qx2 + 1u)) & 1u);
+                const bool b2 = g2 && ((m >> ((qy2 + 1u) * 4u + qx2 + 0u)) & 1u), b3 = g3 && ((m >> ((qy2 + 1u) * 4u + qx2 + 1u)) & 1u);
+                const unsigned long long l0 = __ballot(b0), l1 = __ballot(b1), l2 = __ballot(b2), l3 = __ballot(b3);
+                if (b0) lists[wave][0][c0 + __popcll(l0 & lt)] = (unsigned char)e;
+                if (b1) lists[wave][1][c1 + __popcll(l1 & lt)] = (unsigned char)e;
+                if (b2) lists[wave][2][c2 + __popcll(l2 & lt)] = (unsigned char)e;
+                if (b3) lists[wave][3][c3 + __popcll(l3 & lt)] = (unsigned char)e;
+                c0 += __popcll(l0); c1 += __popcll(l1); c2 += __popcll(l2); c3 += __popcll(l3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const int count = max(max(c0, c1), max(c2, c3));
+        const int my_len = grp == 0 ? c0 : grp == 1 ? c1 : grp == 2 ? c2 : c3;
+        const unsigned round_base = (unsigned)i * ROUND;
+
+        for (int w0 = 0; w0 < count; w0 += 64) {
+            // ---- phase 1: lane (g, e) tests entry w0 + 16 sub + e of group g's list against the 16 pixels of g's block
+            unsigned pass_lo = 0, pass_hi = 0;
+#pragma unroll 1
+            for (int sub = 0; sub < 4; sub++) {
+                const int base = w0 + 16 * sub;
+                if (base >= count)
+                    break;
+                const int pos = base + (int)gi;
+                const int j = (int)my_list[pos];
+                const float4 e = sE[j];
+                const float cc = sF[j];
+                const float u0 = pos < my_len ? blk_px0 - e.x : __builtin_nanf("");     // NaN: every comparison below is false
+                const float v0 = blk_py0 - e.y;
+                float dxx[4], adx[4], dyy[4], cdy[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    dxx[q] = u0 + (float)q;
+                    adx[q] = e.z * dxx[q];
+                    dyy[q] = v0 + (float)q;
+                    cdy[q] = cc * dyy[q] * dyy[q];
+                }
+                int stage = 0;
+                ellipse_ballots<0>(stage, fmaf(dxx[0], fmaf(e.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e.w);
+                const unsigned piece = ((unsigned)__builtin_amdgcn_ds_bpermute((int)pull, stage) >> pull_shift) & 0xFFFFu;
+                if (sub & 2) pass_hi |= piece << (16 * (sub & 1));
+                else pass_lo |= piece << (16 * (sub & 1));
+            }
+            unsigned long long pass = done ? 0ull : ((unsigned long long)pass_hi << 32) | pass_lo;
+
+            // ---- phase 2: the five rays of this pixel through its own passing entries, in list order
+            while (pass != 0 && !done) {
+                const int kk = __builtin_ctzll(pass);
+                pass &= pass - 1;
+                const int j = (int)my_list[w0 + kk];
+                const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j], q3 = sq3[j];
+                bool used = false;
+                used |= ray_entry<true, 0>(st, rx0, ry0, q0, q1, q2, q3);
+                used |= ray_entry<true, 1>(st, rxm, rym, q0, q1, q2, q3);
+                used |= ray_entry<true, 2>(st, rxp, rym, q0, q1, q2, q3);
+                used |= ray_entry<true, 3>(st, rxm, ryp, q0, q1, q2, q3);
+                used |= ray_entry<true, 4>(st, rxp, ryp, q0, q1, q2, q3);
+                if (used) {
+                    const unsigned contributor = round_base + (unsigned)j + 1u;
+                    st.last_contributor = contributor;
+                    my_ids[st.nloc] = (unsigned short)contributor;     // (u_int16_t) cast of forward.cu:969
+                    st.nloc += 1;
+                    if (st.nloc >= F3DG_MAX_CONTRIB)
+                        done = true;                                    // "Maximal contributors are met", forward.cu:972-976
+                }
             }
         }
     }
@@ -481,7 +672,11 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, floa
     unsigned* n_contrib = reinterpret_cast<unsigned*>(ws + L.n_contrib);
     unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
     unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
-    if (g_f3dg_render_pretest && g_f3dg_render_cull)
+    if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel == 2)
+        hipLaunchKernelGGL(integrate_pass1_cull_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+                           hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
+                           out_color, final_T, n_contrib, contrib_ids, contrib_n);
+    else if (g_f3dg_render_pretest && g_f3dg_render_cull)          // round 1's version: per-ray pre-test + block masks from the boxes
         hipLaunchKernelGGL((integrate_pass1_kernel<true>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);

@@ -100,7 +100,9 @@ __device__ __forceinline__ CullConic cull_conic(const float* vg, float thr, floa
     const double A = fabs((double)vg[0]) * X * X + 2.0 * fabs((double)vg[1]) * X * Y + 2.0 * fabs((double)vg[2]) * X +
                      fabs((double)vg[3]) * Y * Y + 2.0 * fabs((double)vg[4]) * Y + fabs((double)vg[5]);
     const double Bn = fabs((double)vg[6]) * X + fabs((double)vg[7]) * Y + fabs((double)vg[8]);
-    const double D = 1.1 * 6.0 * u * (cK * A + Bn * Bn);
+    // (7u on the b term: integrate's loop divides BB / AA in float32, forward.cu:917, one more rounding of b^2 / a than the 6u of the
+    // compositing loop's float64 division)
+    const double D = 1.1 * u * (6.0 * cK * A + 7.0 * Bn * Bn);
     const double B0 = vg[6], B1 = vg[7], B2 = vg[8];
     q.m00 = cK * vg[0] - B0 * B0; q.m01 = cK * vg[1] - B0 * B1; q.m02 = cK * vg[2] - B0 * B2;
     q.m11 = cK * vg[3] - B1 * B1; q.m12 = cK * vg[4] - B1 * B2; q.m22 = cK * vg[5] - B2 * B2 - D;

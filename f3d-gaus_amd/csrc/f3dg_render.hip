@@ -40,6 +40,7 @@
 //  * t = -BB/(2*AA) is a double quotient of float-valued operands rounded to float: identical to ONE IEEE float32
 //    divide (double rounding is innocuous for p = 24, q = 53 >= 2p + 2), so the float64 divide is not needed.
 #include "f3dg_common.h"
+#include "f3dg_ellipse.h"
 
 namespace {
 
@@ -435,26 +436,6 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 // arithmetic mode (tests/test_raster_forward_gpu.py::test_render2_bit_identical).
 
 
-// 16-bit mask of the tile's 4x4 blocks (bit 4 * row + column) that the axis-aligned box of a Gaussian's conservative ellipse
-// (e = (cx, cy, a, b), c; f3dg_preprocess.hip) touches. Half extents of a x^2 + b x y + c y^2 <= 1: sqrt(c / det), sqrt(a / det)
-// with det = a c - b^2 / 4, evaluated in float32 (relative error <= ~3e-5 for the aspect ratios the records are limited to)
-// and widened by 0.05 % + 2e-3 px. "everything" records (a = b = c = 0) give det = 0: every block.
-__device__ __forceinline__ unsigned ellipse_block_mask(float4 e, float c, float tile_px0, float tile_py0)
-{
-    const float det = fmaf(e.z, c, -0.25f * e.w * e.w);
-    if (!(det > 0.0f))
-        return 0xFFFFu;
-    const float hx = sqrtf(c / det) * 1.0005f + 2e-3f, hy = sqrtf(e.z / det) * 1.0005f + 2e-3f;
-    const float x0 = e.x - hx, x1 = e.x + hx, y0 = e.y - hy, y1 = e.y + hy;
-    unsigned mx = 0, my = 0;                          // which of the 4 block columns / rows the box touches
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if (x0 <= tile_px0 + (float)(4 * q + 3) && x1 >= tile_px0 + (float)(4 * q)) mx |= 1u << q;
-        if (y0 <= tile_py0 + (float)(4 * q + 3) && y1 >= tile_py0 + (float)(4 * q)) my |= 1u << q;
-    }
-    return ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 4 : 0u) | ((my & 4u) ? mx << 8 : 0u) | ((my & 8u) ? mx << 12 : 0u);
-}
-
 // ---- optional phase timing (build with -DF3DG_TIMING: tools/render_timing.py). Shader-clock cycles per wave, summed over all
 // waves of all launches since the last reset: [0] barrier waits, [1] staging, [2] list build, [3] phase 1, [4] phase 2,
 // [5] unused, [6] total, [7] waves.
@@ -469,39 +450,6 @@ __device__ unsigned long long g_f3dg_timing[8];
 #define F3DG_T_MARK(k) do { } while (0)
 #define F3DG_T_FLUSH do { } while (0)
 #endif
-
-// Phase 1 of render2 for pixel P of the lane's 4x4 block (and, recursively, the following ones). One comparison = one wave
-// ballot (v_cmp writes a lane mask); two v_writelane_b32 (which ignore EXEC and take the SGPR halves as data) park it in lanes
-// P and 16 + P of `stage`. gfx950 needs two wait states between a VALU write of an SGPR / VCC and a VALU read of it, which the
-// compiler cannot see inside inline assembly: the two FMAs that evaluate the NEXT pixel's ellipse value are placed in that gap
-// (s_nop for the last pixel), so the sequence costs no extra issue slots.
-template <int P>
-__device__ __forceinline__ void ellipse_ballots(int& stage, float Ep, const float (&dxx)[4], const float (&adx)[4],
-                                                const float (&dyy)[4], const float (&cdy)[4], float eb)
-{
-    if constexpr (P < 15) {
-        float En;
-        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
-            "v_fma_f32 %[en], %[eb], %[dy], %[ax]\n\t"
-            "v_fma_f32 %[en], %[dx], %[en], %[cy]\n\t"
-            "v_writelane_b32 %[st], vcc_lo, %[l0]\n\t"
-            "v_writelane_b32 %[st], vcc_hi, %[l1]"
-            : [st] "+v"(stage), [en] "=&v"(En)
-            : [ep] "v"(Ep), [eb] "v"(eb), [dy] "v"(dyy[(P + 1) >> 2]), [ax] "v"(adx[(P + 1) & 3]), [dx] "v"(dxx[(P + 1) & 3]),
-              [cy] "v"(cdy[(P + 1) >> 2]), [l0] "n"(P), [l1] "n"(16 + P)
-            : "vcc");
-        ellipse_ballots<P + 1>(stage, En, dxx, adx, dyy, cdy, eb);
-    } else {
-        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
-            "s_nop 1\n\t"
-            "v_writelane_b32 %[st], vcc_lo, %[l0]\n\t"
-            "v_writelane_b32 %[st], vcc_hi, %[l1]\n\t"
-            "s_nop 0"
-            : [st] "+v"(stage)
-            : [ep] "v"(Ep), [l0] "n"(P), [l1] "n"(16 + P)
-            : "vcc");
-    }
-}
 
 template <bool SAVE_AUX, bool FAST, int ROUND, int OCC>
 __global__ void __launch_bounds__(F3DG_BLOCK, OCC)

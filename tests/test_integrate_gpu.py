@@ -43,22 +43,31 @@ def test_integrate_matches_oracle(name):
     assert_integrate_parity(o, h, name)
 
 
-def test_integrate_filters_are_bit_identical():
+@pytest.mark.parametrize("kw", [dict(P=20000, res=(128, 128), s0=0.03, view="oblique"),
+                                dict(P=3000, res=(96, 80), s0=0.3, view="oblique", aniso=True),        # large, flat splats
+                                dict(P=60000, res=(64, 64), s0=0.004, view="canonical")],               # sub-pixel splats
+                         ids=["mid", "large_aniso", "tiny"])
+def test_integrate_filters_are_bit_identical(kw):
     """The culled lists + K pre-test of pass 1 only remove (ray, Gaussian) pairs the reference `continue`s on."""
-    scene = make_scene(P=20000, res=(128, 128), s0=0.03, view="oblique")
+    scene = make_scene(**kw)
     pts = make_points(scene, 50000)
     L = _lib.lib()
     res = []
     try:
-        for on in (1, 0):
+        # (2, 1): the default, per-pixel ellipse test with Gaussians across the lanes; (1, 1): round 1's per-ray pre-test + box masks;
+        # (2, 0): the plain transcription every variant must match bit for bit
+        for kernel, on in ((2, 1), (1, 1), (2, 0)):
+            L.f3dg_set_option(b"render_kernel", kernel)
             L.f3dg_set_option(b"render_pretest", on)
             L.f3dg_set_option(b"render_cull", on)
             res.append(run_both(scene, pts, torch.device("cuda:0"))[1])
     finally:
+        L.f3dg_set_option(b"render_kernel", 2)
         L.f3dg_set_option(b"render_pretest", 1)
         L.f3dg_set_option(b"render_cull", 1)
-    for k in ("out", "ai", "ci", "radii"):
-        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+    for r in res[:2]:
+        for k in ("out", "ai", "ci", "radii"):
+            assert np.array_equal(r[k].view(np.uint32), res[2][k].view(np.uint32)), k
 
 
 def test_integrate_empty_inputs():

@@ -16,7 +16,10 @@ from f3dgaus_amd.diff_gof_rasterization import GaussianRasterizationSettings_GOF
 
 dev = torch.device("cuda:0")
 RES = 256
-for P, PN, s0 in ((196608, 1_000_000, 0.01), (589824, 1_000_000, 0.01), (196608, 1_000_000, 0.05)):
+CONFIGS = ((196608, 1_000_000, 0.01), (589824, 1_000_000, 0.01), (196608, 1_000_000, 0.05))
+if os.environ.get("CFG"):            # one configuration only (so that rocprofv3 --stats averages belong to it), no sweep
+    CONFIGS = (CONFIGS[int(os.environ["CFG"])],)
+for P, PN, s0 in CONFIGS:
     g = synthetic.make_gaussians(P, s0=s0, seed=0)
     cams = synthetic.orbit_cameras(8, resolution=RES, include_canonical=True)
     gen = torch.Generator().manual_seed(1)
@@ -41,7 +44,17 @@ for P, PN, s0 in ((196608, 1_000_000, 0.01), (589824, 1_000_000, 0.01), (196608,
     dt = (time.perf_counter() - t0) / n
     print(f"integrate P={P} sigma0={s0} PN={PN} @{RES}^2: {dt * 1e3:.2f} ms/call | points in image {int(color[8].sum().item())}, "
           f"max points/pixel {int(color[8].max().item())}, mean alpha_integrated {ai.mean().item():.4f}")
+    # algorithmic bytes of the per-pixel pass (integrate_pass1_kernel), SURVEY 8d's compositing formula on this call's instances:
+    # 72 B per (Gaussian, tile) instance of the reference's lists + 36 B per pixel written + 2 B per contributor id it records
+    f3d.set_option("tile_cull", 0)
+    R = f3d.rasterize_views(args["means3D"], args["opacities"], rs.viewmatrix[None], rs.projmatrix[None], rs.campos[None], rs.bg,
+                            image_height=RES, image_width=RES, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, sh=shs, scales=args["scales"],
+                            rotations=args["rotations"], sh_degree=1)[2].num_rendered
+    f3d.set_option("tile_cull", 1)
+    print(f"  pass 1 of that call: R = {R} instances -> {72 * R + 36 * RES * RES} algorithmic bytes + the contributor lists")
 
+if os.environ.get("CFG"):
+    sys.exit(0)
 # ---- the mesh-extraction sweep (visualize.py:449-507): 9 point sets x V cameras of the merged 589,824 Gaussians
 from f3dgaus_amd import cameras as _cams  # noqa: E402
 P, PN, V, SETS = 589824, 1_000_000, int(os.environ.get("V", 16)), 9
