@@ -495,7 +495,12 @@ integrate_points_bin_kernel(int PN, const float* __restrict__ points3D, const fl
     const unsigned tile = (pix_y / F3DG_TILE) * (unsigned)tiles_x + pix_x / F3DG_TILE;
     pt_pix[idx] = pix_id;
     pt_rank[idx] = atomicAdd(&pix_points[pix_id], 1u);
-    atomicMax(&tile_last[tile], ((unsigned long long)__float_as_uint(depth) << 32) | idx);
+    // (1 M points share 256 tiles: thousands of atomics per address serialise at the L2. The running maximum only grows, so a point
+    // below the value it can already see -- a relaxed load that bypasses the L1 -- need not take part; a stale, lower value only
+    // costs an atomic that changes nothing)
+    const unsigned long long cand = ((unsigned long long)__float_as_uint(depth) << 32) | idx;
+    if (cand > __atomic_load_n(&tile_last[tile], __ATOMIC_RELAXED))
+        atomicMax(&tile_last[tile], cand);
 }
 
 __global__ void __launch_bounds__(F3DG_BLOCK)
