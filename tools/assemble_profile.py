@@ -59,6 +59,17 @@ def main():
             out.append(f"| `{k}` | {f_mb:.1f} | {w_mb:.1f} | {m['SQ_INSTS_VALU']:.3g} | {lanes:.2f} | {m['SQ_INSTS_LDS']:.3g} | {m['SQ_WAVE_CYCLES']:.3g} |")
         open(os.path.join(dst, "c5.md"), "w").write("\n".join(out) + "\n")
 
+    # ---- integrate
+    ilog = os.path.join(src, "bench_integrate.log")
+    if os.path.exists(ilog):
+        out = ["# integrate (Gaussians -> points), 1 M points @256x256 -- `python tools/bench_integrate.py`", "", "```"] + \
+              [l for l in open(ilog).read().splitlines() if l.startswith(("integrate P", "  pass 1", "mesh-extraction"))] + ["```", ""]
+        for c, label in ((0, "196,608 Gaussians, sigma0 = 0.01"), (1, "589,824 Gaussians, sigma0 = 0.01")):
+            st = glob.glob(os.path.join(src, f"int_stats{c}", "*kernel_stats.csv"))
+            if st:
+                out += [f"rocprofv3 --kernel-trace --stats of `CFG={c} python tools/bench_integrate.py` ({label}; 7 calls):", ""] + kernel_table(st[0], 12) + [""]
+        open(os.path.join(dst, "integrate.md"), "w").write("\n".join(out))
+
     # ---- every bench line of the run
     out = ["# Bench lines of the evidence run (tools/collect_r02.sh), one MI355X", ""]
     for log, cmd in (("bench_default", "python bench.py` (C2, fast arithmetic = the default)"),

@@ -27,6 +27,9 @@ rm -f $O/c5_stats/c5_kernel_trace.csv
 python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 > $O/bench_c4_fp32.log 2>&1
 python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone bf16 > $O/bench_c4_bf16.log 2>&1
 python $R/bench.py --workload c4 --images 64 --steps 1 --warmup 1 --backbone bf16 > $O/bench_c4_bf16_64.log 2>&1
+# integrate (Gaussians -> points): the whole bench, then one configuration per rocprofv3 run so that the averages belong to it
+python $R/tools/bench_integrate.py > $O/bench_integrate.log 2>&1
+for c in 0 1; do CFG=$c rocprofv3 --kernel-trace --stats --output-format csv -d $O/int_stats$c -o int -- python $R/tools/bench_integrate.py > $O/int_stats$c.log 2>&1; rm -f $O/int_stats$c/int_kernel_trace.csv; done
 cd $R
 python tests/tools/parity_report.py > $O/parity_report.md 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
