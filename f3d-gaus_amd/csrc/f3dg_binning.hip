@@ -605,34 +605,63 @@ gsort_gather_rects_kernel(int P, u32* __restrict__ gv0, u32* __restrict__ gv1, c
     }
 }
 
-// duplicateWithKeys in (view, depth, id) order: sorted position k of view v emits the tiles of Gaussian perm[v][k]
+// duplicateWithKeys in (view, depth, id) order: sorted position k of view v emits the tiles of Gaussian perm[v][k]. The runs of a
+// workgroup's 256 Gaussians are consecutive in the output (a few instances each), so they are assembled in LDS and written out as
+// whole lines; a workgroup whose Gaussians cover more than DUP_CAP tiles writes its runs directly.
+#define F3DG_DUP_CAP 3072
 template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict__ gv0, const u32* __restrict__ gv1,
                         const u32* __restrict__ minmax, const u32* __restrict__ rx, const u32* __restrict__ offsets_sorted,
                         const F3dgHeader* __restrict__ hdr, G* __restrict__ kgrp, u32* __restrict__ vals)
 {
+    __shared__ G sk[F3DG_DUP_CAP];
+    __shared__ u32 sv[F3DG_DUP_CAP];
     if (hdr->overflow) return;
     const int k = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
-    if (k >= P) return;
     u32 kbase;
     const bool pass2 = gsort_compact(minmax, (u32)v, kbase);      // as in gsort_gather_rects_kernel
     const u32* perm = pass2 ? gv1 : gv0;
     const u32* ry = pass2 ? gv0 : gv1;
-    const size_t pos = (size_t)v * P + k;
-    const u32 x = rx[pos], y = ry[pos];
-    const u32 rminx = x & 0xFFFFu, rmaxx = x >> 16, rminy = y & 0xFFFFu, rmaxy = y >> 16;
-    if (rmaxx > rminx && rmaxy > rminy) {
-        const u32 g = perm[pos];
-        u32 off = (pos == 0) ? 0 : offsets_sorted[pos - 1];
-        const u32 view_base = (u32)v << tile_bits;
-        for (u32 ty = rminy; ty < rmaxy; ty++)
-            for (u32 tx = rminx; tx < rmaxx; tx++) {
-                kgrp[off] = (G)(view_base | (ty * (u32)grid_x + tx));
-                vals[off] = g;
-                off++;
+    // output range of the workgroup
+    const size_t first = (size_t)v * P + (size_t)blockIdx.x * F3DG_BLOCK;
+    const int in_block = min(F3DG_BLOCK, P - (int)(blockIdx.x * F3DG_BLOCK));
+    const u32 base = first == 0 ? 0u : offsets_sorted[first - 1];
+    const u32 n = offsets_sorted[first + in_block - 1] - base;
+    const bool staged = n <= (u32)F3DG_DUP_CAP;
+    if (k < P) {
+        const size_t pos = (size_t)v * P + k;
+        const u32 x = rx[pos], y = ry[pos];
+        const u32 rminx = x & 0xFFFFu, rmaxx = x >> 16, rminy = y & 0xFFFFu, rmaxy = y >> 16;
+        if (rmaxx > rminx && rmaxy > rminy) {
+            const u32 g = perm[pos];
+            u32 off = (pos == 0) ? 0 : offsets_sorted[pos - 1];
+            const u32 view_base = (u32)v << tile_bits;
+            if (staged) {
+                off -= base;
+                for (u32 ty = rminy; ty < rmaxy; ty++)
+                    for (u32 tx = rminx; tx < rmaxx; tx++) {
+                        sk[off] = (G)(view_base | (ty * (u32)grid_x + tx));
+                        sv[off] = g;
+                        off++;
+                    }
+            } else {
+                for (u32 ty = rminy; ty < rmaxy; ty++)
+                    for (u32 tx = rminx; tx < rmaxx; tx++) {
+                        kgrp[off] = (G)(view_base | (ty * (u32)grid_x + tx));
+                        vals[off] = g;
+                        off++;
+                    }
             }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
+            kgrp[base + i] = sk[i];
+            vals[base + i] = sv[i];
+        }
     }
 }
 
