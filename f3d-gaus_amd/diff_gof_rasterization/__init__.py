@@ -374,8 +374,9 @@ class PreparedIntegration:
 
 
 def integrate_prepare(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp,
-                      raster_settings, max_points):
-    """``f3dg_integrate_prepare``: projection + binning + per-pixel pass of ``integrate`` for one camera."""
+                      raster_settings, max_points, buffer=None):
+    """``f3dg_integrate_prepare``: projection + binning + per-pixel pass of ``integrate`` for one camera. ``buffer``: an uint8 device
+    tensor to carve the workspace from (used when it is large enough for the capacity hint; a fresh allocation otherwise)."""
     L = _lib.lib()
     device = means3D.device
     if device.type != "cuda":
@@ -408,7 +409,10 @@ def integrate_prepare(means3D, sh, colors_precomp, opacities, scales, rotations,
             nbytes = L.f3dg_integrate_workspace_bytes(P, int(max_points), W, H, cap)
             if nbytes == 0:
                 raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_integrate_workspace_bytes")
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            if buffer is not None and buffer.numel() >= nbytes:
+                buf, buffer = buffer[:int(nbytes)], None
+            else:
+                buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             needed = C.c_longlong(0)
             rc = L.f3dg_integrate_prepare(
                 _stream(), C.c_void_p(buf.data_ptr()), buf.numel(), cap, int(max_points), P, int(rs.sh_degree), int(M),
