@@ -127,8 +127,9 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
     const float r = __builtin_amdgcn_rcpf(aaf);
     const float t0 = -bhalf * r;
     const float t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
-    if (t < 0.2f)                       // (double)t <= 0.2  <=>  t < 0.2f: 0.2f is the float just above 0.2 (false for NaN,
-        return false;                   // as the reference's test)
+    // (double)t <= 0.2  <=>  t < 0.2f: 0.2f is the float just above 0.2 (false for NaN, as the reference's test). Tested together
+    // with alpha below: a wave nearly always holds a lane that passes, so an early branch here only costs scalar instructions
+    const bool behind = t < 0.2f;
 
     const float p = bhalf * bhalf;
     const float e = fmaf(bhalf, bhalf, -p);
@@ -140,7 +141,7 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
         power = 0.0f;
 
     const float alpha = fminf(0.99f, opac * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
-    if (alpha < 1.0f / 255.0f)
+    if (behind || alpha < 1.0f / 255.0f)
         return false;
     const float Tr = st.Tr;
     const float test_T = Tr * (1 - alpha);
