@@ -560,6 +560,9 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             float g_col0 = 0, g_col1 = 0, g_col2 = 0, g_mx = 0, g_my = 0, g_mz = 0, g_op = 0;
             float g_v0 = 0, g_v1 = 0, g_v2 = 0, g_v3 = 0, g_v4 = 0, g_v5 = 0, g_v6 = 0, g_v7 = 0, g_v8 = 0, g_v9 = 0;
             if (active) {
+                // gradient terms only from here (alpha, the one value that must repeat the forward's bits, is done): products and sums
+                // may contract into FMAs (the file is built with -ffp-contract=off for the alpha path)
+#pragma clang fp contract(fast)
                 const float4 q3 = sq3[j];
                 const float4 con = staged_conic[j];
                 const float2 xy = staged_xy[j];

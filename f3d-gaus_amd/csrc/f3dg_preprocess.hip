@@ -88,6 +88,7 @@ __device__ __forceinline__ float pretest_constant(const float* vg, float thr)
 struct CullConic { double m00, m01, m02, m11, m12, m22; bool ok; };
 __device__ __forceinline__ CullConic cull_conic(const float* vg, float thr, float tan_fovx, float tan_fovy)
 {
+#pragma clang fp contract(fast)      // a bound of this build's own, not a reference value: FMAs are welcome
     CullConic q;
     q.ok = false;
     const double u = 5.9604644775390625e-08;
@@ -112,6 +113,7 @@ __device__ __forceinline__ CullConic cull_conic(const float* vg, float thr, floa
 __device__ __forceinline__ float4 conservative_box(const CullConic& q, float thr, bool have_scale, int W, int H,
                                                    float focal_x, float focal_y)
 {
+#pragma clang fp contract(fast)      // a bound of this build's own, not a reference value: FMAs are welcome
     const float4 all = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);
     if (!have_scale || !(thr < 3.0e38f)) return all;        // thr = +inf (alpha always < 1/255) is handled by the pre-test
     if (!q.ok) return all;
@@ -145,6 +147,7 @@ __device__ __forceinline__ float4 conservative_box(const CullConic& q, float thr
 __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float thr, bool have_scale, int W, int H,
                                                      float focal_x, float focal_y, double ifx, double ify, float4& e, float& ec)
 {
+#pragma clang fp contract(fast)      // a bound of this build's own, not a reference value: FMAs are welcome
     // (the kernel is VALU-bound and a float64 division costs ~15 float64 instructions: reciprocals are formed once and multiplied;
     // every rounding this introduces is far inside the 0.1 % inflation below, and the two square roots, which only feed that
     // inflation and the aspect limit, are float32 and rounded UP)
