@@ -251,7 +251,8 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
  * "render_kernel" (default 2): 2 = Gaussians across the lanes + conservative ellipse (render2), 1 = the round-1 pixel-lane kernel.
  * "render_round" (default 192): list entries a workgroup of render2 stages per round (192 at 7 waves/SIMD or 256 at 6).
  * "render_fast" (default 1): arithmetic of the compositing forward: 0 = the reference's float32 / float64 operation order,
- * 1 = error-free float32 pairs in inference calls (no auxiliary planes; within 3e-7 of mode 0), exact in calls a backward follows,
+ * 1 = error-free float32 pairs for the float64 island and FMA-contracted accumulations downstream of alpha, in inference calls (no
+ * auxiliary planes; within 3e-7 of mode 0), exact in calls a backward follows,
  * 2 = fast in every call.
  * "tile_cull" (default 1): a Gaussian is instantiated only in the tiles that the box of its conservative alpha >= 1/255 ellipse
  * reaches instead of every tile of the reference's 3-sigma square (forward.cu:364-374). The dropped (Gaussian, tile) pairs are a
