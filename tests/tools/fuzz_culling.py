@@ -40,8 +40,10 @@ def plain(on):
 f3d.set_option("render_fast", 0)
 bad = 0
 for i in range(n_scenes):
-    W, H = int(rng.integers(2, 20)) * 8 + int(rng.integers(0, 8)), int(rng.integers(2, 20)) * 8 + int(rng.integers(0, 8))
-    kw = dict(P=int(rng.integers(200, 30000)), res=(W, H), s0=float(10 ** rng.uniform(-2.6, -0.4)), seed=int(rng.integers(1 << 30)),
+    big = os.environ.get("BIG") and i % 4 == 0      # BIG=1: every fourth scene up to 520 px (two tile passes) and 200 k Gaussians
+    hi = 66 if big else 20
+    W, H = int(rng.integers(2, hi)) * 8 + int(rng.integers(0, 8)), int(rng.integers(2, hi)) * 8 + int(rng.integers(0, 8))
+    kw = dict(P=int(rng.integers(200, 200000 if big else 30000)), res=(W, H), s0=float(10 ** rng.uniform(-2.6, -0.4)), seed=int(rng.integers(1 << 30)),
               view=[int(v) for v in rng.choice(9, size=int(rng.integers(1, 4)), replace=False)], aniso=bool(rng.integers(0, 2)),
               kernel_size=float(rng.choice([0.0, 0.0, 0.1, 0.3])), scale_modifier=float(rng.choice([1.0, 1.0, 0.5, 2.0])),
               behind_fraction=float(rng.choice([0.0, 0.05])), sh_degree=int(rng.integers(0, 2)))
