@@ -36,6 +36,13 @@ __global__ void fill_background_kernel(int V, size_t HW, const float* __restrict
     (void)bg; (void)bg_per_view;
 }
 
+// debug export: the final list's Gaussian ids (the quadrant masks of F3DG_ID_BITS stripped)
+__global__ void export_ids_kernel(const unsigned* __restrict__ src, size_t n, unsigned* __restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i] & F3DG_ID_MASK;
+}
+
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's live roofline figure) ----
 enum { ST_PREPROCESS = 0, ST_BINNING, ST_RENDER, ST_COUNT };
 enum { BW_RENDER = 0, BW_GAUSSIAN, BW_COUNT };       // backward stages, recorded by f3dg_backward
@@ -82,7 +89,8 @@ int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
-int g_f3dg_render_kernel = 2;
+int g_f3dg_render_kernel = 3;
+int g_f3dg_render_dma = 1;
 int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
@@ -92,7 +100,8 @@ extern "C" int f3dg_set_option(const char* name, int value)
 {
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : 2; return F3DG_OK; }
+    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; return F3DG_OK; }
+    if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
@@ -285,8 +294,8 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     hipStream_t s = (hipStream_t)stream;
     if (n_views <= 0 || P < 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !background || !workspace)
         return F3DG_ERR_BAD_ARG;
-    if (max_rendered > 0xFFFFFFF0ll || (long long)n_views * P > 0xFFFFFFF0ll)
-        return F3DG_ERR_BAD_ARG;                       // instance and (view,Gaussian) indices are 32-bit
+    if (max_rendered > 0xFFFFFFF0ll || (long long)n_views * P > 0xFFFFFFF0ll || P > (int)F3DG_ID_MASK)
+        return F3DG_ERR_BAD_ARG;                       // instance and (view,Gaussian) indices are 32-bit, list entries hold 28-bit ids
     const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
     if (workspace_bytes < L.total) return F3DG_ERR_WORKSPACE;
     char* ws = static_cast<char*>(workspace);
@@ -503,7 +512,9 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
     CP(offsets, L.offsets, VP * 4);
     CP(clamped, L.clamped, VP);
     CP(keys_sorted, L.keys[0], C * 8);
-    CP(point_list, L.vals[0], C * 4);
+    if (point_list && C)        // the Gaussian ids without the quadrant masks of the compositing kernel (F3DG_ID_BITS)
+        hipLaunchKernelGGL(export_ids_kernel, dim3((unsigned)((C + 1023) / 1024 < 4096 ? (C + 1023) / 1024 : 4096)), dim3(256), 0, s,
+                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), C, point_list);
     CP(ranges, L.ranges, (size_t)n_views * T * 8);
     CP(final_T, L.final_T, (size_t)n_views * 4 * HW * 4);
     CP(n_contrib, L.n_contrib, (size_t)n_views * 2 * HW * 4);

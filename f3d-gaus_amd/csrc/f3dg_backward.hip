@@ -199,7 +199,7 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
         __syncthreads();
         const unsigned progress = (unsigned)i * F3DG_BLOCK + threadIdx.x;
         if (range.x + progress < range.y) {
-            const unsigned id = point_list[range.y - progress - 1];       // back to front
+            const unsigned id = point_list[range.y - progress - 1] & F3DG_ID_MASK;       // back to front
             const float4* src = reinterpret_cast<const float4*>(rec + vP + id);
             staged[threadIdx.x * 4 + 0] = src[0];
             staged[threadIdx.x * 4 + 1] = src[1];
@@ -462,7 +462,7 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
         __syncthreads();
         const int progress = i * F3DG_BLOCK + (int)threadIdx.x;
         if (progress < block_last) {
-            const unsigned id = point_list[range.x + (unsigned)(block_last - 1 - progress)];       // back to front
+            const unsigned id = point_list[range.x + (unsigned)(block_last - 1 - progress)] & F3DG_ID_MASK;       // back to front
             const float4* src = reinterpret_cast<const float4*>(rec + vP + id);
             sq0[threadIdx.x] = src[0];
             sq1[threadIdx.x] = src[1];

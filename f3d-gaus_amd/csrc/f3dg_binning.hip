@@ -598,7 +598,8 @@ gsort_gather_rects_kernel(int P, u32* __restrict__ gv0, u32* __restrict__ gv1, c
     for (int i = 0; i < ITEMS; i++) {
         const int k = k0 + i * F3DG_BLOCK;
         if (k < P) {
-            tiles_sorted[vb + k] = ((r[i].x >> 16) - (r[i].x & 0xFFFFu)) * ((r[i].y >> 16) - (r[i].y & 0xFFFFu));
+            tiles_sorted[vb + k] = (((r[i].x >> 16) & F3DG_RECT_COORD) - (r[i].x & F3DG_RECT_COORD)) *
+                                   (((r[i].y >> 16) & F3DG_RECT_COORD) - (r[i].y & F3DG_RECT_COORD));
             rx[vb + k] = r[i].x;
             ry[vb + k] = r[i].y;
         }
@@ -633,26 +634,40 @@ duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict_
     if (k < P) {
         const size_t pos = (size_t)v * P + k;
         const u32 x = rx[pos], y = ry[pos];
-        const u32 rminx = x & 0xFFFFu, rmaxx = x >> 16, rminy = y & 0xFFFFu, rmaxy = y >> 16;
+        const u32 rminx = x & F3DG_RECT_COORD, rmaxx = (x >> 16) & F3DG_RECT_COORD, rminy = y & F3DG_RECT_COORD, rmaxy = (y >> 16) & F3DG_RECT_COORD;
         if (rmaxx > rminx && rmaxy > rminy) {
             const u32 g = perm[pos];
             u32 off = (pos == 0) ? 0 : offsets_sorted[pos - 1];
             const u32 view_base = (u32)v << tile_bits;
+            // quadrant mask of an instance (f3dg_common.h: F3DG_ID_BITS): the halves of the first / last tile column and row that the
+            // conservative box misses are cleared
+            auto halves = [](u32 t, u32 tmin, u32 tmax, u32 word) -> u32 {
+                u32 m = 3u;
+                if (t == tmin && (word & F3DG_RECT_SKIP_LO)) m &= ~1u;
+                if (t + 1u == tmax && (word & F3DG_RECT_SKIP_HI)) m &= ~2u;
+                return m;
+            };
             if (staged) {
                 off -= base;
-                for (u32 ty = rminy; ty < rmaxy; ty++)
+                for (u32 ty = rminy; ty < rmaxy; ty++) {
+                    const u32 my = halves(ty, rminy, rmaxy, y);
                     for (u32 tx = rminx; tx < rmaxx; tx++) {
+                        const u32 mx = halves(tx, rminx, rmaxx, x);
                         sk[off] = (G)(view_base | (ty * (u32)grid_x + tx));
-                        sv[off] = g;
+                        sv[off] = g | ((((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u)) << F3DG_ID_BITS);
                         off++;
                     }
+                }
             } else {
-                for (u32 ty = rminy; ty < rmaxy; ty++)
+                for (u32 ty = rminy; ty < rmaxy; ty++) {
+                    const u32 my = halves(ty, rminy, rmaxy, y);
                     for (u32 tx = rminx; tx < rmaxx; tx++) {
+                        const u32 mx = halves(tx, rminx, rmaxx, x);
                         kgrp[off] = (G)(view_base | (ty * (u32)grid_x + tx));
-                        vals[off] = g;
+                        vals[off] = g | ((((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u)) << F3DG_ID_BITS);
                         off++;
                     }
+                }
             }
         }
     }
@@ -676,7 +691,7 @@ export_keys_kernel(u32 nseg, int P, int tile_bits, int T, const uint2* __restric
         const u32 view = seg / (u32)T, tile = seg % (u32)T;
         const u64 hi = (u64)((view << tile_bits) | tile) << 32;
         for (u32 i = r.x + threadIdx.x; i < r.y; i += F3DG_BLOCK)
-            keys_out[i] = hi | (u64)__float_as_uint(depths[(size_t)view * P + point_list[i]]);
+            keys_out[i] = hi | (u64)__float_as_uint(depths[(size_t)view * P + (point_list[i] & F3DG_ID_MASK)]);
     }
 }
 

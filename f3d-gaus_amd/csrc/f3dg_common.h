@@ -18,6 +18,17 @@
 #define F3DG_SCAN_ITEMS 16
 #define F3DG_SCAN_CHUNK (F3DG_BLOCK * F3DG_SCAN_ITEMS)
 
+// A point-list entry is the Gaussian id in its low 28 bits and, above them, the mask of the tile's four 8x8 pixel quadrants
+// (bit 28 + 2 * qy + qx) that the axis-aligned box of the Gaussian's conservative alpha >= 1/255 ellipse reaches: the one-wave
+// compositing kernel (render3, f3dg_render.hip) stages an entry only in the quadrants whose bit is set. Every other consumer
+// strips the mask. The tile rectangles that carry the information from the projection kernel to the instance generation keep
+// tile coordinates in 15 bits; bit 15 / 31 of a word says that the box misses the first / second half of the first / last tile.
+#define F3DG_ID_BITS 28
+#define F3DG_ID_MASK 0x0FFFFFFFu
+#define F3DG_RECT_COORD 0x7FFFu
+#define F3DG_RECT_SKIP_LO 0x8000u
+#define F3DG_RECT_SKIP_HI 0x80000000u
+
 // XCD-aware (view, unit) of workgroup b of a V * U grid. Consecutive workgroup ids land on different XCDs (id % 8); the views are
 // handed out in groups of 8, one view per XCD, so that all units (tiles, sort chunks) of a view share one XCD's L2. The last
 // V % 8 views are spread over all XCDs unit by unit (a single-view call uses the whole chip).
@@ -137,7 +148,9 @@ extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
 extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
-extern int g_f3dg_render_kernel;       // 2 (default): render2 (Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+extern int g_f3dg_render_kernel;       // 3 (default): render3 (one wave64 per 8x8 quadrant, no barriers); 2: render2 (four waves per tile,
+                                       // Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);
 void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);
 int f3dg_render_uses_fast(int save_aux);       // the arithmetic mode a compositing launch with / without SAVE_AUX takes

@@ -60,6 +60,38 @@ __device__ __forceinline__ void ellipse_ballots(int& stage, float Ep, const floa
     }
 }
 
+// Phase 1 of render3 (one wave64 per 8x8 pixel quadrant): lane e holds list entry e of the window and evaluates its ellipse at
+// pixel P = 8 * row + column of the quadrant (and, recursively, at the following ones); the comparison IS the ballot "which entries
+// can reach pixel P", and two v_writelane_b32 hand its halves to lane P -- the lane that blends pixel P -- so that after the 64
+// steps every lane holds the 64-bit pass mask of its own pixel. Same instruction pattern and wait states as ellipse_ballots.
+template <int P>
+__device__ __forceinline__ void quad_ballots(int& lo, int& hi, float Ep, const float (&dxx)[8], const float (&adx)[8],
+                                             const float (&dyy)[8], const float (&cdy)[8], float eb)
+{
+    if constexpr (P < 63) {
+        float En;
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "v_fma_f32 %[en], %[eb], %[dy], %[ax]\n\t"
+            "v_fma_f32 %[en], %[dx], %[en], %[cy]\n\t"
+            "v_writelane_b32 %[lo], vcc_lo, %[l]\n\t"
+            "v_writelane_b32 %[hi], vcc_hi, %[l]"
+            : [lo] "+v"(lo), [hi] "+v"(hi), [en] "=&v"(En)
+            : [ep] "v"(Ep), [eb] "v"(eb), [dy] "v"(dyy[(P + 1) >> 3]), [ax] "v"(adx[(P + 1) & 7]), [dx] "v"(dxx[(P + 1) & 7]),
+              [cy] "v"(cdy[(P + 1) >> 3]), [l] "n"(P)
+            : "vcc");
+        quad_ballots<P + 1>(lo, hi, En, dxx, adx, dyy, cdy, eb);
+    } else {
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "s_nop 1\n\t"
+            "v_writelane_b32 %[lo], vcc_lo, %[l]\n\t"
+            "v_writelane_b32 %[hi], vcc_hi, %[l]\n\t"
+            "s_nop 0"
+            : [lo] "+v"(lo), [hi] "+v"(hi)
+            : [ep] "v"(Ep), [l] "n"(P)
+            : "vcc");
+    }
+}
+
 } // namespace
 
 #endif

@@ -157,7 +157,7 @@ integrate_pass1_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, 
 
         const unsigned progress = (unsigned)i * F3DG_ROUND + threadIdx.x;
         if (threadIdx.x < F3DG_ROUND && range.x + progress < range.y) {
-            const unsigned id = point_list[range.x + progress];
+            const unsigned id = point_list[range.x + progress] & F3DG_ID_MASK;
             const float4* src = reinterpret_cast<const float4*>(rec + id);
             const float4 a = src[0], b = src[1], c = src[2];
             float4 d = src[3];
@@ -322,7 +322,7 @@ integrate_pass1_cull_kernel(int W, int H, int tiles_x, float focal_x, float foca
         const unsigned progress = (unsigned)i * ROUND + threadIdx.x;
         unsigned short m16 = 0;
         if (range.x + progress < range.y) {
-            const unsigned id = point_list[range.x + progress];
+            const unsigned id = point_list[range.x + progress] & F3DG_ID_MASK;
             const float4* src = reinterpret_cast<const float4*>(rec + id);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
             float4 e = cull[id];
@@ -553,7 +553,7 @@ integrate_points_kernel(int PN, const float* __restrict__ points3D, const float*
         if (target <= num_iterated || target > last_contributor)
             break;
         num_iterated = target;
-        const unsigned g = point_list[range_x + target - 1u];
+        const unsigned g = point_list[range_x + target - 1u] & F3DG_ID_MASK;
         const float4* src = reinterpret_cast<const float4*>(rec + g);
         const float4 q0 = src[0], q1 = src[1], q2 = src[2];
         const float n0 = q0.x * rx + q0.y * ry + q0.z;
@@ -677,7 +677,7 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, floa
     unsigned* n_contrib = reinterpret_cast<unsigned*>(ws + L.n_contrib);
     unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
     unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
-    if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel == 2)
+    if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 2)
         hipLaunchKernelGGL(integrate_pass1_cull_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);

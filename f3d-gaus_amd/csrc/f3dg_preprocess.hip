@@ -448,27 +448,39 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                         box = conservative_box(cq, thr, have_scale, W, H, focal_x, focal_y);
                     conservative_ellipse(cq, thr, have_scale, W, H, focal_x, focal_y, inv_focal_x, inv_focal_y, ce, cec);
                 }
-                if (tile_cull) {
+                {
                     // Tile culling (option "tile_cull"): the reference instantiates the Gaussian in every tile of the square around
                     // its 3-sigma circle (rect above); only tiles that the axis-aligned box of the conservative ellipse reaches can
                     // hold a pixel with alpha >= 1/255, the others would be a bare `continue` for each of their pixels.
                     const float edet = fmaf(ce.z, cec, -0.25f * ce.w * ce.w);
                     if (edet > 0.0f) {
                         const float hx = sqrtf(cec / edet) * 1.0005f + 2e-3f, hy = sqrtf(ce.z / edet) * 1.0005f + 2e-3f;
-                        // tile t holds the pixel centres 16 t .. 16 t + 15
-                        const float inv_tile = 1.0f / (float)F3DG_TILE;
-                        const float lx = ceilf((ce.x - hx - (float)(F3DG_TILE - 1)) * inv_tile), ux = floorf((ce.x + hx) * inv_tile) + 1.0f;
-                        const float ly = ceilf((ce.y - hy - (float)(F3DG_TILE - 1)) * inv_tile), uy = floorf((ce.y + hy) * inv_tile) + 1.0f;
-                        const int cminx = max(rminx, (int)fminf(fmaxf(lx, 0.0f), (float)grid_x));
-                        const int cmaxx = min(rmaxx, (int)fminf(fmaxf(ux, 0.0f), (float)grid_x));
-                        const int cminy = max(rminy, (int)fminf(fmaxf(ly, 0.0f), (float)grid_y));
-                        const int cmaxy = min(rmaxy, (int)fminf(fmaxf(uy, 0.0f), (float)grid_y));
-                        if (cmaxx > cminx && cmaxy > cminy) {
-                            my_tiles = (unsigned)((cmaxx - cminx) * (cmaxy - cminy));
-                            rect = make_uint2((unsigned)cminx | ((unsigned)cmaxx << 16), (unsigned)cminy | ((unsigned)cmaxy << 16));
-                        } else {
-                            my_tiles = 0;
-                            rect = make_uint2(0u, 0u);
+                        int fminx = rminx, fmaxx = rmaxx, fminy = rminy, fmaxy = rmaxy;
+                        if (tile_cull) {
+                            // tile t holds the pixel centres 16 t .. 16 t + 15
+                            const float inv_tile = 1.0f / (float)F3DG_TILE;
+                            const float lx = ceilf((ce.x - hx - (float)(F3DG_TILE - 1)) * inv_tile), ux = floorf((ce.x + hx) * inv_tile) + 1.0f;
+                            const float ly = ceilf((ce.y - hy - (float)(F3DG_TILE - 1)) * inv_tile), uy = floorf((ce.y + hy) * inv_tile) + 1.0f;
+                            const int cminx = max(rminx, (int)fminf(fmaxf(lx, 0.0f), (float)grid_x));
+                            const int cmaxx = min(rmaxx, (int)fminf(fmaxf(ux, 0.0f), (float)grid_x));
+                            const int cminy = max(rminy, (int)fminf(fmaxf(ly, 0.0f), (float)grid_y));
+                            const int cmaxy = min(rmaxy, (int)fminf(fmaxf(uy, 0.0f), (float)grid_y));
+                            if (cmaxx > cminx && cmaxy > cminy) {
+                                my_tiles = (unsigned)((cmaxx - cminx) * (cmaxy - cminy));
+                                rect = make_uint2((unsigned)cminx | ((unsigned)cmaxx << 16), (unsigned)cminy | ((unsigned)cmaxy << 16));
+                                fminx = cminx; fmaxx = cmaxx; fminy = cminy; fmaxy = cmaxy;
+                            } else {
+                                my_tiles = 0;
+                                rect = make_uint2(0u, 0u);
+                            }
+                        }
+                        // Quadrant hints for the one-wave compositing kernel (f3dg_common.h: F3DG_RECT_SKIP_*): tile t's first
+                        // half holds the pixel centres 16 t .. 16 t + 7, its second half 16 t + 8 .. 16 t + 15. The same box.
+                        if (my_tiles != 0) {
+                            if (ce.x - hx > (float)(F3DG_TILE * fminx + 7)) rect.x |= F3DG_RECT_SKIP_LO;
+                            if (ce.x + hx < (float)(F3DG_TILE * (fmaxx - 1) + 8)) rect.x |= F3DG_RECT_SKIP_HI;
+                            if (ce.y - hy > (float)(F3DG_TILE * fminy + 7)) rect.y |= F3DG_RECT_SKIP_LO;
+                            if (ce.y + hy < (float)(F3DG_TILE * (fmaxy - 1) + 8)) rect.y |= F3DG_RECT_SKIP_HI;
                         }
                     }
                 }

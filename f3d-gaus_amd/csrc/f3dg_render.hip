@@ -262,7 +262,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 
         const unsigned progress = (unsigned)i * F3DG_ROUND + threadIdx.x;
         if (threadIdx.x < F3DG_ROUND && range.x + progress < range.y) {
-            const unsigned id = point_list[range.x + progress];
+            const unsigned id = point_list[range.x + progress] & F3DG_ID_MASK;
             const float4* src = reinterpret_cast<const float4*>(vrec + id);
             const float4 a = src[0], b = src[1], c = src[2];
             float4 d = src[3];
@@ -527,7 +527,7 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
         const unsigned progress = (unsigned)i * ROUND + threadIdx.x;
         unsigned short m16 = 0;
         if (threadIdx.x < ROUND && range.x + progress < range.y) {
-            const unsigned id = point_list[range.x + progress];
+            const unsigned id = point_list[range.x + progress] & F3DG_ID_MASK;
             const float4* src = reinterpret_cast<const float4*>(vrec + id);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
             const float4 e0 = vcull[id];
@@ -651,6 +651,200 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     }
 }
 
+// =====================================================================================================================
+// render3: ONE wave64 per 8x8 pixel quadrant of a tile -- no workgroup barriers, nothing shared between waves.
+//
+// render2 couples the four waves of a tile through two __syncthreads per staging round: an instrumented build attributes 25-30 % of
+// a wave's life to waiting at them (the quadrants of a tile have different amounts of work) and 20-40 % to the staged gathers, which
+// all four waves sit out together; VALU issue reaches ~62 %. Here a workgroup is one wave that owns a quadrant from its first list
+// entry to its last pixel's saturation and then retires; the SIMD's other waves (other quadrants, other tiles, up to 8 per SIMD) fill
+// every wait, and a quadrant stops staging as soon as ITS 64 pixels are finished instead of the tile's 256.
+//
+//   scan     the tile's list is read 64 ids at a time (the next 64 are always in flight); an entry is kept when the quadrant's bit
+//            of the mask that instance generation left above the id is set (F3DG_ID_BITS: the box of the conservative ellipse
+//            reaches the quadrant). Kept (list position, id) pairs queue up in a 128-entry LDS ring until 64 are waiting.
+//   stage    lane e takes queue entry e: its 64-byte record goes to LDS by four global_load_lds_dwordx4 (no VGPRs, no ds_write; the
+//            LDS image [chunk][entry] is exactly the structure-of-arrays phase 2 wants), its ellipse stays in five registers.
+//   phase 1  Gaussians across the lanes: lane e evaluates its entry's ellipse at the quadrant's 64 pixels; each comparison is a wave
+//            ballot and lands, by two v_writelane, in the lane that owns the pixel (quad_ballots): 5 instructions per 64 tests, no
+//            per-block lists, no ds_bpermute.
+//   phase 2  pixels across the lanes: every pixel walks its own 64-bit pass mask in list order through the reference's recurrence
+//            (blend_entry / blend_entry_fast, unchanged); the bit index IS the LDS slot, so the list-byte read of render2 is gone.
+// The conservative filters only drop pairs that are a bare `continue` in the reference, so the images are bit-identical to the
+// plain transcription within an arithmetic mode (tests/test_raster_forward_gpu.py). LDS: 4 KB of records + 1 KB of queue per wave.
+
+#define F3DG_R3_WIN 64              // list entries per window = lanes
+#define F3DG_R3_RING 128            // queue ring of (list position, id) pairs
+#define F3DG_R3_FLAG 0x80000000u    // contributor values of the current window are slots (flag | slot) until the window ends
+
+template <bool SAVE_AUX, bool FAST, bool DMA, int OCC>
+__global__ void __launch_bounds__(64, OCC)
+render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                   const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                   float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+{
+    unsigned view, unit;                      // the four quadrants of a tile and all tiles of a view share one XCD's L2
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x;
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const unsigned n = range.y - range.x;
+
+    __shared__ float4 sR[4][F3DG_R3_WIN];     // records of the window, [16-byte chunk][entry]: v0..v3 | v4..v7 | v8 v9 opacity K | r g b c
+    __shared__ uint2 sQ[F3DG_R3_RING];        // (list position, Gaussian id) of the kept entries, ring
+
+    const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vcull = cull + (size_t)view * P;
+    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    bool done = !inside;
+    PixelState st;
+    st.Tr = 1.0f;
+    st.last_contributor = 0; st.max_contributor = (unsigned)-1;
+    st.C0 = st.C1 = st.C2 = st.C3 = st.C4 = st.C5 = st.C6 = st.C7 = 0;
+    st.dist1 = st.dist2 = st.distortion = 0;
+    F3DG_T_DECL
+
+    unsigned cursor = 0, qhead = 0, qcount = 0;                       // wave-uniform
+    unsigned idn = lane < n ? point_list[range.x + lane] : 0u;       // the 64 list entries at `cursor`, always one chunk ahead
+    if (__ballot(!done) != 0ull)
+    for (;;) {
+        // ---- scan: keep the entries whose box reaches this quadrant
+        while (qcount < F3DG_R3_WIN && cursor < n) {
+            const unsigned idm = idn, pos = cursor + lane;
+            cursor += 64u;
+            idn = cursor + lane < n ? point_list[range.x + cursor + lane] : 0u;
+            const bool keep = pos < n && (idm & qbit) != 0u;
+            const unsigned long long kb = __ballot(keep);
+            if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R3_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+            qcount += (unsigned)__popcll(kb);
+        }
+        if (qcount == 0u)
+            break;
+        const unsigned m = qcount < F3DG_R3_WIN ? qcount : F3DG_R3_WIN;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        F3DG_T_MARK(2);
+
+        // ---- stage: lane e <- queue entry e
+        float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float ec = 0.0f;
+        if (lane < m) {
+            const unsigned id = sQ[(qhead + lane) & (F3DG_R3_RING - 1)].y;
+            const float4* src = reinterpret_cast<const float4*>(vrec + id);
+            if (DMA) {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                     (__attribute__((address_space(3))) void*)&sR[c][0], 16, 0, 0);
+                e4 = vcull[id];
+            } else {
+                const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+                e4 = vcull[id];
+                sR[0][lane] = a; sR[1][lane] = b; sR[2][lane] = c; sR[3][lane] = d;
+                ec = d.w;
+            }
+        }
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane < m) ec = sR[3][lane].w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        F3DG_T_MARK(1);
+
+        // ---- phase 1: lane e tests entry e against the 64 pixels of the quadrant
+        int pass_lo = 0, pass_hi = 0;
+        {
+            const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");     // NaN: every comparison below is false
+            const float v0 = (float)qy0 - e4.y;
+            float dxx[8], adx[8], dyy[8], cdy[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                dxx[q] = u0 + (float)q;
+                adx[q] = e4.z * dxx[q];
+                dyy[q] = v0 + (float)q;
+                cdy[q] = ec * dyy[q] * dyy[q];
+            }
+            quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+        }
+        F3DG_T_MARK(3);
+        unsigned long long pass = done ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+
+        // ---- phase 2: this pixel's own passing entries, in list order, through the reference's arithmetic
+        while (pass != 0 && !done) {
+            const int j = __builtin_ctzll(pass);
+            pass &= pass - 1;
+            const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
+            const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+            const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+            const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+            const float aaf = ray_x * n0 + ray_y * n1 + n2;
+            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+            done = (FAST ? blend_entry_fast : blend_entry)(st, F3DG_R3_FLAG | (unsigned)j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+        }
+        if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
+            if (st.last_contributor - F3DG_R3_FLAG < (unsigned)F3DG_R3_WIN)
+                st.last_contributor = sQ[(qhead + (st.last_contributor - F3DG_R3_FLAG)) & (F3DG_R3_RING - 1)].x + 1u;
+            if (st.max_contributor - F3DG_R3_FLAG < (unsigned)F3DG_R3_WIN)
+                st.max_contributor = sQ[(qhead + (st.max_contributor - F3DG_R3_FLAG)) & (F3DG_R3_RING - 1)].x + 1u;
+        }
+        F3DG_T_MARK(4);
+        qhead += m;
+        qcount -= m;
+        if (__ballot(!done) == 0ull)
+            break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the window's slots are rewritten by the next one
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    F3DG_T_FLUSH;
+
+    if (inside) {
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = distortion_before_normalized;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        out[8 * HW + pix_id] = distortion;
+    }
+}
+
 } // namespace
 
 int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f3dg_render_fast == 1 && !save_aux); }
@@ -667,6 +861,19 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     // back to front by dividing final_T by (1 - alpha) with ITS alphas: they must be the forward's to the bit, or the 1e-6 relative
     // difference is amplified by 1 / (1 - alpha) per layer (measured at C5: compositing-stage gradients 2.5e-5 vs 1.8e-6 off the oracle).
     const int g_f3dg_render_fast = f3dg_render_uses_fast(save_aux);
+    if (g_f3dg_render_kernel == 3) {
+        const dim3 grid3((unsigned)V * (unsigned)T * 4u);
+#define F3DG_LAUNCH3D(AUX, FST, DMA, OCC) hipLaunchKernelGGL((render3_fwd_kernel<AUX, FST, DMA, OCC>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T,  \
+                                                  focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \
+                                                  out_color, final_T, n_contrib)
+#define F3DG_LAUNCH3(AUX, FST, OCC) do { if (g_f3dg_render_dma) F3DG_LAUNCH3D(AUX, FST, true, OCC); else F3DG_LAUNCH3D(AUX, FST, false, OCC); } while (0)
+        if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3(true, true, 7); else F3DG_LAUNCH3(true, false, 6); }
+        else { if (g_f3dg_render_fast) F3DG_LAUNCH3(false, true, 8); else F3DG_LAUNCH3(false, false, 6); }
+#undef F3DG_LAUNCH3
+#undef F3DG_LAUNCH3D
+        F3DG_HIP_CHECK(hipGetLastError());
+        return F3DG_OK;
+    }
     if (g_f3dg_render_kernel == 2) {
 #define F3DG_LAUNCH2R(AUX, FST, RND, OCC) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST, RND, OCC>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \

@@ -62,7 +62,7 @@ def test_integrate_filters_are_bit_identical(kw):
             L.f3dg_set_option(b"render_cull", on)
             res.append(run_both(scene, pts, torch.device("cuda:0"))[1])
     finally:
-        L.f3dg_set_option(b"render_kernel", 2)
+        L.f3dg_set_option(b"render_kernel", 3)
         L.f3dg_set_option(b"render_pretest", 1)
         L.f3dg_set_option(b"render_cull", 1)
     for r in res[:2]:

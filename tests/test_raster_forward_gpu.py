@@ -194,12 +194,17 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
         for pre, cull, que in ((1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)):
             L.f3dg_set_option(b"render_pretest", pre); L.f3dg_set_option(b"render_cull", cull); L.f3dg_set_option(b"render_queue", que)
             variants.append(run_hip(scene, gpu_device))
-        L.f3dg_set_option(b"render_kernel", 2)      # render2 (default): Gaussians across the lanes + conservative ellipse in phase 1
+        L.f3dg_set_option(b"render_kernel", 2)      # render2: four waves per tile, Gaussians across the lanes + conservative ellipse in phase 1
         for rnd in (192, 256):                      # list entries staged per round (fast arithmetic: 192 by default)
             L.f3dg_set_option(b"render_round", rnd)
             variants.append(run_hip(scene, gpu_device))
+        L.f3dg_set_option(b"render_kernel", 3)      # render3 (default): one wave64 per 8x8 quadrant, quadrant masks from the binning stage
+        for dma in (1, 0):                          # records staged by global_load_lds / through registers
+            L.f3dg_set_option(b"render_dma", dma)
+            variants.append(run_hip(scene, gpu_device))
     finally:
-        L.f3dg_set_option(b"render_kernel", 2)
+        L.f3dg_set_option(b"render_kernel", 3)
+        L.f3dg_set_option(b"render_dma", 1)
         L.f3dg_set_option(b"render_round", 192)
         for o in (b"render_pretest", b"render_cull", b"render_queue"):
             L.f3dg_set_option(o, 1)
