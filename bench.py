@@ -15,12 +15,15 @@ Workloads (`--workload`):
       weights) + cycle aggregation (8 novel views of all B images in one launch sequence, 8 re-predictions, in-place merge)
       + the 8 orbit views of every merged set + frame packing + the gather. A "step" = B x 8 final views.
 
-Every number of the JSON line is measured in THIS run except the two `*_from_profiles` objects, which are read from the
-committed rocprofv3 PMC passes of the same command (profiles/<round>/traffic.json) and say so: hardware counters cannot be read
-from inside the process. `roofline` is the compositing kernel, timed with HIP events the library records on the launch stream;
-`rooflines_other` prices the projection and binning stages with SURVEY 8d's byte formulas; `with_d2h` repeats the timed loop with
-frame packing + the device-to-host copy of the RGB frames inside it (SURVEY 8d "how to time"); `cpu_baseline` times the CPU
-oracle (the build's plain-C restatement: kind "port") on a bounded sample of the same workload on this box's host cores.
+Every number of the JSON line is measured in THIS run except the `*_from_profiles` objects, which are read from the committed
+rocprofv3 PMC passes of the same command (profiles/<round>/traffic.json) and say so: hardware counters cannot be read from inside
+the process. C2 at N = 1 runs three timed loops of K steps each: frames left in HBM (`value_in_hbm`), frames packed to 8-bit RGB
+and copied to pinned host memory behind the next step's rendering (`value`: SURVEY 8d "views/s ... including the final D2H of RGB"),
+and the in-HBM loop again in the reference's float32/float64 arithmetic (`value_exact`, `roofline_exact`). `roofline` is the
+compositing kernel, timed with HIP events the library records on the launch stream, on the list entries the launch is handed
+(`frac_on_reference_instances`: the same formula on the reference's instance count); `rooflines_other` prices the projection and
+binning stages with this build's own byte streams; `cpu_baseline` times the CPU oracle (the build's plain-C restatement: kind
+"port") on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
 import ctypes as C
@@ -37,8 +40,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-RASTER_LAUNCHES_PER_CALL = 22    # kernels of one forward call at 256^2 (profiles/*/summary.md): projection, 9 scan, keys, 2 radix,
-                                 # bounds / counts / ranges, 3 tile-sort tiers, header, compositing
 
 
 def parse():
@@ -62,7 +63,8 @@ def parse():
                     help="1 (library default): a Gaussian is instantiated only in the tiles its alpha >= 1/255 ellipse reaches; "
                          "0: the reference's tile lists (every tile of the 3-sigma square)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-d2h", action="store_true", help="skip the second timed loop (frame packing + device-to-host copy)")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the timed loops with frame packing + device-to-host copy: `value` is then the in-HBM rate")
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra timed loop in the reference's arithmetic (value_exact / roofline_exact)")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
     return ap.parse_args()
 
@@ -145,6 +147,9 @@ def main():
         _lib.check(L.f3dg_set_option(b"render_round", int(os.environ["F3DG_RENDER_ROUND"])), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
+    for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad")):     # A/B switches of render3
+        if os.environ.get(env):
+            _lib.check(L.f3dg_set_option(opt, int(os.environ[env])), "f3dg_set_option")
     _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
     result = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, rank, world, dist, device, comm_device, f3d, L)
     if rank == 0:
@@ -167,7 +172,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     chunks = [(a, min(a + args.views_per_call, V)) for a in range(0, V, args.views_per_call)]
     workspaces = {}
 
-    def render_chunk(a, b, check):
+    def render_chunk(a, b, check, out=out):
         o, r, ws = f3d.rasterize_views(
             g["xyz"], g["opacity"], cams["viewmatrix"][a:b], cams["projmatrix"][a:b], cams["campos"][a:b], bg,
             image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs,
@@ -198,56 +203,117 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         if world > 1:
             gat.submit(f3d.gaussian_renderer.pack_frames(out))          # uint8 [V,H,W,3], one kernel
 
-    timed(step, gat.barrier, args.warmup, 0)
-    L.f3dg_profile_enable(1)
-    elapsed = timed(step, gat.barrier, 0, args.steps)
-    L.f3dg_profile_enable(0)
-    stage_ms = (C.c_double * 5)()
-    ncalls = C.c_int(0)
-    _lib.check(L.f3dg_profile_collect(stage_ms, C.byref(ncalls)), "f3dg_profile_collect")
-    for ws in workspaces.values():      # no overflow happened in the timed region
-        f3d.diff_gof_rasterization.read_status(ws)
-    elapsed = max_over_ranks(elapsed, dist, world, comm_device if world > 1 else device)
+    def measure(fn, warmup, steps):
+        """(seconds for `steps` steps, per-stage HIP-event milliseconds summed over them, forward calls, kernel launches)"""
+        timed(fn, gat.barrier, warmup, 0)
+        L.f3dg_profile_enable(1)
+        L.f3dg_debug_launch_count(1)
+        t = timed(fn, gat.barrier, 0, steps)
+        launches = int(L.f3dg_debug_launch_count(1))
+        L.f3dg_profile_enable(0)
+        st = (C.c_double * 5)()
+        nc = C.c_int(0)
+        _lib.check(L.f3dg_profile_collect(st, C.byref(nc)), "f3dg_profile_collect")
+        for ws in workspaces.values():      # no overflow happened in the timed region
+            f3d.diff_gof_rasterization.read_status(ws)
+        return t, [st[i] for i in range(5)], max(int(nc.value), 1), launches
 
-    # second timed loop (N = 1): the frames leave the GPU -- packing to 8-bit RGB (visualize.py:416) or the float32 RGB planes, and
-    # the device-to-host copy into pinned memory, inside the timed region (SURVEY 8d "views/s ... including the final D2H of RGB")
-    d2h = None
+    # (1) frames left in HBM (N > 1: + the RCCL gather of the packed frames)
+    elapsed_hbm, stage_ms, ncalls, nlaunch = measure(step, args.warmup, args.steps)
+    elapsed_hbm = max_over_ranks(elapsed_hbm, dist, world, comm_device if world > 1 else device)
+
+    # (2) N = 1, SURVEY 8d "views/s = views / wall time including the final D2H of RGB only": the frames leave the GPU as 8-bit RGB
+    # (what the reference turns every frame into before it writes the video, visualize.py:407,416). Two output buffers: while
+    # step i + 1 renders, a side stream packs step i's frames (f3dg_pack_frames) and copies them to pinned host memory; everything
+    # is waited for inside the timed region. Also timed: the float32 RGB planes, un-pipelined (the PCIe-heavy variant).
+    elapsed, d2h = elapsed_hbm, None
     if world == 1 and not args.no_d2h:
-        host_u8 = torch.empty((V, RES, RES, 3), dtype=torch.uint8).pin_memory()
-        host_f32 = torch.empty((V, 3, RES, RES), dtype=torch.float32).pin_memory()
+        side = torch.cuda.Stream(device=device)
+        outs = [out, torch.empty_like(out)]
+        host = [torch.empty((V, RES, RES, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        rendered = [torch.cuda.Event() for _ in range(2)]
+        copied = [torch.cuda.Event() for _ in range(2)]
+        state = {"i": 0}
 
-        def step_u8():
-            step()
-            host_u8.copy_(f3d.gaussian_renderer.pack_frames(out), non_blocking=True)
+        def step_d2h():
+            k = state["i"] & 1
+            state["i"] += 1
+            torch.cuda.current_stream().wait_event(copied[k])        # the side stream has read buffer k (two steps ago)
+            for a, b in chunks:
+                render_chunk(a, b, check=False, out=outs[k])
+            rendered[k].record()
+            with torch.cuda.stream(side):
+                side.wait_event(rendered[k])
+                host[k].copy_(f3d.gaussian_renderer.pack_frames(outs[k]), non_blocking=True)
+                copied[k].record()
+
+        for ev in copied:
+            ev.record()
+        elapsed, stage_ms, ncalls, nlaunch = measure(step_d2h, 2, args.steps)
+
+        host_f32 = torch.empty((V, 3, RES, RES), dtype=torch.float32).pin_memory()
 
         def step_f32():
             step()
             host_f32.copy_(out[:, :3], non_blocking=True)
 
-        e8 = timed(step_u8, gat.barrier, 1, args.steps)
         e32 = timed(step_f32, gat.barrier, 1, args.steps)
-        d2h = {"uint8_rgb": {"value": V * args.steps / e8, "unit": "views/s", "ms_per_step": 1e3 * e8 / args.steps,
-                             "bytes_per_step": V * RES * RES * 3},
+        d2h = {"uint8_rgb": {"value": V * args.steps / elapsed, "unit": "views/s", "ms_per_step": 1e3 * elapsed / args.steps,
+                             "bytes_per_step": V * RES * RES * 3, "pipelined": True},
                "float32_rgb": {"value": V * args.steps / e32, "unit": "views/s", "ms_per_step": 1e3 * e32 / args.steps,
-                               "bytes_per_step": V * RES * RES * 12},
-               "note": "same step + f3dg_pack_frames (uint8) or the three float planes, + cudaMemcpyAsync to pinned host memory, "
-                       "synchronised once after the last step"}
+                               "bytes_per_step": V * RES * RES * 12, "pipelined": False},
+               "note": "uint8: f3dg_pack_frames + copy to pinned host memory on a side stream, double-buffered behind the next step's "
+                       "rendering, all waited for inside the timed region (= `value`); float32: the three RGB planes copied after every "
+                       "step on the same stream"}
+
+    # (3) the same build in the reference's own arithmetic (float32 with the float64 island, forward.cu:511-579), frames left in HBM
+    exact = None
+    if args.render_mode == "fast" and not args.no_exact:
+        _lib.check(L.f3dg_set_option(b"render_fast", 0), "f3dg_set_option")
+        e_x, st_x, nc_x, _ = measure(step, 1, args.steps)
+        _lib.check(L.f3dg_set_option(b"render_fast", 1), "f3dg_set_option")
+        e_x = max_over_ranks(e_x, dist, world, comm_device if world > 1 else device)
+        exact = (e_x, st_x, nc_x)
 
     if rank != 0:
         return None
     copy_gbs = measured_copy_bandwidth(device)
     T = ((RES + 15) // 16) ** 2
-    launches = max(int(ncalls.value), 1)
-    per = lambda ms: ms / launches
-    # algorithmic bytes per launch, summed over the views of a launch
+    per = lambda ms, n=None: ms / (n or ncalls)
     nl = len(chunks)
-    b_render = (72.0 * R_total + (36.0 * RES * RES + 8.0 * T) * V) / nl      # inference mode: the aux planes are not written
-    b_render_proc = (72.0 * R_proc + (36.0 * RES * RES + 8.0 * T) * V) / nl  # the same formula on the instances the launch is handed
-    b_pre = 207.0 * P * V / nl
-    sort_bits = 32 + T.bit_length()       # getHigherMsb(T) of rasterizer_impl.cu:35-50 (9 for 256 tiles): the reference sorts 41 bits
-    b_bin = (20.0 * P * V + 12.0 * R_total + 24.0 * R_total * ((sort_bits + 7) // 8) + 8.0 * R_total + 8.0 * T * V) / nl
+    # ALGORITHMIC bytes per launch (SURVEY 8d), summed over the views of a launch. The unit count is what the launch is handed
+    # (R_proc: the culled lists); the same formula on the reference's num_rendered (R_total) is the secondary figure.
+    b_render = (72.0 * R_proc + (36.0 * RES * RES + 8.0 * T) * V) / nl      # inference mode: the aux planes are not written
+    b_render_ref = (72.0 * R_total + (36.0 * RES * RES + 8.0 * T) * V) / nl
+    # this build's own streams (DESIGN.md section 3): projection reads the 92 B of a Gaussian once per call and writes 96 B per
+    # (view, Gaussian) (record 64, ellipse 16, radius 4, rectangle 8, sort key 4); binning moves 108 B per (view, Gaussian) (three
+    # depth-sort passes 56, rectangle gather 24, prefix sum 12, instance generation 16) + 18 B per instance (generation 6, tile pass
+    # histogram 2 + scatter 10) + the ranges
+    b_pre = (92.0 * P + 96.0 * P * V) / nl
+    b_bin = (108.0 * P * V + 18.0 * R_proc + 8.0 * T * V) / nl
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     prof = profiles_record(P, V, RES, args.views_per_call, args.render_mode, args.tile_cull)
+    kname = {3: "render3_fwd_kernel", 2: "render2_fwd_kernel", 1: "render_fwd_kernel"}[render_kernel_id()]
+
+    def roofline(stage, mode_fast, n):
+        ms = per(stage[2], n)
+        return {"bound": "hbm", "kernel": "%s<SAVE_AUX=false, FAST=%s>" % (kname, "true" if mode_fast else "false"),
+                "achieved": gbs(b_render, ms), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(b_render, ms) / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": b_render, "ms_per_launch": ms,
+                "units": "72 B x instances_processed_per_step (the list entries the launch is handed) + 36 B x pixels + 8 B x tiles",
+                "frac_on_reference_instances": gbs(b_render_ref, ms) / HBM_PEAK_GBS,
+                "units_reference": "the same formula on instances_per_step = the reference's num_rendered for this input (tile_cull 0)"}
+
+    rf = roofline(stage_ms, args.render_mode == "fast", ncalls)
+    rf.update({"traffic": None,      # HBM bytes need PMC counters: see traffic_from_profiles
+               "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
+               "peak_measured_copy": copy_gbs,     # SURVEY 8d: device-to-device copy on THIS box, read + write bytes
+               "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
+                                     "compositing": stage_ms[2] / args.steps}})
+    caveat = ("fast = error-free float32 pairs for the float64 island + hardware exp/rcp/rsq; every channel within 1e-4 of the oracle "
+              "(RGB <= 3e-7), EXCEPT that the distortion channel (values 1e-7..1e-5 from cancelling float32 sums) moves by 3-17 % "
+              "relative (median) at sigma0 = 0.01 -- absolute <= 1e-6, the reference's own 1-ulp noise on that channel") \
+        if args.render_mode == "fast" else "exact = the reference's float32/float64 operation order"
     result = {
         "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)",
         "value": world * V * args.steps / elapsed,
@@ -256,43 +322,45 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.render_mode == "fast" else "f32 (+f64 islands, as the reference)", "data": "synthetic",
-        "config": {"workload": "C2: 1 image/GPU, %d Gaussians (sigma0=%g), %d-view orbit @%dx%d, GOF forward raster only, "
-                               "compositing arithmetic: %s" % (P, args.sigma0, V, RES, RES, "fast (error-free float32 pairs; parity-gated at 1e-4)"
-                                                               if args.render_mode == "fast" else "exact (reference float32/float64 order)"),
-                   "gaussians": P, "views": V, "resolution": RES, "instances_per_step": R_total,
+        "config": {"workload": "C2: 1 image/GPU, %d Gaussians (sigma0=%g), %d-view orbit @%dx%d, GOF forward raster only; timed region = "
+                               "%s; compositing arithmetic: %s" % (
+                                   P, args.sigma0, V, RES, RES,
+                                   "render + RCCL gather of the 8-bit frames to rank 0" if world > 1 else
+                                   ("render, frames left in HBM" if d2h is None else "render + 8-bit RGB frames copied to pinned host memory"),
+                                   caveat),
+                   "gaussians": P, "views": V, "resolution": RES, "sigma0": args.sigma0, "instances_per_step": R_total,
                    "instances_processed_per_step": R_proc, "tile_cull": args.tile_cull,
                    "views_per_call": args.views_per_call, "render_mode": args.render_mode,
+                   "kernel_launches_per_call": nlaunch / float(ncalls),
                    "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "render2_fwd_kernel<SAVE_AUX=false, FAST=%s>" % ("true" if args.render_mode == "fast" else "false"),
-                     "achieved": gbs(b_render, per(stage_ms[2])), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs(b_render, per(stage_ms[2])) / HBM_PEAK_GBS,
-                     "traffic": None,      # HBM bytes need PMC counters: see traffic_from_profiles
-                     "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
-                     "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
-                     "algorithmic_bytes_per_launch": b_render, "ms_per_launch": per(stage_ms[2]),
-                     "units": "72 B x instances_per_step (the reference's num_rendered for this input: the workload's size) + 36 B x pixels "
-                              "+ 8 B x tiles; with tile culling the launch is handed instances_processed_per_step of them -- "
-                              "on that count the same formula gives achieved_on_processed_instances",
-                     "achieved_on_processed_instances": gbs(b_render_proc, per(stage_ms[2])),
-                     "frac_on_processed_instances": gbs(b_render_proc, per(stage_ms[2])) / HBM_PEAK_GBS,
-                     "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
-                                           "compositing": stage_ms[2] / args.steps}},
+        "value_in_hbm": world * V * args.steps / elapsed_hbm, "ms_per_step_in_hbm": 1e3 * elapsed_hbm / args.steps,
+        "roofline": rf,
         "rooflines_other": {
             "preprocess_kernel": {"bound": "hbm", "algorithmic_bytes_per_launch": b_pre, "ms_per_launch": per(stage_ms[0]),
                                   "achieved": gbs(b_pre, per(stage_ms[0])), "unit": "GB/s", "frac": gbs(b_pre, per(stage_ms[0])) / HBM_PEAK_GBS,
-                                  "formula": "207 B x P x views (92 read + 115 written per Gaussian and view)"},
+                                  "formula": "this build's streams: 92 B x P (inputs, once per call) + 96 B x P x views written",
+                                  "traffic_from_profiles": (prof.get("stages") or {}).get("preprocess")},
             "binning (depth sort per Gaussian, instance generation, tile pass, ranges)": {
                 "bound": "hbm", "algorithmic_bytes_per_launch": b_bin, "ms_per_launch": per(stage_ms[1]),
                 "achieved": gbs(b_bin, per(stage_ms[1])), "unit": "GB/s", "frac": gbs(b_bin, per(stage_ms[1])) / HBM_PEAK_GBS,
-                "formula": "20 P + 12 R (keys) + 24 R x ceil(%d key bits / 8) (the reference's radix passes) + 8 R + 8 T (ranges): the bytes of "
-                           "the REFERENCE's algorithm (a %d-bit sort of every instance); this stage sorts the Gaussians by depth once per view "
-                           "and the instances by tile only, so it moves fewer bytes and frac can exceed 1" % (sort_bits, sort_bits)}},
+                "formula": "this build's streams: 108 B x P x views + 18 B x instances_processed + 8 B x tiles x views",
+                "traffic_from_profiles": (prof.get("stages") or {}).get("binning")}},
     }
     if d2h:
         result["with_d2h"] = d2h
+    if exact:
+        e_x, st_x, nc_x = exact
+        result["value_exact"] = world * V * args.steps / e_x
+        result["ms_per_step_exact"] = 1e3 * e_x / args.steps
+        result["roofline_exact"] = roofline(st_x, False, nc_x)
+        result["roofline_exact"]["note"] = "same run, option render_fast = 0: the reference's float32/float64 operation order; frames left in HBM"
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(g, cams, shs, P, RES, args.cpu_sample_views)
     return result
+
+
+def render_kernel_id():
+    return int(os.environ.get("F3DG_RENDER_KERNEL", "3"))
 
 
 # ---------------------------------------------------------------------------------------------------------------- C4
@@ -329,7 +397,9 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
     timed(step, gat.barrier, args.warmup, 0)
     step.events.clear()
     L.f3dg_profile_enable(1)
+    L.f3dg_debug_launch_count(1)
     elapsed = timed(step, gat.barrier, 0, args.steps)
+    nlaunch = int(L.f3dg_debug_launch_count(1))      # kernels of libf3dg_hip.so: rasterizer, splat head, hand-off, GroupNorm, packing
     L.f3dg_profile_enable(0)
     stage_ms = (C.c_double * 5)()
     ncalls = C.c_int(0)
@@ -355,7 +425,7 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
                                   "rasterizer stages (HIP events)": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
                                                                      "compositing": stage_ms[2] / args.steps}},
         "launches": {"rasterizer_calls_per_step": calls_per_step, "rasterizer_calls_per_image": calls_per_step / B,
-                     "rasterizer_kernel_launches_per_image": RASTER_LAUNCHES_PER_CALL * calls_per_step / B,
+                     "library_kernel_launches_per_image": nlaunch / float(max(args.steps, 1)) / B,
                      "reference_rasterizer_calls_per_image": 2 * V,
                      "note": "the reference issues one rasterizer call (>= 10 launches + a blocking D2H) per (image, view): "
                              "visualize.py:293-314 and :387-416"},

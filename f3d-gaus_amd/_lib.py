@@ -51,6 +51,7 @@ SIGNATURES = {
     "f3dg_group_norm_silu_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
     "f3dg_set_option": (_i, [C.c_char_p, _i]),
     "f3dg_profile_enable": (_i, [_i]),
+    "f3dg_debug_launch_count": (C.c_longlong, [_i]),
     "f3dg_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "f3dg_backward_pairs": (_i, [_p, _p, C.POINTER(_ll)]),
     "f3dg_debug_timing": (_i, [C.POINTER(C.c_ulonglong), _i]),

@@ -85,12 +85,14 @@ void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s)
     if (slot >= 0 && slot < (int)g_prof.bwd.size()) (void)hipEventRecord(g_prof.bwd[slot].ev[stage_done + 1], s);
 }
 
+unsigned long long g_f3dg_kernel_launches = 0;      // host-side counter of F3DG_KLAUNCH (not thread-safe: a diagnostic)
 int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
+int g_f3dg_render_lds_pad = 0;
 int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
@@ -101,6 +103,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; return F3DG_OK; }
+    if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
@@ -109,6 +112,13 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
     return F3DG_ERR_BAD_ARG;
+}
+
+extern "C" long long f3dg_debug_launch_count(int reset)
+{
+    const long long n = (long long)g_f3dg_kernel_launches;
+    if (reset) g_f3dg_kernel_launches = 0;
+    return n;
 }
 
 extern "C" int f3dg_profile_enable(int on)
@@ -303,11 +313,11 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     const size_t HW = (size_t)W * H;
 
     const int save_aux = (flags & F3DG_FLAG_SAVE_AUX) ? 1 : 0;
-    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered,
+    F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered,
                        (unsigned)f3dg_render_uses_fast(save_aux));
 
     if (P == 0) {
-        hipLaunchKernelGGL(fill_background_kernel, dim3(1024), dim3(256), 0, s, n_views, HW, background,
+        F3DG_KLAUNCH(fill_background_kernel, dim3(1024), dim3(256), 0, s, n_views, HW, background,
                            (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color);
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
@@ -365,7 +375,7 @@ extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_
     char* ws = static_cast<char*>(workspace);
     F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
     if (h_needed) *h_needed = 0;
-    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
+    F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
     int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                  view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
     if (rc != F3DG_OK) return rc;
@@ -424,7 +434,7 @@ extern "C" long long f3dg_integrate(void* stream, void* workspace, size_t worksp
     if (h_needed) *h_needed = 0;
     if (P == 0 || PN == 0) {                               // rasterize_points.cu:300: nothing runs, the fills stay
         if (workspace_bytes < sizeof(F3dgHeader)) return F3DG_ERR_WORKSPACE;
-        hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<F3dgHeader*>(workspace), (unsigned)max_rendered);
+        F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<F3dgHeader*>(workspace), (unsigned)max_rendered);
         int rc = f3dg_launch_integrate_fill(s, W, H, PN, out_color, out_alpha_integrated, out_color_integrated);
         if (rc != F3DG_OK) return rc;
         F3DG_HIP_CHECK(hipStreamSynchronize(s));
@@ -513,7 +523,7 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
     CP(clamped, L.clamped, VP);
     CP(keys_sorted, L.keys[0], C * 8);
     if (point_list && C)        // the Gaussian ids without the quadrant masks of the compositing kernel (F3DG_ID_BITS)
-        hipLaunchKernelGGL(export_ids_kernel, dim3((unsigned)((C + 1023) / 1024 < 4096 ? (C + 1023) / 1024 : 4096)), dim3(256), 0, s,
+        F3DG_KLAUNCH(export_ids_kernel, dim3((unsigned)((C + 1023) / 1024 < 4096 ? (C + 1023) / 1024 : 4096)), dim3(256), 0, s,
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), C, point_list);
     CP(ranges, L.ranges, (size_t)n_views * T * 8);
     CP(final_T, L.final_T, (size_t)n_views * 4 * HW * 4);

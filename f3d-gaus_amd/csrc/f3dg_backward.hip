@@ -1026,7 +1026,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     const int prof = f3dg_prof_bwd_begin(s);
 
     if (g_f3dg_render_cull)
-        hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
+        F3DG_KLAUNCH(render_bwd_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
                            reinterpret_cast<const float4*>(ws + L.bbox),
@@ -1035,7 +1035,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
                            reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
                            acc);
     else     // option render_cull = 0: the lock-step kernel (every lane visits every entry, wave butterflies), kept for A/B
-        hipLaunchKernelGGL(render_bwd_lockstep_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
+        F3DG_KLAUNCH(render_bwd_lockstep_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
                            reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
@@ -1043,7 +1043,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
                            reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
                            acc);
     f3dg_prof_bwd_mark(prof, 0, s);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, P,
+    F3DG_KLAUNCH(preprocess_bwd_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, P,
                        D, M, means3D, radii_used, shs, reinterpret_cast<const unsigned char*>(ws + L.clamped), scales,
                        rotations, viewmatrix, cam_pos, acc, dL_dview2gaussian, dL_dcolor, dL_dmean3D, dL_dsh, dL_dscale,
                        dL_drot, n_views);

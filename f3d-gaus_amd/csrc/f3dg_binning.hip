@@ -746,9 +746,9 @@ int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out,
     if (n == 0) return F3DG_OK;
     const unsigned nblocks = (unsigned)((n + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK);
     if (nblocks > tmp_elems) return F3DG_ERR_WORKSPACE;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(F3DG_BLOCK), 0, s, in, (u64)n, tmp);
-    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(1024), 0, s, tmp, nblocks, hdr_total);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(F3DG_BLOCK), 0, s, in, out, (u64)n, tmp, exclusive);
+    F3DG_KLAUNCH(scan_reduce_kernel, dim3(nblocks), dim3(F3DG_BLOCK), 0, s, in, (u64)n, tmp);
+    F3DG_KLAUNCH(scan_blocksums_kernel, dim3(1), dim3(1024), 0, s, tmp, nblocks, hdr_total);
+    F3DG_KLAUNCH(scan_apply_kernel, dim3(nblocks), dim3(F3DG_BLOCK), 0, s, in, out, (u64)n, tmp, exclusive);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
@@ -784,18 +784,18 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
     u32* chunk_minmax = minmax + 2 * (size_t)V;
     const bool view_scan = cps <= 64;      // one workgroup per view (<= 4 rounds of 4096 entries) or the general three-kernel scan
 #define F3DG_GSORT_PASS(PASS, IN, OUT)                                                                                                     \
-    hipLaunchKernelGGL((gsort_hist_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], (u32)P, cps, hist, minmax, chunk_minmax); \
+    F3DG_KLAUNCH((gsort_hist_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], (u32)P, cps, hist, minmax, chunk_minmax); \
     if (view_scan)                                                                                                                         \
-        hipLaunchKernelGGL(gsort_scan_kernel, dim3(V), dim3(1024), 0, s, 256u * cps, (u32)P, hist);                                       \
+        F3DG_KLAUNCH(gsort_scan_kernel, dim3(V), dim3(1024), 0, s, 256u * cps, (u32)P, hist);                                       \
     else {                                                                                                                                 \
         rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * gblocks, scan_tmp, L.scan_tmp_elems, 1, nullptr);        \
         if (rc != F3DG_OK) return rc;                                                                                                      \
     }                                                                                                                                      \
-    hipLaunchKernelGGL((gsort_scatter_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], gv[IN], gk[OUT], gv[OUT], (u32)P, cps, \
+    F3DG_KLAUNCH((gsort_scatter_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], gv[IN], gk[OUT], gv[OUT], (u32)P, cps, \
                        hist, minmax)
     F3DG_GSORT_PASS(0, 0, 1);
     F3DG_GSORT_PASS(1, 1, 0);
-    hipLaunchKernelGGL(gsort_range_kernel, dim3(V), dim3(64), 0, s, cps, chunk_minmax, minmax);
+    F3DG_KLAUNCH(gsort_range_kernel, dim3(V), dim3(64), 0, s, cps, chunk_minmax, minmax);
     F3DG_GSORT_PASS(2, 0, 1);
     F3DG_GSORT_PASS(3, 1, 0);
 #undef F3DG_GSORT_PASS
@@ -804,13 +804,13 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
     u32* rx = gk[0];
 
     // 2. instances in (view, depth, id) order
-    hipLaunchKernelGGL(gsort_gather_rects_kernel, dim3((unsigned)V * (unsigned)((P + 4 * F3DG_BLOCK - 1) / (4 * F3DG_BLOCK))), dim3(F3DG_BLOCK), 0, s, P, gv[0], gv[1], minmax,
+    F3DG_KLAUNCH(gsort_gather_rects_kernel, dim3((unsigned)V * (unsigned)((P + 4 * F3DG_BLOCK - 1) / (4 * F3DG_BLOCK))), dim3(F3DG_BLOCK), 0, s, P, gv[0], gv[1], minmax,
                        reinterpret_cast<const uint2*>(ws + L.rects), offsets_sorted, rx);
     rc = f3dg_launch_scan_inclusive(s, offsets_sorted, offsets_sorted, (unsigned long long)VP, scan_tmp, L.scan_tmp_elems, 0, hdr);
     if (rc != F3DG_OK) return rc;
     const int passes = f3dg_sort_passes(V, T);
     int src = passes & 1;                                                      // so that the tile pass(es) end in half 0
-    hipLaunchKernelGGL((duplicate_sorted_kernel<G>), pgrid, dim3(F3DG_BLOCK), 0, s, P, tile_bits, grid_x, gv[0], gv[1], minmax, rx, offsets_sorted, hdr,
+    F3DG_KLAUNCH((duplicate_sorted_kernel<G>), pgrid, dim3(F3DG_BLOCK), 0, s, P, tile_bits, grid_x, gv[0], gv[1], minmax, rx, offsets_sorted, hdr,
                        kgrp[src], vals[src]);
 
     // 3. stable pass(es) over the tile bits inside every view's segment of the instance arrays: (view, tile, depth, id) order
@@ -819,24 +819,24 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
         u32* segtab = reinterpret_cast<u32*>(ws + L.segtab);
         const u32 xstride = (u32)V / 8u + 2u;
         st.vstart = segtab; st.bglob = segtab + (V + 1); st.xprefix = segtab + 2 * (V + 1); st.xstride = xstride; st.V = (u32)V;
-        hipLaunchKernelGGL(view_segments_kernel, dim3(1), dim3(512), 0, s, V, P, offsets_sorted, hdr, segtab, segtab + (V + 1),
+        F3DG_KLAUNCH(view_segments_kernel, dim3(1), dim3(512), 0, s, V, P, offsets_sorted, hdr, segtab, segtab + (V + 1),
                            segtab + 2 * (V + 1), xstride);
         const size_t nbmax = (size_t)L.sort_blocks + (size_t)V;                // >= sum over the views of ceil(instances / chunk)
         const u32 per_xcd = (u32)((nbmax + 7) / 8 < 160 ? (nbmax + 7) / 8 : 160);   // 5 workgroups per CU of the scatter's LDS
         const u32 per_xcd_h = (u32)((nbmax + 7) / 8 < 512 ? (nbmax + 7) / 8 : 512);
         for (int p = 0; p < passes; p++) {
             F3DG_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(u32) * 256 * nbmax, s));
-            hipLaunchKernelGGL((radix2_hist_var_kernel<G>), dim3(8 * per_xcd_h), dim3(F3DG_BLOCK), 0, s, kgrp[src], st, 8 * p, hist);
+            F3DG_KLAUNCH((radix2_hist_var_kernel<G>), dim3(8 * per_xcd_h), dim3(F3DG_BLOCK), 0, s, kgrp[src], st, 8 * p, hist);
             rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * nbmax, scan_tmp, L.scan_tmp_elems, 1, nullptr);
             if (rc != F3DG_OK) return rc;
             // (a single pass: the group stream is not needed again, the ranges come from the scanned histogram)
-            hipLaunchKernelGGL((radix2_scatter_var_kernel<G>), dim3(8 * per_xcd), dim3(F3DG_BLOCK), 0, s, kgrp[src], vals[src],
+            F3DG_KLAUNCH((radix2_scatter_var_kernel<G>), dim3(8 * per_xcd), dim3(F3DG_BLOCK), 0, s, kgrp[src], vals[src],
                                passes == 1 ? (G*)nullptr : kgrp[src ^ 1], vals[src ^ 1], st, 8 * p, hist);
             src ^= 1;
         }
         if (passes == 1) {
             const u32 nseg = (u32)V * (u32)T;
-            hipLaunchKernelGGL(ranges_from_offsets_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, (u32)V, (u32)T, tile_bits,
+            F3DG_KLAUNCH(ranges_from_offsets_kernel, dim3((nseg + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, (u32)V, (u32)T, tile_bits,
                                segtab + (V + 1), hist, hdr, reinterpret_cast<uint2*>(ws + L.ranges));
             F3DG_HIP_CHECK(hipGetLastError());
             return F3DG_OK;
@@ -844,7 +844,7 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
     }
     // 4. identifyTileRanges on the final list
     F3DG_HIP_CHECK(hipMemsetAsync(ws + L.ranges, 0, sizeof(uint2) * (size_t)V * T, s));
-    hipLaunchKernelGGL((group_bounds_kernel<G>), dim3(2048), dim3(F3DG_BLOCK), 0, s, kgrp[0], hdr, tile_bits, T, reinterpret_cast<u32*>(ws + L.ranges));
+    F3DG_KLAUNCH((group_bounds_kernel<G>), dim3(2048), dim3(F3DG_BLOCK), 0, s, kgrp[0], hdr, tile_bits, T, reinterpret_cast<u32*>(ws + L.ranges));
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
@@ -880,7 +880,7 @@ int f3dg_launch_export_keys(hipStream_t s, int V, int P, int W, int H, const F3d
     const int T = grid_x * grid_y;
     const u32 nseg = (u32)V * (u32)T;
     const u32 rg = nseg < 65535u * 4u ? nseg : 65535u * 4u;
-    hipLaunchKernelGGL(export_keys_kernel, dim3(rg), dim3(F3DG_BLOCK), 0, s, nseg, P, f3dg_tile_bits(T), T,
+    F3DG_KLAUNCH(export_keys_kernel, dim3(rg), dim3(F3DG_BLOCK), 0, s, nseg, P, f3dg_tile_bits(T), T,
                        reinterpret_cast<const uint2*>(ws + L.ranges), reinterpret_cast<const F3dgHeader*>(ws + L.header),
                        reinterpret_cast<const u32*>(ws + L.vals[0]), reinterpret_cast<const float*>(ws + L.depths),
                        reinterpret_cast<u64*>(ws + L.keys[0]));

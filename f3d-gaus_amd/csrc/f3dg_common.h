@@ -117,6 +117,10 @@ struct F3dgIntegLayout {
 };
 F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap);
 
+// every kernel launch of the library goes through this macro: f3dg_debug_launch_count reports how many a call sequence issued
+extern unsigned long long g_f3dg_kernel_launches;
+#define F3DG_KLAUNCH(...) do { ++g_f3dg_kernel_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 int f3dg_set_hip_error(hipError_t e, const char* where);
 #define F3DG_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return f3dg_set_hip_error(_e, #expr); } while (0)
 
@@ -150,6 +154,7 @@ extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it 
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
 extern int g_f3dg_render_kernel;       // 3 (default): render3 (one wave64 per 8x8 quadrant, no barriers); 2: render2 (four waves per tile,
                                        // Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);
 void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);

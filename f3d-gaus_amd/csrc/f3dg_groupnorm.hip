@@ -140,7 +140,7 @@ int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const 
     if (N < 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0 || !x || !weight || !bias || !y) return F3DG_ERR_BAD_ARG;
     if (N == 0) return F3DG_OK;
     if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;       // 16-byte loads / stores
-    hipLaunchKernelGGL(group_norm_silu_kernel<T>, dim3((unsigned)(N * groups)), dim3(GN_THREADS), 0, (hipStream_t)stream, C, HW,
+    F3DG_KLAUNCH(group_norm_silu_kernel<T>, dim3((unsigned)(N * groups)), dim3(GN_THREADS), 0, (hipStream_t)stream, C, HW,
                        groups, x, weight, bias, eps, apply_silu, y);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

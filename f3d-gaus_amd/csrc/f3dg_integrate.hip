@@ -656,7 +656,7 @@ F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap)
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated)
 {
-    hipLaunchKernelGGL(integrate_fill_kernel, dim3(1024), dim3(256), 0, s, (size_t)W * H, (size_t)PN, out_color,
+    F3DG_KLAUNCH(integrate_fill_kernel, dim3(1024), dim3(256), 0, s, (size_t)W * H, (size_t)PN, out_color,
                        out_alpha_integrated, out_color_integrated);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
@@ -678,15 +678,15 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, floa
     unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
     unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
     if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 2)
-        hipLaunchKernelGGL(integrate_pass1_cull_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+        F3DG_KLAUNCH(integrate_pass1_cull_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);
     else if (g_f3dg_render_pretest && g_f3dg_render_cull)          // round 1's version: per-ray pre-test + block masks from the boxes
-        hipLaunchKernelGGL((integrate_pass1_kernel<true>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+        F3DG_KLAUNCH((integrate_pass1_kernel<true>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);
     else
-        hipLaunchKernelGGL((integrate_pass1_kernel<false>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+        F3DG_KLAUNCH((integrate_pass1_kernel<false>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);
     F3DG_HIP_CHECK(hipGetLastError());
@@ -717,17 +717,17 @@ int f3dg_launch_integrate_points(hipStream_t s, int PN, int W, int H, float foca
 
     F3DG_HIP_CHECK(hipMemsetAsync(ws + I.pix_points, 0, I.clear_bytes, s));
     const dim3 pgrid((PN + F3DG_BLOCK - 1) / F3DG_BLOCK);
-    hipLaunchKernelGGL(integrate_points_bin_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
+    F3DG_KLAUNCH(integrate_points_bin_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
                        focal_x, focal_y, hdr, out_alpha_integrated, out_color_integrated, pix_points, tile_last, pt_pix, pt_rank);
     int rc = f3dg_launch_scan_inclusive(s, pix_points, pix_start, (unsigned long long)W * H,
                                         reinterpret_cast<unsigned*>(ws + I.scan_tmp), I.scan_tmp_elems, 1, nullptr);
     if (rc != F3DG_OK) return rc;
-    hipLaunchKernelGGL(integrate_points_perm_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, pt_pix, pt_rank, pix_start, perm);
-    hipLaunchKernelGGL(integrate_points_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
+    F3DG_KLAUNCH(integrate_points_perm_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, pt_pix, pt_rank, pix_start, perm);
+    F3DG_KLAUNCH(integrate_points_kernel, pgrid, dim3(F3DG_BLOCK), 0, s, PN, points3D, viewmatrix, W, H, tiles_x,
                        focal_x, focal_y, hdr, ranges, point_list, rec, contrib_ids, contrib_n, n_contrib, out_color,
                        out_alpha_integrated, out_color_integrated, pix_points, pix_start, perm, alpha_min);
     F3DG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(integrate_epilogue_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+    F3DG_KLAUNCH(integrate_epilogue_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
                        points3D, viewmatrix, pix_points, tile_last, out_color);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

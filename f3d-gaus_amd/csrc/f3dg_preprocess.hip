@@ -530,7 +530,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
-    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales, scale_modifier,
+    F3DG_KLAUNCH(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales, scale_modifier,
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
                        depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all, tile_cull,
@@ -545,7 +545,7 @@ extern "C" int f3dg_mark_visible(void* stream, int P, const float* means3D, cons
     (void)projmatrix;   // the reference computes p_proj but only tests view-space z (auxiliary.h:192)
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return F3DG_ERR_BAD_ARG;
     if (P == 0) return F3DG_OK;
-    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D,
+    F3DG_KLAUNCH(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D,
                        viewmatrix, present);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

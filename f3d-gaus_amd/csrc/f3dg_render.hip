@@ -863,19 +863,20 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     const int g_f3dg_render_fast = f3dg_render_uses_fast(save_aux);
     if (g_f3dg_render_kernel == 3) {
         const dim3 grid3((unsigned)V * (unsigned)T * 4u);
-#define F3DG_LAUNCH3D(AUX, FST, DMA, OCC) hipLaunchKernelGGL((render3_fwd_kernel<AUX, FST, DMA, OCC>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T,  \
+#define F3DG_LAUNCH3D(AUX, FST, DMA, OCC) F3DG_KLAUNCH((render3_fwd_kernel<AUX, FST, DMA, OCC>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \
                                                   out_color, final_T, n_contrib)
 #define F3DG_LAUNCH3(AUX, FST, OCC) do { if (g_f3dg_render_dma) F3DG_LAUNCH3D(AUX, FST, true, OCC); else F3DG_LAUNCH3D(AUX, FST, false, OCC); } while (0)
-        if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3(true, true, 7); else F3DG_LAUNCH3(true, false, 6); }
-        else { if (g_f3dg_render_fast) F3DG_LAUNCH3(false, true, 8); else F3DG_LAUNCH3(false, false, 6); }
+        // every variant fits 64 VGPRs without spills: 8 waves per SIMD, 32 x 5 KB = the CU's 160 KB of LDS
+        if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3(true, true, 8); else F3DG_LAUNCH3(true, false, 8); }
+        else { if (g_f3dg_render_fast) F3DG_LAUNCH3(false, true, 8); else F3DG_LAUNCH3(false, false, 8); }
 #undef F3DG_LAUNCH3
 #undef F3DG_LAUNCH3D
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
     }
     if (g_f3dg_render_kernel == 2) {
-#define F3DG_LAUNCH2R(AUX, FST, RND, OCC) hipLaunchKernelGGL((render2_fwd_kernel<AUX, FST, RND, OCC>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
+#define F3DG_LAUNCH2R(AUX, FST, RND, OCC) F3DG_KLAUNCH((render2_fwd_kernel<AUX, FST, RND, OCC>), grid, dim3(F3DG_BLOCK), 0, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,     \
                                                   out_color, final_T, n_contrib)
         // fast arithmetic fits 72 VGPRs: 192-entry rounds (18 KB of LDS) run 7 workgroups per CU, 2.53 vs 2.66 ms at C2; the exact
@@ -888,7 +889,7 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
     }
-#define F3DG_LAUNCH(AUX, PRE, CUL, QUE, FST) hipLaunchKernelGGL((render_fwd_kernel<AUX, PRE, CUL, QUE, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, \
+#define F3DG_LAUNCH(AUX, PRE, CUL, QUE, FST) F3DG_KLAUNCH((render_fwd_kernel<AUX, PRE, CUL, QUE, FST>), grid, dim3(F3DG_BLOCK), 0, s, V, P, \
                                                             W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec,   \
                                                             bbox, background, bg_per_view, out_color, final_T, n_contrib)
 #define F3DG_LAUNCH_Q(AUX, PRE, CUL) do { if (g_f3dg_render_fast) { if (g_f3dg_render_queue) F3DG_LAUNCH(AUX, PRE, CUL, true, true); else F3DG_LAUNCH(AUX, PRE, CUL, false, true); } \

@@ -184,7 +184,7 @@ extern "C" int f3dg_splat_head(void* stream, int B, int H, int W, const float* n
     const long long HW = (long long)H * W;
     if (n_offset < 0 || n_total < n_offset + HW) return F3DG_ERR_BAD_ARG;
     dim3 grid((unsigned)((HW + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)B);
-    hipLaunchKernelGGL(splat_head_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, (int)HW, net_out, depth,
+    F3DG_KLAUNCH(splat_head_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, (int)HW, net_out, depth,
                        ray_dirs, view_to_world, cam_quat, squre_clip, n_total, n_offset, xyz, opacity, scaling,
                        rotation, features_dc, features_rest, unet_depth);
     F3DG_HIP_CHECK(hipGetLastError());
@@ -198,7 +198,7 @@ extern "C" int f3dg_render_epilogue(void* stream, int n_views, int H, int W, con
     if (n_views <= 0 || H <= 0 || W <= 0 || !raster || !c2w) return F3DG_ERR_BAD_ARG;
     if (!normal_world && !depth_normal) return F3DG_OK;
     dim3 grid((unsigned)(((long long)H * W + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)n_views);
-    hipLaunchKernelGGL(epilogue_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, H, W, raster, c2w, fx, fy,
+    F3DG_KLAUNCH(epilogue_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, H, W, raster, c2w, fx, fy,
                        normal_world, depth_normal);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
@@ -211,7 +211,7 @@ extern "C" int f3dg_pack_frames(void* stream, int n_frames, int H, int W, int sr
     if (n_frames == 0) return F3DG_OK;
     const size_t HW = (size_t)H * W;
     if (((uintptr_t)src & 15u) || ((uintptr_t)dst & 3u)) return F3DG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(pack_frames_kernel, dim3((unsigned)((HW / 4 + F3DG_BLOCK) / F3DG_BLOCK), (unsigned)n_frames), dim3(F3DG_BLOCK), 0,
+    F3DG_KLAUNCH(pack_frames_kernel, dim3((unsigned)((HW / 4 + F3DG_BLOCK) / F3DG_BLOCK), (unsigned)n_frames), dim3(F3DG_BLOCK), 0,
                        (hipStream_t)stream, HW, src_channels, src, dst);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
@@ -259,7 +259,7 @@ extern "C" int f3dg_cycle_inputs(void* stream, int B, int V, int H, int W, const
     if (B == 0) return F3DG_OK;
     const size_t HW = (size_t)H * W;
     if ((HW & 3u) || ((uintptr_t)raster & 15u) || ((uintptr_t)xin & 15u) || ((uintptr_t)depth & 15u)) return F3DG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(cycle_inputs_kernel, dim3((unsigned)((HW / 4 + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)(B * V)), dim3(F3DG_BLOCK), 0,
+    F3DG_KLAUNCH(cycle_inputs_kernel, dim3((unsigned)((HW / 4 + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)(B * V)), dim3(F3DG_BLOCK), 0,
                        (hipStream_t)stream, HW, B, V, raster, xin, depth);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

@@ -248,7 +248,13 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
  * "render_queue" (default 1): two-phase compositing loop (cheap test for 64 entries, then per-pixel queues of the passing
  * ones); also bit-identical. "sort_wide_groups" (default 0): forces the 32-bit (view, tile) stream of the binning stage, which
  * is otherwise only used when views << tile_bits exceeds 16 bits (tests).
- * "render_kernel" (default 2): 2 = Gaussians across the lanes + conservative ellipse (render2), 1 = the round-1 pixel-lane kernel.
+ * "render_kernel" (default 3): 3 = render3, one wave64 per 8x8 pixel quadrant with no workgroup barriers: the wave scans the tile's
+ * list, keeps the entries whose quadrant bit is set (instance generation leaves a 4-bit quadrant mask above the 28-bit Gaussian id of
+ * every list entry, from the box of the conservative alpha >= 1/255 ellipse), stages 64 records per window by global_load_lds, tests
+ * them with the Gaussians across the lanes and blends with the pixels across the lanes; 2 = render2, four coupled waves per tile
+ * with per-4x4-block lists; 1 = the round-1 pixel-lane kernel (its plain variant is the transcription-order baseline of the tests).
+ * "render_dma" (default 1): render3 stages records by global_load_lds_dwordx4 (1) or through registers (0); "render_lds_pad"
+ * (default 0): extra dynamic LDS bytes per render3 workgroup (occupancy experiments).
  * "render_round" (default 192): list entries a workgroup of render2 stages per round (192 at 7 waves/SIMD or 256 at 6).
  * "render_fast" (default 1): arithmetic of the compositing forward: 0 = the reference's float32 / float64 operation order,
  * 1 = error-free float32 pairs for the float64 island and FMA-contracted accumulations downstream of alpha, in inference calls (no
@@ -261,6 +267,10 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
  * f3dg_integrate always uses the reference's lists.
  * Returns F3DG_ERR_BAD_ARG for unknown names. */
 int f3dg_set_option(const char* name, int value);
+
+/* Diagnostic: number of kernels this library has launched from this process since the last reset (host-side counter, every
+ * launch site counts; memsets / copies do not). bench.py reports launches per call from it. */
+long long f3dg_debug_launch_count(int reset);
 
 /* Optional per-stage timing of the forward path with HIP events recorded on the caller's stream (this is what
  * bench.py uses for the live roofline figure). f3dg_profile_enable(1) makes every following

@@ -9,6 +9,9 @@ import torch
 
 SH_C0 = 0.28209479177387814
 SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+         -0.5900435899266435)
 
 
 def view2gaussian64(means, scales, rots, view):
@@ -37,7 +40,15 @@ def colour64(means, shs, campos, deg):
     if deg > 0:
         x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
         res = res - SH_C1 * y * shs[:, 1] + SH_C1 * z * shs[:, 2] - SH_C1 * x * shs[:, 3]
-    assert deg <= 1, "truth implemented for the degrees F3D-Gaus uses"
+    if deg > 1:       # real spherical harmonics of degree 2 and 3 in the 3DGS basis (forward.cu:40-66)
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = res + SH_C2[0] * xy * shs[:, 4] + SH_C2[1] * yz * shs[:, 5] + SH_C2[2] * (2 * zz - xx - yy) * shs[:, 6] \
+            + SH_C2[3] * xz * shs[:, 7] + SH_C2[4] * (xx - yy) * shs[:, 8]
+        if deg > 2:
+            res = res + SH_C3[0] * y * (3 * xx - yy) * shs[:, 9] + SH_C3[1] * xy * z * shs[:, 10] \
+                + SH_C3[2] * y * (4 * zz - xx - yy) * shs[:, 11] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * shs[:, 12] \
+                + SH_C3[4] * x * (4 * zz - xx - yy) * shs[:, 13] + SH_C3[5] * z * (xx - yy) * shs[:, 14] \
+                + SH_C3[6] * x * (xx - 3 * yy) * shs[:, 15]
     return torch.clamp_min(res + 0.5, 0.0)
 
 

@@ -210,3 +210,61 @@ def test_c3_cycle_aggregation_batch_8_at_256(gpu_device):
     assert merged["xyz"].shape == (B, 589824, 3)
     orbit = f3d.cycle.render_orbit(merged, cfg, rig=rig, num_views=4, views_per_call=4)
     assert orbit["render"].shape == (B, 4, 3, res, res) and bool(torch.isfinite(orbit["render"]).all())
+
+
+def test_c3_batch_64_cycle_views_in_one_sets_call(gpu_device):
+    """BASELINE C3's cycle render at its full batch: B = 64 images x 65,536 Gaussians x 8 views @256x256 as ONE f3dg_forward_sets
+    call of 512 views = 131,072 (view, tile) groups, which does not fit the 16-bit group stream: the natural u32 path of the
+    binning stage. An inference call keeps no auxiliary planes, so the list properties are evaluated against the depth of every
+    (view, Gaussian) recomputed here in the kernel's float32 operation order; two views go through the oracle at full size."""
+    B, Pset, res, Vs = 64, 65536, 256, 8
+    V, T = B * Vs, (res // 16) ** 2
+    sets = [synthetic.make_gaussians(Pset, s0=0.01, seed=100 + b, device=gpu_device) for b in range(B)]
+    g = {k: torch.cat([s[k] for s in sets], 0).contiguous() for k in sets[0]}
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
+    cams = synthetic.orbit_cameras(Vs, resolution=res, device=gpu_device)
+    vm, pm, cp = (cams[k].repeat(B, *([1] * (cams[k].ndim - 1))) for k in ("viewmatrix", "projmatrix", "campos"))
+    out, radii, ws = f3d.rasterize_views(
+        g["xyz"], g["opacity"], vm, pm, cp, torch.zeros(3, device=gpu_device), image_height=res, image_width=res,
+        tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"], rotations=g["rotation"], sh_degree=1,
+        n_sets=B)
+    assert out.shape == (V, 9, res, res) and radii.shape == (V, Pset)
+    assert (V - 1) << 8 | 255 > 0xFFFF            # (view << tile_bits | tile) needs more than 16 bits
+    R, cap = ws.num_rendered, ws.max_rendered
+    pl = torch.zeros(cap, dtype=torch.int32, device=gpu_device)
+    ranges = torch.zeros(V * T * 2, dtype=torch.int32, device=gpu_device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = _lib.lib().f3dg_debug_export(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(ws.buffer), Pset, res, res, V, cap,
+                                      None, None, None, None, None, None, None, p(pl), p(ranges), None, None, None)
+    assert rc == 0
+    pl = pl[:R].long()
+    rg = ranges.view(V * T, 2).long()
+    counts = rg[:, 1] - rg[:, 0]
+    nz = counts > 0
+    assert int(counts.sum()) == R and bool((counts >= 0).all()) and R > 2 * Pset * V
+    assert torch.equal(rg[nz, 0], (torch.cumsum(counts, 0) - counts)[nz]), "ranges do not partition the list in (view, tile) order"
+    assert int(pl.min()) >= 0 and int(pl.max()) < Pset
+    # depth of every (view, Gaussian) of its own set in the kernel's order: ((m2 x + m6 y) + m10 z) + m14 (auxiliary.h:86-94)
+    seg_of = torch.repeat_interleave(torch.arange(V * T, device=gpu_device), counts)
+    view_of = seg_of // T
+    xyz = g["xyz"].view(B, Pset, 3)[view_of // Vs, pl]
+    m = vm.reshape(V, 16)[view_of]
+    depth = ((m[:, 2] * xyz[:, 0] + m[:, 6] * xyz[:, 1]) + m[:, 10] * xyz[:, 2]) + m[:, 14]
+    key = (seg_of << 32) | depth.view(torch.int32).long()           # depths are positive: their bit patterns order like the values
+    d = key[1:] - key[:-1]
+    assert bool((d >= 0).all()), "list not sorted by (view, tile, depth)"
+    assert bool(((pl[1:] - pl[:-1])[d == 0] > 0).all()), "equal keys not in ascending Gaussian order"
+    # every visible Gaussian is in the list of the tile that holds its projected centre... at least: radii > 0 <=> instantiated somewhere
+    inst = torch.zeros(V * Pset, dtype=torch.bool, device=gpu_device)
+    inst[view_of * Pset + pl] = True
+    assert bool((inst.view(V, Pset) <= (radii > 0)).all())
+    assert bool(torch.isfinite(out).all()) and float(out[:, 7].min()) >= 0 and float(out[:, 7].max()) <= 1 + 1e-5
+    # the same view rendered alone (one set, one camera) is bit-identical; two views against the oracle
+    for v in (5, 8 * 37 + 2):
+        b, c = divmod(v, Vs)
+        single, _, _ = _render(sets[b], cams, torch.cat([sets[b]["features_dc"], sets[b]["features_rest"]], 1).contiguous(), res,
+                               slice(c, c + 1), gpu_device, save_aux=False)
+        assert torch.equal(single[0], out[v]), v
+        o = run_oracle(_oracle_scene(sets[b], cams, torch.cat([sets[b]["features_dc"], sets[b]["features_rest"]], 1), res, c))
+        assert np.array_equal(radii[v].cpu().numpy(), o["radii"])
+        assert_render_parity(out[v].cpu().numpy(), o["out_color"], f"C3 set {b} camera {c}")

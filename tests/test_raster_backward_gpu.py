@@ -43,6 +43,8 @@ CASES = {
     "B2_oblique_aniso_random": (dict(P=5000, res=(128, 128), s0=0.02, view="oblique", aniso=True, behind_fraction=0.05, bg=(0.3, 0.1, 0.6)), "random"),
     "B3_filter_scalemod_random": (dict(P=3000, res=(96, 96), s0=0.05, view="oblique", kernel_size=0.1, scale_modifier=0.5), "random"),
     "B4_colors_precomp": (dict(P=2500, res=(100, 72), s0=0.05, view="oblique", colors_precomp=True), "random"),
+    "B5_sh_degree2": (dict(P=2500, res=(80, 64), s0=0.05, view="oblique", sh_degree=2, bg=(0.2, 0.4, 0.1)), "random"),      # M = 9  (backward.cu:62-104)
+    "B6_sh_degree3": (dict(P=2500, res=(64, 80), s0=0.05, view="oblique", sh_degree=3), "random"),                          # M = 16 (backward.cu:106-138)
 }
 
 
@@ -74,6 +76,8 @@ def test_backward_vs_oracle(name, gpu_device):
         assert _rel(gh["dL_dsh"], go["dL_dsh"]) <= 1e-5
     # per-Gaussian stage: no worse than the oracle against the fp64 truth
     truth = per_gaussian_truth(scene, 0, o["radii"], go["dL_dview2gaussian"], go["dL_dcolor"])
+    if scene["shs"] is not None:        # dL/dsh is linear in dL/dcolour: well conditioned, checked against the float64 chain rule too
+        assert _rel(gh["dL_dsh"], truth["dL_dsh"]) <= 1e-5, name
     # floor = the reference's own run-to-run spread for that gradient (3e-4 / 2e-2 / 0.4 of the maximum)
     for hk, ok, floor in (("dL_dmeans3D", "dL_dmean3D", 3e-4), ("dL_drotations", "dL_drot", 2e-2), ("dL_dscales", "dL_dscale", 0.4)):
         e_h, e_o = _rel(gh[hk], truth[ok]), _rel(go[ok], truth[ok])

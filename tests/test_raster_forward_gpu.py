@@ -36,6 +36,8 @@ SCENES = {
     "F12_depth_spread": dict(P=800, res=(64, 64), s0=0.3, view="canonical", depth_range=(1.0, 30.0)),   # distortion values > 1e-4: rel 1e-3 applies
     "F10_huge_tile_lists": dict(P=50000, res=(32, 32), s0=0.05, view="canonical"),     # 4 tiles with lists > 16320 entries
     "F13_single_tile": dict(P=300, res=(16, 12), s0=0.05, view="canonical"),          # one tile: no tile pass at all
+    "F14_sh_degree2": dict(P=3000, res=(96, 64), s0=0.05, view="oblique", sh_degree=2),    # M = 9  (forward.cu:40-51)
+    "F15_sh_degree3": dict(P=3000, res=(64, 96), s0=0.05, view="oblique", sh_degree=3),    # M = 16 (forward.cu:53-66)
 }
 
 
@@ -109,6 +111,53 @@ def test_forward_batched_views_equal_single_views(gpu_device, kw):
         assert_render_parity(h["out_color"][v], o["out_color"], f"view{v}")
         total += R
     assert total == h["num_rendered"]
+
+
+@pytest.mark.parametrize("which", ["cov3D+view2gaussian", "view2gaussian"])
+def test_precomputed_covariance_and_view2gaussian(which, gpu_device):
+    """cov3D_precomp replaces scales / rotations in the 2D footprint (forward.cu:338-348), view2gaussian_precomp replaces the
+    computed view2gaussian in the compositing stage (forward.cu:396-403); a caller that precomputes the library's own values gets the
+    scale/rotation render back, and both paths match the oracle called the same way."""
+    import f3dgaus_amd as f3d
+    scene = make_scene(P=3000, res=(96, 80), s0=0.05, view="oblique", bg=(0.1, 0.3, 0.2))
+    base = run_oracle(scene)
+    cov3D, v2g = base["cov3D"], base["view2gaussian"]
+    npy = lambda t: t.detach().cpu().numpy()
+    kw = dict(means3D=npy(scene["means3D"]), opacities=npy(scene["opacities"]), viewmatrix=npy(scene["viewmatrix"][0]),
+              projmatrix=npy(scene["projmatrix"][0]), campos=npy(scene["campos"][0]), tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"],
+              W=scene["W"], H=scene["H"], bg=npy(scene["bg"]), shs=npy(scene["shs"]), sh_degree=1, view2gaussian_precomp=v2g)
+    from oracle import gof
+    o = gof.Oracle()
+    if which == "view2gaussian":
+        out_o, radii_o, R_o = o.forward(scales=npy(scene["scales"]), rotations=npy(scene["rotations"]), **kw)
+    else:
+        out_o, radii_o, R_o = o.forward(cov3D_precomp=cov3D, **kw)
+    dev = lambda t: None if t is None else t.to(gpu_device)
+    pre = dict(view2gaussian_precomp=torch.from_numpy(v2g).to(gpu_device).unsqueeze(0))
+    if which == "view2gaussian":
+        pre.update(scales=dev(scene["scales"]), rotations=dev(scene["rotations"]))
+    else:
+        pre.update(cov3Ds_precomp=torch.from_numpy(cov3D).to(gpu_device))
+    out, radii, ws = f3d.rasterize_views(
+        dev(scene["means3D"]), dev(scene["opacities"]), dev(scene["viewmatrix"]), dev(scene["projmatrix"]), dev(scene["campos"]),
+        dev(scene["bg"]), image_height=scene["H"], image_width=scene["W"], tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"],
+        sh=dev(scene["shs"]), sh_degree=1, save_aux=True, **pre)
+    assert np.array_equal(radii[0].cpu().numpy(), radii_o) and np.array_equal(radii_o, base["radii"])
+    assert_render_parity(out[0].cpu().numpy(), out_o, which)
+    assert_render_parity(out[0].cpu().numpy(), base["out_color"], which + " vs scale/rotation render")
+
+
+def test_c2_view_with_large_splats_full_size(gpu_device):
+    """SURVEY 8d's second sweep: one full-size C2 view at sigma0 = 0.05 (R / P ~ 14, tile lists of ~10 k entries: the
+    compositing-heavy, numerically benign regime), in both arithmetic modes (this module's fixture)."""
+    scene = make_scene(P=196608, res=(256, 256), s0=0.05, view="oblique")
+    h = run_hip(scene, gpu_device)
+    o = run_oracle(scene)
+    assert h["num_rendered"] == o["num_rendered"] and h["num_rendered"] > 8 * 196608
+    assert np.array_equal(h["point_list"], o["point_list"])
+    assert np.array_equal(h["ranges"][0], o["ranges"])
+    assert_render_parity(h["out_color"][0], o["out_color"], "C2 sigma0=0.05")
+    assert (h["n_contrib"][0] == o["n_contrib"]).mean() >= 0.999
 
 
 def test_wide_group_stream_is_identical(gpu_device):
