@@ -16,14 +16,14 @@ thread_local char g_last_error[512] = "";
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-__global__ void init_header_kernel(F3dgHeader* hdr, unsigned capacity, unsigned alpha_fast = 0)
+__global__ void init_header_kernel(F3dgHeader* hdr, unsigned capacity, unsigned alpha_fast = 0, unsigned save_aux = 0)
 {
     if (threadIdx.x < 64) {
         unsigned* w = reinterpret_cast<unsigned*>(hdr);
         w[threadIdx.x] = 0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { hdr->capacity = capacity; hdr->alpha_fast = alpha_fast; }
+    if (threadIdx.x == 0) { hdr->capacity = capacity; hdr->alpha_fast = alpha_fast; hdr->save_aux = save_aux; }
 }
 
 __global__ void fill_background_kernel(int V, size_t HW, const float* __restrict__ bg, int bg_per_view,
@@ -313,8 +313,11 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     const size_t HW = (size_t)W * H;
 
     const int save_aux = (flags & F3DG_FLAG_SAVE_AUX) ? 1 : 0;
+    // several Gaussian sets in one call are an inference path: f3dg_backward and the per-Gaussian backward index the Gaussian inputs
+    // without a set offset, and view2gaussian_precomp is [n_views, P, 10] of ONE set
+    if (n_sets > 1 && (save_aux || view2gaussian_precomp != nullptr)) return F3DG_ERR_BAD_ARG;
     F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered,
-                       (unsigned)f3dg_render_uses_fast(save_aux));
+                       (unsigned)f3dg_render_uses_fast(save_aux), (unsigned)save_aux);
 
     if (P == 0) {
         F3DG_KLAUNCH(fill_background_kernel, dim3(1024), dim3(256), 0, s, n_views, HW, background,
@@ -505,9 +508,17 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
                                  float* final_T /*[V*4*HW]*/, unsigned* n_contrib /*[V*2*HW]*/, float* depths /*[V*P]*/)
 {
     hipStream_t s = (hipStream_t)stream;
+    if (!workspace) return F3DG_ERR_BAD_ARG;
     const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
     const char* ws = static_cast<const char*>(workspace);
     const size_t VP = (size_t)n_views * P, HW = (size_t)W * H;
+    if (means2D || conic || tiles || offsets || clamped || keys_sorted || final_T || n_contrib || depths) {
+        // these planes are written by a SAVE_AUX forward only (the keys are rebuilt from `depths`): refuse to hand out stale memory
+        F3dgHeader h;
+        F3DG_HIP_CHECK(hipMemcpyAsync(&h, ws + L.header, sizeof h, hipMemcpyDeviceToHost, s));
+        F3DG_HIP_CHECK(hipStreamSynchronize(s));
+        if (!h.save_aux) return F3DG_ERR_BAD_ARG;
+    }
     const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
     const size_t C = (size_t)max_rendered;
     if (keys_sorted && P > 0) {      // the 64-bit keys are not kept by the forward: rebuild them from the final list

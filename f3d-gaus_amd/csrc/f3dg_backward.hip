@@ -164,6 +164,7 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
     __shared__ float2 staged_xy[F3DG_BLOCK];
     __shared__ unsigned staged_id[F3DG_BLOCK];
 
+    const bool alpha_fast = hdr->alpha_fast != 0;     // the arithmetic the forward of this workspace used for alpha: repeated to the bit
     const size_t vP = (size_t)view * P;
     const float* fT = final_T + (size_t)view * 4 * HW;
     const unsigned* nc = n_contrib + (size_t)view * 2 * HW;
@@ -234,13 +235,29 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
             const float CC = q2.y;
             float t = 0, G = 0, alpha = 0;
             if (active) {
-                const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
-                t = (float)(-0.5 * q);
-                if (t <= F3DG_NEAR_PLANE) active = false;
-                const double min_value = -q * (BB / 4.) + CC;
-                float power = (float)(-0.5f * min_value);
-                if (power > 0.0f) power = 0.0f;
-                G = expf(power);
+                if (alpha_fast) {
+                    // blend_entry_fast of f3dg_render.hip, operation for operation (the forward of this workspace used it)
+                    const float r = __builtin_amdgcn_rcpf(aaf);
+                    const float t0 = -bhalf * r;
+                    t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+                    if (t < 0.2f) active = false;
+                    const float p = bhalf * bhalf;
+                    const float e = fmaf(bhalf, bhalf, -p);
+                    const float q1 = p * r;
+                    const float q2_ = (fmaf(-q1, aaf, p) + e) * r;
+                    const float min_value = (CC - q1) - q2_;
+                    float power = -0.5f * min_value;
+                    if (power > 0.0f) power = 0.0f;
+                    G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                } else {
+                    const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
+                    t = (float)(-0.5 * q);
+                    if (t <= F3DG_NEAR_PLANE) active = false;
+                    const double min_value = -q * (BB / 4.) + CC;
+                    float power = (float)(-0.5f * min_value);
+                    if (power > 0.0f) power = 0.0f;
+                    G = expf(power);
+                }
                 alpha = fminf(0.99f, q2.z * G);
                 if (alpha < 1.0f / 255.0f) active = false;
             }

@@ -54,7 +54,7 @@ struct F3dgHeader {
     unsigned int reserved1[3];
     unsigned int alpha_fast;      // arithmetic the compositing forward of this call used for alpha (1: error-free float32 pairs): the
                                   // backward must repeat it to the bit
-    unsigned int reserved0;
+    unsigned int save_aux;        // 1 when the forward of this workspace ran with F3DG_FLAG_SAVE_AUX (the auxiliary planes are valid)
     unsigned long long bwd_pairs; // contributing (pixel, Gaussian) pairs of the last f3dg_backward on this workspace ("C" of SURVEY 8d)
     unsigned int reserved[54];
 };

@@ -1,44 +1,43 @@
 // f3dg_render.hip -- per-tile front-to-back GOF compositing (the roofline kernel of the path).
 //
-// Replaces renderCUDA<3> (reference RAST/cuda_rasterizer/forward.cu:409-612): for every pixel of a 16x16 tile,
-// walk the tile's depth-sorted Gaussian list, intersect the pixel ray with each Gaussian's quadric
-// (view2gaussian: Sigma', B, C), turn the minimum of the quadric along the ray into an alpha, and blend RGB,
-// view-space normal, median depth, alpha and the 2DGS-style distortion term front to back.
+// Replaces renderCUDA<3> (reference RAST/cuda_rasterizer/forward.cu:409-612): for every pixel of a 16x16 tile, walk the tile's
+// depth-sorted Gaussian list, intersect the pixel ray with each Gaussian's quadric (view2gaussian: Sigma', B, C), turn the minimum
+// of the quadric along the ray into an alpha, and blend RGB, view-space normal, median depth, alpha and the 2DGS-style distortion
+// term front to back. All views of a call are ONE launch; an XCD-aware id -> (view, tile) map keeps a view's records in one L2.
 //
-// MI355X shape: one 256-thread workgroup (4 wave64, each a 16x4 pixel strip) per (view, tile); ALL views of a
-// call are one launch. The tile's list is staged through LDS 256 Gaussians per round as whole 64-byte records
-// (one float4 x4 coalesced-by-record gather per thread), and every lane then reads the SAME record per step
-// (LDS broadcast, 4 ds_read_b128 per Gaussian per wave). The blend itself is a strict per-pixel recurrence in
-// float32/float64 whose operation order is the reference's (built with -ffp-contract=off): the exponent
-// -(1/2)(C - B^2/4A) cancels 1e5..1e6 x and any re-association moves isolated pixels by 1e-2.
+// The blend is a strict per-pixel recurrence whose float32 / float64 operation order is the reference's (blend_entry; the file is
+// built with -ffp-contract=off): the exponent -(1/2)(C - B^2/4A) cancels 1e5..1e6 x and any re-association moves isolated pixels by
+// 1e-2. blend_entry_fast is the inference-mode variant: the same float32 a, b in the reference's order, the float64
+// island replaced by error-free float32 pairs. There is no inter-pixel arithmetic, hence no MFMA.
 //
-// Only `done`-voting and staging are cooperative; there is no inter-pixel arithmetic, hence no MFMA.
-//
-// ALU diet that does not change results (the kernel is VALU-bound, ~200 pixel tests per 72-byte instance):
-//  * conservative pre-test. Only ~5 % of (pixel, Gaussian) tests end in a blend; the rest leave through
-//    `alpha < 1/255` (or `t <= 0.2`), both of which are a bare `continue`. A float32 estimate of the exponent,
-//    With b = BB/2 and a = AA (the reference's own float32 values, computed in its order) the exponent is
-//    p = -(C - b^2/a)/2, and alpha < 1/255 is certain when p < thr = log(1/(255*opacity)) - 1e-4, i.e. when
-//    b^2 < K0*a with K0 = C + 2 thr. The record carries K = K0*(1 - 5e-7) (>= 0), which absorbs the two float32
-//    product roundings of the test  fl(b*b) < fl(K*a)  -- three VALU instructions -- so a true test PROVES
-//    alpha < 1/255 and the pair is skipped before any float64 instruction, expf or divide. NaN falls through to the
-//    exact path. The tests run
-//    every scene with the pre-test on and off and require bit-identical outputs.
-//  * per-group culling. A tile's list holds every Gaussian whose 3-sigma SQUARE touches the 16x16 tile, but a 16-lane
-//    group owns a 4x4 pixel block and only ~1/5 of the (block, Gaussian) pairs contain a pixel with alpha >= 1/255. The staging
-//    thread therefore also fetches the Gaussian's conservative alpha >= 1/255 box (f3dg_preprocess.hip) and publishes
-//    a 16-bit block mask; each wave compacts the 256 staged entries into FOUR index lists (one per 16-lane group) with
-//    ballots, and every group walks only its own (per-lane LDS addresses; a broadcast inside the group). Skipped entries would have been a bare `continue` for all 64 lanes, and `contributor` is set from the
-//    entry's position, so every output and auxiliary plane is bit-identical (asserted with the option on and off).
-//  * per-lane work queues. After the two filters above the expensive exact path still ran with ~1/4 of the lanes
-//    active, because a wave executes it whenever ANY of its 64 pixels passes. The loop is therefore split in two
-//    phases per window of 64 (compacted) entries: phase 1 runs only the cheap pre-test for all 64 entries with all
-//    lanes busy and leaves a 64-bit pass mask per pixel; phase 2 lets every pixel walk ITS OWN set bits in ascending
-//    order (per-lane LDS addresses, hence the SoA staging arrays), so the wave executes max-over-lanes(#passes)
-//    exact iterations instead of #(entries with any pass) -- about half as many, at twice the lane utilisation.
-//    Per pixel the sequence of blended Gaussians and every arithmetic operation on them is unchanged.
-//  * t = -BB/(2*AA) is a double quotient of float-valued operands rounded to float: identical to ONE IEEE float32
-//    divide (double rounding is innocuous for p = 24, q = 53 >= 2p + 2), so the float64 divide is not needed.
+// Three generations of the kernel live here; all of them only ever REMOVE (pixel, Gaussian) pairs that are a bare `continue` in the
+// reference (alpha < 1/255 proven by a conservative test), so their images are bit-identical within an arithmetic mode:
+//   render3_fwd_kernel (default, option render_kernel = 3): one wave64 per 8x8 pixel quadrant, no workgroup barriers. The wave
+//       scans the tile list for the entries whose quadrant bit is set (F3DG_ID_BITS), stages 64 records per window by
+//       global_load_lds, tests entries against the quadrant's pixels with the Gaussians across the lanes (ballots delivered by
+//       v_writelane) and blends with the pixels across the lanes. See the comment above the kernel.
+//   render2_fwd_kernel (render_kernel = 2): one 256-thread workgroup per tile, four coupled waves (an 8x8 quadrant each), 192 or
+//       256 entries staged per round with two barriers, per-4x4-block compacted lists, phase 1 across the lanes.
+//   render_fwd_kernel (render_kernel = 1): the round-1 pixel-lane kernel. Its plain variant (no pre-test, no culling, no queues) is
+//       the transcription-order baseline every other variant is compared with bit for bit
+//       (tests/test_raster_forward_gpu.py::test_pretest_is_conservative_bit_identical_outputs). Its filters:
+//  * conservative pre-test. Only ~5 % of (pixel, Gaussian) tests end in a blend; the rest leave through `alpha < 1/255` (or
+//    `t <= 0.2`), both of which are a bare `continue`. With b = BB/2 and a = AA (the reference's own float32 values, computed in
+//    its order) the exponent is p = -(C - b^2/a)/2, and alpha < 1/255 is certain when p < thr = log(1/(255*opacity)) - 1e-4, i.e.
+//    when b^2 < K0*a with K0 = C + 2 thr. The record carries K = K0*(1 - 5e-7) (>= 0), which absorbs the two float32 product
+//    roundings of the test  fl(b*b) < fl(K*a)  -- three VALU instructions -- so a true test PROVES alpha < 1/255 and the pair is
+//    skipped before any float64 instruction, expf or divide. NaN falls through to the exact path.
+//  * per-group culling. A tile's list holds every Gaussian whose 3-sigma SQUARE touches the 16x16 tile, but a 16-lane group owns a
+//    4x4 pixel block and only ~1/5 of the (block, Gaussian) pairs contain a pixel with alpha >= 1/255. The staging thread fetches
+//    the Gaussian's conservative alpha >= 1/255 box (f3dg_preprocess.hip) and publishes a 16-bit block mask; each wave compacts the
+//    staged entries into FOUR index lists (one per 16-lane group) with ballots, and every group walks only its own. `contributor`
+//    is set from the entry's position, so every output and auxiliary plane is unchanged.
+//  * per-lane work queues. The loop is split in two phases per window of 64 (compacted) entries: phase 1 runs only the cheap
+//    pre-test for all 64 entries with all lanes busy and leaves a 64-bit pass mask per pixel; phase 2 lets every pixel walk ITS
+//    OWN set bits in ascending order, so the wave executes max-over-lanes(#passes) exact iterations instead of #(entries with any
+//    pass). Per pixel the sequence of blended Gaussians and every arithmetic operation on them is unchanged.
+//  * t = -BB/(2*AA) is a double quotient of float-valued operands rounded to float: identical to ONE IEEE float32 divide (double
+//    rounding is innocuous for p = 24, q = 53 >= 2p + 2), so the float64 divide is not needed.
 #include "f3dg_common.h"
 #include "f3dg_ellipse.h"
 

@@ -82,7 +82,28 @@ class Workspace:
         return True
 
 
-_WS_CACHE = {}      # (device index, stream) -> Workspace reused by no-grad single-view calls on that stream
+class _StreamCache(dict):
+    """Per-(device, stream) cache that keeps the most recently used entries only: transient streams do not pin their workspaces."""
+
+    def __init__(self, limit=8):
+        super().__init__()
+        self.limit = limit
+
+    def get(self, key, default=None):
+        if key in self:
+            self[key] = super().pop(key)      # move to the end: most recently used
+            return super().get(key)
+        return default
+
+    def __setitem__(self, key, value):
+        if key in self:
+            super().pop(key)
+        super().__setitem__(key, value)
+        while len(self) > self.limit:
+            super().pop(next(iter(self)))
+
+
+_WS_CACHE = _StreamCache()      # (device index, stream) -> Workspace reused by no-grad single-view calls on that stream
 _CAP_HINT = {}      # (P, W, H, n_views) -> instances/capacity that worked last time
 
 
@@ -292,7 +313,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         return grads
 
 
-_INTEG_WS = {}      # (device index, stream) -> (key, capacity, buffer) reused by integrate calls on that stream
+_INTEG_WS = _StreamCache()      # (device index, stream) -> (key, capacity, buffer) reused by integrate calls on that stream
 
 
 def integrate_gaussians_to_points(points3D, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -22,13 +22,21 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return importlib.util.spec_from_loader(fullname, self)
 
     def create_module(self, spec):
-        return importlib.import_module(_REAL + spec.name[len(_ALIAS):])      # the real module object, imported once
+        module = importlib.import_module(_REAL + spec.name[len(_ALIAS):])    # the real module object, imported once
+        self._real_spec = getattr(self, "_real_spec", {})
+        self._real_spec[id(module)] = module.__spec__
+        return module
 
     def exec_module(self, module):
-        pass
+        # importlib has just replaced module.__spec__ by the alias spec (its __package__ is still the real name): put the real one
+        # back, or relative imports inside the module warn "__package__ != __spec__.parent" and importlib.reload breaks
+        real = getattr(self, "_real_spec", {}).pop(id(module), None)
+        if real is not None:
+            module.__spec__ = real
 
 
-sys.meta_path.insert(0, _AliasFinder())
+if not any(isinstance(f, _AliasFinder) or type(f).__name__ == "_AliasFinder" for f in sys.meta_path):
+    sys.meta_path.insert(0, _AliasFinder())
 _pkg = importlib.import_module(_REAL)
 for _name, _mod in list(sys.modules.items()):
     if _name.startswith(_REAL + "."):

@@ -100,7 +100,9 @@ int f3dg_forward_batched(void* stream, void* workspace, size_t workspace_bytes, 
  * aggregation loop (reference visualize.py:293-314 renders 8 views of each of B images with B x 8 separate rasterizer calls):
  * means3D ... rotations are [n_sets, P, ...], the cameras [n_sets * views_per_set, ...] (set-major), out_color
  * [n_sets * views_per_set, 9, H, W], radii [n_sets * views_per_set, P]; view i renders set i / views_per_set.
- * f3dg_forward_batched is the n_sets = 1 case. Workspace: f3dg_workspace_bytes(P, W, H, n_sets * views_per_set, max_rendered). */
+ * f3dg_forward_batched is the n_sets = 1 case. Workspace: f3dg_workspace_bytes(P, W, H, n_sets * views_per_set, max_rendered).
+ * n_sets > 1 is an inference path: with F3DG_FLAG_SAVE_AUX or view2gaussian_precomp it returns F3DG_ERR_BAD_ARG (f3dg_backward
+ * indexes the Gaussian inputs of ONE set). */
 int f3dg_forward_sets(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
                       int n_sets, int views_per_set, int P, int D, int M,
                       const float* background, int W, int H,
@@ -243,10 +245,11 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
 
 /* Runtime switches (process-wide). Known names: "render_pretest" (default 1): the compositing kernel first runs a
  * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;
- * results are bit-identical with it on or off (asserted by the tests). "render_cull" (default 1): every 16x4 pixel strip
- * of a tile walks only the staged Gaussians whose conservative alpha >= 1/255 box touches it; also bit-identical.
+ * results are bit-identical with it on or off (asserted by the tests). "render_cull" (default 1): every 16-lane group (a 4x4
+ * pixel block) of the pixel-lane kernel walks only the staged Gaussians whose conservative alpha >= 1/255 box touches its block, and
+ * the compositing backward walks per-quadrant culled lists (0: its lock-step variant); also bit-identical.
  * "render_queue" (default 1): two-phase compositing loop (cheap test for 64 entries, then per-pixel queues of the passing
- * ones); also bit-identical. "sort_wide_groups" (default 0): forces the 32-bit (view, tile) stream of the binning stage, which
+ * ones); also bit-identical. These three act on render_kernel = 1 (and the backward); render2 / render3 always filter. "sort_wide_groups" (default 0): forces the 32-bit (view, tile) stream of the binning stage, which
  * is otherwise only used when views << tile_bits exceeds 16 bits (tests).
  * "render_kernel" (default 3): 3 = render3, one wave64 per 8x8 pixel quadrant with no workgroup barriers: the wave scans the tile's
  * list, keeps the entries whose quadrant bit is set (instance generation leaves a 4-bit quadrant mask above the 28-bit Gaussian id of
@@ -290,7 +293,9 @@ int f3dg_backward_pairs(void* stream, const void* workspace, long long* h_pairs)
  * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
  *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], culling-ellipse c); depths [V*P], means2D [V*P*2], conic [V*P*4],
  *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped), keys_sorted [cap] u64 (all SAVE_AUX: an inference call does not write them),
- *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX). */
+ *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX).
+ * Asking for a SAVE_AUX-only plane of a workspace whose last forward was an inference call returns F3DG_ERR_BAD_ARG (BLOCKING then:
+ * the header is read back); rec, point_list (Gaussian ids, quadrant masks stripped) and ranges are always available. */
 int f3dg_debug_export(void* stream, const void* workspace, int P, int W, int H, int n_views,
                       long long max_rendered, float* rec, float* means2D, float* conic, unsigned* tiles,
                       unsigned* offsets, unsigned char* clamped, unsigned long long* keys_sorted,

@@ -111,10 +111,12 @@ def _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled):
         n_contrib=torch.zeros(V * 2 * H * W, dtype=torch.int32, device=device),
         depths=torch.zeros(V * max(P, 1), dtype=torch.float32, device=device))
     if P > 0:
+        # an inference call (no SAVE_AUX) keeps the records, the final list and the ranges only: the other planes stay zero here
+        always = ("rec", "point_list", "ranges")
         rc = _lib.lib().f3dg_debug_export(
             C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), P, W, H, V, cap,
-            *[C.c_void_p(e[k].data_ptr()) for k in ("rec", "means2D", "conic", "tiles", "offsets", "clamped", "keys",
-                                                     "point_list", "ranges", "final_T", "n_contrib", "depths")])
+            *[C.c_void_p(e[k].data_ptr()) if (save_aux or k in always) else None
+              for k in ("rec", "means2D", "conic", "tiles", "offsets", "clamped", "keys", "point_list", "ranges", "final_T", "n_contrib", "depths")])
         assert rc == 0
     torch.cuda.synchronize()
     if culled is not None:

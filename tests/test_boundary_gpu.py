@@ -75,7 +75,29 @@ def test_integration_md_C_shim_verbatim(gpu_device):
     n, color, radii, geom, binning, img = shim_C.rasterize_gaussians(*args)
     ref, ref_radii, ws = _batched(d)
     assert n == ws.num_rendered and torch.equal(color, ref[0]) and torch.equal(radii, ref_radii[0])
-    assert geom.dtype == torch.uint8 and binning.numel() == 0 and img.numel() == 0
+    assert geom.dtype == torch.uint8 and binning.numel() == 1 and int(binning[0]) >= n and img.numel() == 0
+    # RAST/diff_gof_rasterization/__init__.py:115-138: the backward half of the shim against the package's own backward
+    assert "def rasterize_gaussians_backward(" in shim_C.SOURCE
+    gen = torch.Generator().manual_seed(4)
+    dpix = torch.randn(9, rs.image_height, rs.image_width, generator=gen).to(gpu_device)
+    bargs = (rs.bg, d["means3D"], radii, empty, d["scales"], d["rotations"], rs.scale_modifier, empty, empty, rs.viewmatrix, rs.projmatrix,
+             rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, dpix, d["shs"], rs.sh_degree, rs.campos, geom, n, binning, img,
+             rs.debug)
+    grads = shim_C.rasterize_gaussians_backward(*bargs)
+    assert len(grads) == 9
+    from f3dgaus_amd.diff_gof_rasterization.backward import rasterize_backward_raw
+    _, ref_radii_aux, ws_aux = _batched(d, save_aux=True)
+    g = rasterize_backward_raw(ws_aux, d["means3D"], d["shs"], None, d["scales"], d["rotations"], ref_radii_aux, dpix[None], rs.sh_degree,
+                               rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.scale_modifier)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    for got, key in zip(grads, ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+                                "dL_drotations", "dL_dview2gaussian")):
+        want = g[key][0] if g[key].shape[0] == 1 and g[key].ndim == got.ndim + 1 else g[key]
+        assert got.shape == want.shape, key
+        if key == "dL_dcov3D":
+            assert not got.any()
+        else:
+            assert rel(got, want) <= (1e-3 if key in ("dL_dmeans3D", "dL_dscales", "dL_drotations") else 1e-5), key    # float atomics order
     with pytest.raises(RuntimeError, match="means3D must have dimensions"):
         shim_C.rasterize_gaussians(args[0], d["means3D"].reshape(-1), *args[2:])
     # RAST/diff_gof_rasterization/__init__.py:269-293

@@ -66,3 +66,15 @@ def test_c2_full_size_properties(gpu_device):
     # a view rendered alone equals the same view rendered inside the batch, bit for bit
     single, _, _ = _render(scene, gpu_device, colors=c1, views=slice(5, 6))
     assert torch.equal(single[0], o1[5])
+    # the DEFAULT inference path (no auxiliary planes: fast arithmetic, tile-culled lists -- what bench.py and the cycle / orbit
+    # renders run) on the same inputs: within 1e-6 of the SAVE_AUX render, same radii, identical batch-vs-single bits
+    oi, ri, wsi = _render(scene, gpu_device, colors=c1, save_aux=False)
+    assert np.array_equal(ri.cpu().numpy(), h["radii"]) and wsi.num_rendered <= R
+    # (isolated pixels may differ by more: an alpha just at 1/255 or a transmittance just at 1e-4 decided the other way)
+    for ch in (slice(0, 6), slice(7, 8)):
+        d = (oi[:, ch] - o1[:, ch]).abs()
+        assert d.max().item() < 1e-4 and (d <= 2e-6).float().mean().item() >= 0.9999, ch
+    # (the median depth is a value ~7: relative; a 1-ulp alpha difference may move the T > 0.5 switch of isolated pixels by a Gaussian)
+    assert ((oi[:, 6] - o1[:, 6]).abs() <= 2e-6 * o1[:, 6].abs()).float().mean().item() >= 0.999
+    si, _, _ = _render(scene, gpu_device, colors=c1, views=slice(5, 6), save_aux=False)
+    assert torch.equal(si[0], oi[5])
