@@ -17,6 +17,7 @@
 // of percent on dL/dscale (SURVEY 0.9 -- the reference's own run-to-run spread), so float64 sums make the result
 // reproducible to rounding where the reference is not.
 #include "f3dg_common.h"
+#include "f3dg_ellipse.h"
 
 namespace {
 
@@ -704,6 +705,333 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
         atomicAdd(&hdr->bwd_pairs, (unsigned long long)n_pairs);
 }
 
+// ---- render3's counterpart: ONE wave64 per 8x8 quadrant, no workgroup barriers (the default) ------------------------------------
+// Same arithmetic per contributing (pixel, Gaussian) pair and the same transposed wave reduction as render_bwd_kernel above. What
+// changes is everything around it, as in the forward (f3dg_render.hip, render3_fwd_kernel):
+//   * a workgroup is one wave that owns a quadrant from its deepest last contributor back to the first list entry; nothing is
+//     shared with the other quadrants of the tile and nothing waits at a barrier;
+//   * the wave scans the tile's list BACKWARDS 64 ids at a time and keeps the entries whose quadrant bit is set (F3DG_ID_BITS);
+//   * a window of 64 kept entries is staged (record by global_load_lds, 2D conic, centre) and tested with the Gaussians across the
+//     lanes against the conservative ellipse (quad_ballots_any): every pixel gets its pass mask and the wave the mask of entries
+//     that can reach ANY of its pixels -- the others are never looked at (the four-wave kernel computes the reference's a, b and
+//     the K pre-test for all 64 pixels of every box-culled entry before it can skip one);
+//   * the surviving entries are walked in lock-step, back to front, because the 17 partials of a Gaussian are reduced across the
+//     wave before they touch memory.
+__global__ void __launch_bounds__(64, F3DG_BWD_OCC)
+render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                   F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                   const float4* __restrict__ cull,
+                   const float2* __restrict__ means2D, const float4* __restrict__ conic,
+                   const float* __restrict__ background, int bg_per_view,
+                   const float* __restrict__ final_T, const unsigned* __restrict__ n_contrib,
+                   const float* __restrict__ dL_dpixels,
+                   float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
+                   double* __restrict__ dL_dv2g_acc)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x;
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+
+    __shared__ float4 sR[4][64];          // records of the window, [16-byte chunk][entry] (global_load_lds image)
+    __shared__ float4 sC[64];             // 2D conic + opacity * coef
+    __shared__ float2 sX[64];             // projected centre
+    __shared__ uint2 sQ[128];             // (list position, Gaussian id) of the kept entries, ring
+
+    const bool alpha_fast = hdr->alpha_fast != 0;
+    const size_t vP = (size_t)view * P;
+    const F3dgRec* vrec = rec + vP;
+    const float4* vcull = cull + vP;
+    const float* fT = final_T + (size_t)view * 4 * HW;
+    const unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+    const float* dpix = dL_dpixels + (size_t)view * F3DG_OUT_CHANNELS * HW;
+    const float* bg = background + (bg_per_view ? 3 * view : 0);
+
+    const float T_final = inside ? fT[pix_id] : 0;
+    float Tr = T_final;
+    const float final_D = inside ? fT[pix_id + HW] : 0;
+    const float final_A = 1 - T_final;
+    const float dL_dreg = inside ? dpix[8 * HW + pix_id] : 0;
+
+    const int last_contributor = inside ? (int)nc[pix_id] : 0;
+    const int max_contributor = inside ? (int)nc[pix_id + HW] : 0;
+    float accum_rec0 = 0, accum_rec1 = 0, accum_rec2 = 0;
+    float dpx0 = 0, dpx1 = 0, dpx2 = 0, dn0 = 0, dn1 = 0, dn2 = 0, dL_dmax_depth = 0;
+    if (inside) {
+        dpx0 = dpix[pix_id]; dpx1 = dpix[HW + pix_id]; dpx2 = dpix[2 * HW + pix_id];
+        dn0 = dpix[3 * HW + pix_id]; dn1 = dpix[4 * HW + pix_id]; dn2 = dpix[5 * HW + pix_id];
+        dL_dmax_depth = dpix[6 * HW + pix_id];
+    }
+    float last_alpha = 0;
+    float last_c0 = 0, last_c1 = 0, last_c2 = 0;
+    float last_n0 = 0, last_n1 = 0, last_n2 = 0;
+    float acc_n0 = 0, acc_n1 = 0, acc_n2 = 0;
+    const float ddelx_dx = (float)(0.5 * W);
+    const float ddely_dy = (float)(0.5 * H);
+    const float bg_dot_dpixel = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;
+
+    // entries at or behind a pixel's last contributor are skipped by the reference one by one (backward.cu:745-746): the wave starts
+    // at the deepest last contributor of ITS 64 pixels
+    const int wave_last = min((int)__builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, last_contributor)),
+                              (int)(range.y - range.x));
+    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned n_pairs = 0;                 // contributing (pixel, Gaussian) pairs of this wave
+
+    unsigned cursor = (unsigned)wave_last, qhead = 0, qcount = 0;     // list positions [0, cursor) are still to be scanned
+    unsigned idn = lane < cursor ? point_list[range.x + cursor - 1u - lane] : 0u;       // back to front: lane l reads position cursor - 1 - l
+    for (;;) {
+        while (qcount < 64u && cursor != 0u) {
+            const unsigned idm = idn;
+            const bool valid = lane < cursor;
+            const unsigned pos = cursor - 1u - lane;
+            cursor = cursor > 64u ? cursor - 64u : 0u;
+            idn = lane < cursor ? point_list[range.x + cursor - 1u - lane] : 0u;
+            const bool keep = valid && (idm & qbit) != 0u;
+            const unsigned long long kb = __ballot(keep);
+            if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & 127u] = make_uint2(pos, idm & F3DG_ID_MASK);
+            qcount += (unsigned)__popcll(kb);
+        }
+        if (qcount == 0u)
+            break;
+        const unsigned m = qcount < 64u ? qcount : 64u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float ec = 0.0f;
+        if (lane < m) {
+            const unsigned id = sQ[(qhead + lane) & 127u].y;
+            const float4* src = reinterpret_cast<const float4*>(vrec + id);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                 (__attribute__((address_space(3))) void*)&sR[c][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(conic + vP + id),
+                                             (__attribute__((address_space(3))) void*)&sC[0], 16, 0, 0);
+            e4 = vcull[id];
+            sX[lane] = means2D[vP + id];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < m) ec = sR[3][lane].w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- phase 1: lane e tests entry e against the 64 pixels of the quadrant
+        int pass_lo = 0, pass_hi = 0;
+        unsigned long long any = 0ull;
+        {
+            const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
+            const float v0 = (float)qy0 - e4.y;
+            float dxx[8], adx[8], dyy[8], cdy[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                dxx[q] = u0 + (float)q;
+                adx[q] = e4.z * dxx[q];
+                dyy[q] = v0 + (float)q;
+                cdy[q] = ec * dyy[q] * dyy[q];
+            }
+            quad_ballots_any<0>(pass_lo, pass_hi, any, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+        }
+        const unsigned long long pass = ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+
+        // ---- lock-step walk over the entries that reach at least one pixel, back to front (window slot order)
+        unsigned long long todo = any;
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint2 pe = sQ[(qhead + (unsigned)j) & 127u];
+            const int contributor = (int)pe.x;                             // 0-based position from the front
+            bool active = inside && ((pass >> j) & 1ull) != 0ull && contributor < last_contributor;
+            if (__ballot(active) == 0)
+                continue;
+
+            const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j];
+            const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+            const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+            const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+            const float aaf = ray_x * n0 + ray_y * n1 + n2;
+            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+
+            const float CC = q2.y;
+            float t = 0, G = 0, alpha = 0;
+            if (active) {
+                if (alpha_fast) {
+                    // blend_entry_fast of f3dg_render.hip, operation for operation (the forward of this workspace used it)
+                    const float r = __builtin_amdgcn_rcpf(aaf);
+                    const float t0 = -bhalf * r;
+                    t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+                    if (t < 0.2f) active = false;
+                    const float p = bhalf * bhalf;
+                    const float e = fmaf(bhalf, bhalf, -p);
+                    const float q1_ = p * r;
+                    const float q2_ = (fmaf(-q1_, aaf, p) + e) * r;
+                    const float min_value = (CC - q1_) - q2_;
+                    float power = -0.5f * min_value;
+                    if (power > 0.0f) power = 0.0f;
+                    G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                    alpha = fminf(0.99f, q2.z * G);
+                } else {
+                    const double AA = aaf;
+                    const double BB = 2 * bhalf;
+                    const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
+                    t = (float)(-0.5 * q);
+                    if (t <= F3DG_NEAR_PLANE) active = false;
+                    const double min_value = -q * (BB / 4.) + CC;
+                    float power = (float)(-0.5f * min_value);
+                    if (power > 0.0f) power = 0.0f;
+                    G = expf(power);
+                    alpha = fminf(0.99f, q2.z * G);
+                }
+                if (alpha < 1.0f / 255.0f) active = false;
+            }
+            {
+                const unsigned long long act = __ballot(active);
+                if (act == 0)
+                    continue;
+                n_pairs += (unsigned)__popcll(act);
+            }
+
+            float g_col0 = 0, g_col1 = 0, g_col2 = 0, g_mx = 0, g_my = 0, g_mz = 0, g_op = 0;
+            float g_v0 = 0, g_v1 = 0, g_v2 = 0, g_v3 = 0, g_v4 = 0, g_v5 = 0, g_v6 = 0, g_v7 = 0, g_v8 = 0, g_v9 = 0;
+            if (active) {
+                // gradient terms only from here (see render_bwd_kernel): float32 with one reciprocal each, FMA contraction allowed
+#pragma clang fp contract(fast)
+                const float4 q3 = sR[3][j];
+                const float4 con = sC[j];
+                const float2 xy = sX[j];
+                const float d_x = (float)(xy.x - (pixf_x - 0.5)), d_y = (float)(xy.y - (pixf_y - 0.5));
+
+                const float inv_t = 1.0f / t;
+                const float mapped_max_t = fmaf(-0.20040080160320642f, inv_t, 1.0020040080160322f);
+                const float dmax_t_dd = 0.20040080160320642f * inv_t * inv_t;
+                const float inv_len = 1.0f / sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7f);
+                const float nn0 = -n0 * inv_len, nn1 = -n1 * inv_len, nn2 = -n2 * inv_len;
+
+                Tr = Tr / (1.f - alpha);
+                const float dchannel_dcolor = alpha * Tr;
+
+                float dL_dalpha = 0.0f;
+                const float c0 = q3.x, c1 = q3.y, c2 = q3.z;
+                accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0; last_c0 = c0;
+                dL_dalpha += (c0 - accum_rec0) * dpx0;
+                g_col0 = dchannel_dcolor * dpx0;
+                accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1; last_c1 = c1;
+                dL_dalpha += (c1 - accum_rec1) * dpx1;
+                g_col1 = dchannel_dcolor * dpx1;
+                accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2; last_c2 = c2;
+                dL_dalpha += (c2 - accum_rec2) * dpx2;
+                g_col2 = dchannel_dcolor * dpx2;
+
+                float dL_dmax_t = 0.0f;
+                dL_dmax_t += 2.0f * (Tr * alpha) * (mapped_max_t * final_A - final_D) * dL_dreg * dmax_t_dd;
+                dL_dalpha += 0.f - 0.f;
+
+                acc_n0 = last_alpha * last_n0 + (1.f - last_alpha) * acc_n0; last_n0 = nn0;
+                dL_dalpha += (nn0 - acc_n0) * dn0;
+                const float dnn0 = alpha * Tr * dn0;
+                acc_n1 = last_alpha * last_n1 + (1.f - last_alpha) * acc_n1; last_n1 = nn1;
+                dL_dalpha += (nn1 - acc_n1) * dn1;
+                const float dnn1 = alpha * Tr * dn1;
+                acc_n2 = last_alpha * last_n2 + (1.f - last_alpha) * acc_n2; last_n2 = nn2;
+                dL_dalpha += (nn2 - acc_n2) * dn2;
+                const float dnn2 = alpha * Tr * dn2;
+
+                float dL_dlength = (dnn0 * n0 + dnn1 * n1 + dnn2 * n2);
+                dL_dlength *= inv_len * inv_len;
+                float dLn0 = (-dnn0 + dL_dlength * n0) * inv_len;
+                float dLn1 = (-dnn1 + dL_dlength * n1) * inv_len;
+                float dLn2 = (-dnn2 + dL_dlength * n2) * inv_len;
+
+                float dL_dt = dL_dmax_t;
+                if (contributor == max_contributor - 1)
+                    dL_dt += dL_dmax_depth;
+
+                dL_dalpha *= Tr;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+                const float dL_dG = con.w * dL_dalpha;
+                const float gdx = G * d_x;
+                const float gdy = G * d_y;
+                const float dG_ddelx = -gdx * con.x - gdy * con.y;
+                const float dG_ddely = -gdy * con.z - gdx * con.y;
+                g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                g_my = dL_dG * dG_ddely * ddely_dy;
+                g_mz = fabsf(dL_dG * dG_ddelx * ddelx_dx) + fabsf(dL_dG * dG_ddely * ddely_dy);
+                g_op = G * dL_dalpha;
+
+                const float dL_dpower = dL_dG * G;
+                const float dL_dmin_value = dL_dpower * -0.5f;
+                const float qf = -2.0f * t, inv_a = 1.0f / aaf;
+                float dL_dA = dL_dmin_value * qf * qf * 0.25f;
+                float dL_dB = dL_dmin_value * (-0.5f * qf);
+                const float dL_dC = dL_dmin_value;
+                dL_dA += dL_dt * (0.5f * qf * inv_a);
+                dL_dB += dL_dt * (-0.5f * inv_a);
+                dLn0 += dL_dA * ray_x;
+                dLn1 += dL_dA * ray_y;
+                dLn2 += dL_dA;
+
+                g_v0 = dLn0 * ray_x;
+                g_v1 = dLn0 * ray_y + dLn1 * ray_x;
+                g_v2 = dLn0 + dLn2 * ray_x;
+                g_v3 = dLn1 * ray_y;
+                g_v4 = dLn1 + dLn2 * ray_y;
+                g_v5 = dLn2;
+                g_v6 = dL_dB * 2 * ray_x;
+                g_v7 = dL_dB * 2 * ray_y;
+                g_v8 = dL_dB * 2;
+                g_v9 = dL_dC;
+            }
+
+            // the 17 partials summed over the wave's 64 pixels (pair32 / pair16, then row-local DPP); lane 15 of row r holds
+            //                     row 0          row 1          row 2          row 3
+            const float f0 = row_total(pair16(pair32(g_col0, g_col1), pair32(g_col2, g_mx)));     // col0   col2   col1   mean2D.x
+            const float f1 = row_total(pair16(pair32(g_my, g_mz), pair32(g_op, 0.0f)));           // m2D.y  opacity m2D.z  -
+            const float d0 = row_total(pair16(pair32(g_v0, g_v1), pair32(g_v2, g_v3)));   // v0 v2 v1 v3
+            const float d1 = row_total(pair16(pair32(g_v4, g_v5), pair32(g_v6, g_v7)));   // v4 v6 v5 v7
+            const float d2 = row_total(pair16(pair32(g_v8, g_v9), 0.0f));                 // v8 -  v9 -
+            if ((lane & 15u) == 15u) {
+                const unsigned row = lane >> 4;
+                const unsigned id = pe.y;
+                const size_t gi = vP + id;
+                float* c = dL_dcolors + gi * 3;
+                float* mm = dL_dmean2D + gi * 3;
+                unsafeAtomicAdd(row == 0 ? c : row == 1 ? c + 2 : row == 2 ? c + 1 : mm, f0);
+                if (row < 3) unsafeAtomicAdd(row == 0 ? mm + 1 : row == 1 ? dL_dopacity + id : mm + 2, f1);
+                double* acc = dL_dv2g_acc + gi * 10;
+                const unsigned perm = row == 0 ? 0u : row == 1 ? 2u : row == 2 ? 1u : 3u;
+                unsafeAtomicAdd(acc + perm, (double)d0);
+                unsafeAtomicAdd(acc + 4 + perm, (double)d1);
+                if ((row & 1u) == 0) unsafeAtomicAdd(acc + 8 + (row >> 1), (double)d2);
+            }
+        }
+        qhead += m;
+        qcount -= m;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the window's slots are rewritten by the next one
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane == 0 && n_pairs)
+        atomicAdd(&hdr->bwd_pairs, (unsigned long long)n_pairs);
+}
+
 struct M3 { float m[3][3]; };
 struct M4 { float m[4][4]; };
 __device__ __forceinline__ M3 mul(const M3& a, const M3& b)
@@ -1042,7 +1370,16 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     F3DG_HIP_CHECK(hipMemsetAsync(&hdr->bwd_pairs, 0, sizeof(hdr->bwd_pairs), s));
     const int prof = f3dg_prof_bwd_begin(s);
 
-    if (g_f3dg_render_cull)
+    if (g_f3dg_render_cull && g_f3dg_render_kernel == 3)
+        F3DG_KLAUNCH(render3_bwd_kernel, dim3((unsigned)n_views * (unsigned)T * 4u), dim3(64), 0, s, n_views, P, W, H,
+                           tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
+                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
+                           reinterpret_cast<const float4*>(ws + L.cull),
+                           reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
+                           background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
+                           reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
+                           acc);
+    else if (g_f3dg_render_cull)
         F3DG_KLAUNCH(render_bwd_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),

@@ -92,6 +92,37 @@ __device__ __forceinline__ void quad_ballots(int& lo, int& hi, float Ep, const f
     }
 }
 
+// The same with a wave-level summary: `any` collects the OR of the 64 ballots, i.e. the mask of the window's entries that can reach
+// at least one pixel of the quadrant (the compositing backward walks entries in lock-step and skips the others outright).
+template <int P>
+__device__ __forceinline__ void quad_ballots_any(int& lo, int& hi, unsigned long long& any, float Ep, const float (&dxx)[8],
+                                                 const float (&adx)[8], const float (&dyy)[8], const float (&cdy)[8], float eb)
+{
+    if constexpr (P < 63) {
+        float En;
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "v_fma_f32 %[en], %[eb], %[dy], %[ax]\n\t"
+            "v_fma_f32 %[en], %[dx], %[en], %[cy]\n\t"
+            "v_writelane_b32 %[lo], vcc_lo, %[l]\n\t"
+            "v_writelane_b32 %[hi], vcc_hi, %[l]\n\t"
+            "s_or_b64 %[any], %[any], vcc"
+            : [lo] "+v"(lo), [hi] "+v"(hi), [any] "+s"(any), [en] "=&v"(En)
+            : [ep] "v"(Ep), [eb] "v"(eb), [dy] "v"(dyy[(P + 1) >> 3]), [ax] "v"(adx[(P + 1) & 7]), [dx] "v"(dxx[(P + 1) & 7]),
+              [cy] "v"(cdy[(P + 1) >> 3]), [l] "n"(P)
+            : "vcc", "scc");
+        quad_ballots_any<P + 1>(lo, hi, any, En, dxx, adx, dyy, cdy, eb);
+    } else {
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "s_nop 1\n\t"
+            "v_writelane_b32 %[lo], vcc_lo, %[l]\n\t"
+            "v_writelane_b32 %[hi], vcc_hi, %[l]\n\t"
+            "s_or_b64 %[any], %[any], vcc"
+            : [lo] "+v"(lo), [hi] "+v"(hi), [any] "+s"(any)
+            : [ep] "v"(Ep), [l] "n"(P)
+            : "vcc", "scc");
+    }
+}
+
 } // namespace
 
 #endif

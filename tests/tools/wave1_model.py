@@ -130,12 +130,41 @@ for tile in tiles:
                     bm += int(cnts[blk[lanes] == bb].max()) * 16
                 t["lost_block"] += mx * 64 - bm
 
+        # sliding window: 64 entries resident, slides by STEP when every lane has consumed the oldest STEP entries
+        for STEP in (32, 16):
+            key = ("slide", STEP)
+            t = tot.setdefault(key, dict(trips=0, staged=0, slides=0))
+            if len(lst) == 0:
+                continue
+            pm = proc[np.ix_(lanes, lst)]                     # [64, n_q] passing & before saturation
+            nq = pm.shape[1]
+            nxt = [np.nonzero(pm[l])[0] for l in range(64)]   # per lane: positions (in quadrant list) it must process, in order
+            ptr = np.zeros(64, dtype=np.int64)
+            s = 0
+            while s < nq and lst[s] <= dq:
+                hi = min(s + 64, nq)
+                t["staged"] += min(STEP, nq - s) if s > 0 else min(64, nq)
+                t["slides"] += 1
+                # trips until every lane has no unprocessed entry < s + STEP
+                while True:
+                    cur = np.array([nxt[l][ptr[l]] if ptr[l] < len(nxt[l]) else 1 << 30 for l in range(64)])
+                    if not (cur < min(s + STEP, nq)).any():
+                        break
+                    can = cur < hi
+                    ptr[can] += 1
+                    t["trips"] += 1
+                s += STEP
+
 scale = 256.0 / NT
 print("tiles %d  tile entries/view %.3g  quadrant entries/view %.3g (x%.2f)  phase-2 pairs/view %.3g" %
       (NT, tile_entries * scale, quad_entries * scale, quad_entries / tile_entries, pairs_total * scale))
 ideal = pairs_total / 64.0
 t = tot["r2"]
 print("render2 shape: staged %.3g/view, trips %.3g, lane utilisation %.3f" % (t["staged"] * scale, t["trips"] * scale, ideal / t["trips"]))
+for STEP in (32, 16):
+    t = tot[("slide", STEP)]
+    print("one wave, 64 resident entries sliding by %d: staged %.3g/view, trips %.3g, lane utilisation %.3f, slides %.3g" %
+          (STEP, t["staged"] * scale, t["trips"] * scale, ideal / t["trips"], t["slides"] * scale))
 for wn in WINS:
     t = tot[("w1", wn)]
     print("one wave, %3d-entry windows: staged %.3g/view (gather x%.2f of render2), trips %.3g, lane utilisation %.3f, "
