@@ -93,6 +93,7 @@ int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
 int g_f3dg_render_lds_pad = 0;
+int g_f3dg_bwd_occ = 4;
 int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
@@ -103,6 +104,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; return F3DG_OK; }
+    if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = value == 5 ? 5 : value == 6 ? 6 : 4; return F3DG_OK; }
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }

@@ -154,6 +154,7 @@ extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it 
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
 extern int g_f3dg_render_kernel;       // 3 (default): render3 (one wave64 per 8x8 quadrant, no barriers); 2: render2 (four waves per tile,
                                        // Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is compiled for: 4 (default: 10.4 ms at C5), 5 (10.6) or 6 (spills, 12.0)
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);
