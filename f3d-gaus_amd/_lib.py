@@ -52,6 +52,7 @@ SIGNATURES = {
     "f3dg_set_option": (_i, [C.c_char_p, _i]),
     "f3dg_profile_enable": (_i, [_i]),
     "f3dg_debug_launch_count": (C.c_longlong, [_i]),
+    "f3dg_debug_launch_times": (_i, [_i]),
     "f3dg_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "f3dg_backward_pairs": (_i, [_p, _p, C.POINTER(_ll)]),
     "f3dg_debug_timing": (_i, [C.POINTER(C.c_ulonglong), _i]),

@@ -8,6 +8,7 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 namespace {
@@ -18,6 +19,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 __global__ void init_header_kernel(F3dgHeader* hdr, unsigned capacity, unsigned alpha_fast = 0, unsigned save_aux = 0)
 {
+    // (calls without Gaussians; otherwise the projection kernel's first workgroup initialises the header: F3dgHeaderInit)
     if (threadIdx.x < 64) {
         unsigned* w = reinterpret_cast<unsigned*>(hdr);
         w[threadIdx.x] = 0;
@@ -85,6 +87,19 @@ void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s)
     if (slot >= 0 && slot < (int)g_prof.bwd.size()) (void)hipEventRecord(g_prof.bwd[slot].ev[stage_done + 1], s);
 }
 
+int g_f3dg_small_path = 1;
+int g_f3dg_small_debug = 0;
+namespace {
+// shapes (P, n_views, W, H) whose small-call path overflowed a tile list: they take the general path from then on
+struct SmallShape { unsigned v[4]; };
+std::vector<SmallShape> g_small_disabled;
+bool small_disabled(unsigned P, unsigned V, unsigned W, unsigned H)
+{
+    for (const SmallShape& d : g_small_disabled)
+        if (d.v[0] == P && d.v[1] == V && d.v[2] == W && d.v[3] == H) return true;
+    return false;
+}
+} // namespace
 unsigned long long g_f3dg_kernel_launches = 0;      // host-side counter of F3DG_KLAUNCH (not thread-safe: a diagnostic)
 int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
@@ -104,6 +119,9 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; return F3DG_OK; }
+    if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) g_small_disabled.clear(); return F3DG_OK; }
+    if (name && strcmp(name, "small_debug") == 0) { g_f3dg_small_debug = value; return F3DG_OK; }
+    if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = value == 5 ? 5 : value == 6 ? 6 : 4; return F3DG_OK; }
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
@@ -114,6 +132,32 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
     return F3DG_ERR_BAD_ARG;
+}
+
+int g_f3dg_time_launches = 0;
+namespace { struct LaunchSite { const char* file; int line; long long ns, n, max_ns; }; std::vector<LaunchSite> g_sites; }
+long long f3dg_now_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+void f3dg_note_launch_time(const char* file, int line, long long ns)
+{
+    for (LaunchSite& s : g_sites)
+        if (s.file == file && s.line == line) { s.ns += ns; s.n++; if (ns > s.max_ns) s.max_ns = ns; return; }
+    g_sites.push_back({file, line, ns, 1, ns});
+}
+// diagnostic: prints (stderr) the host time spent inside hipLaunchKernelGGL per launch site since the last reset
+extern "C" int f3dg_debug_launch_times(int reset)
+{
+    for (const LaunchSite& s : g_sites) {
+        const char* base = strrchr(s.file, '/');
+        fprintf(stderr, "%-22s:%4d  %6lld launches  %8.2f us avg  %9.1f us max\n", base ? base + 1 : s.file, s.line, s.n,
+                1e-3 * (double)s.ns / (double)s.n, 1e-3 * (double)s.max_ns);
+    }
+    if (reset) g_sites.clear();
+    return F3DG_OK;
 }
 
 extern "C" long long f3dg_debug_launch_count(int reset)
@@ -218,6 +262,9 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.final_T = take((size_t)V * 4 * HW * sizeof(float));
     L.n_contrib = take((size_t)V * 2 * HW * sizeof(unsigned));
     L.bwd_acc = take(VP * 10 * sizeof(double));
+    L.small_cap = f3dg_small_shape(P, W, H, V) ? (unsigned)F3DG_SMALL_CAP : 0u;
+    L.small_cnt = take((size_t)V * T * sizeof(unsigned));
+    L.small_list = take((size_t)V * T * L.small_cap * sizeof(unsigned));
     L.total = off;
     return L;
 }
@@ -251,7 +298,7 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* view2gaussian_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* cam_pos, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
-                 int* radii_used, int save_aux, int need_box, int tile_cull, ProfCall* prof)
+                 int* radii_used, int save_aux, int need_box, int tile_cull, ProfCall* prof, F3dgHeaderInit init, int small = 0)
 {
     int rc = f3dg_launch_preprocess(s, n_views, views_per_set, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
@@ -263,10 +310,10 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     reinterpret_cast<float4*>(ws + L.cull),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
-                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux, tile_cull);
+                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux, tile_cull, init);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_PREPROCESS, s);
-    rc = f3dg_launch_binning(s, n_views, P, W, H, L, ws, save_aux);
+    rc = small ? f3dg_launch_small_bin(s, n_views, P, W, H, L, ws) : f3dg_launch_binning(s, n_views, P, W, H, L, ws, save_aux);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_BINNING, s);
     return F3DG_OK;
@@ -318,8 +365,15 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     // several Gaussian sets in one call are an inference path: f3dg_backward and the per-Gaussian backward index the Gaussian inputs
     // without a set offset, and view2gaussian_precomp is [n_views, P, 10] of ONE set
     if (n_sets > 1 && (save_aux || view2gaussian_precomp != nullptr)) return F3DG_ERR_BAD_ARG;
-    F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered,
-                       (unsigned)f3dg_render_uses_fast(save_aux), (unsigned)save_aux);
+    // small-call path (f3dg_small.hip): inference calls of one or two views of a modest set go projection -> per-tile sort -> compositing
+    const int small = g_f3dg_small_path && !save_aux && n_sets == 1 && P > 0 && L.small_cap != 0 && g_f3dg_render_kernel == 3 &&
+                      !small_disabled((unsigned)P, (unsigned)n_views, (unsigned)W, (unsigned)H);
+    // (the header is initialised by the first workgroup of the projection kernel; without Gaussians there is no such launch)
+    const F3dgHeaderInit hinit = { hdr, (unsigned)max_rendered, (unsigned)f3dg_render_uses_fast(save_aux), (unsigned)save_aux, (unsigned)small,
+                                   { (unsigned)P, (unsigned)n_views, (unsigned)W, (unsigned)H } };
+    if (P == 0)
+        F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered, (unsigned)f3dg_render_uses_fast(save_aux),
+                     (unsigned)save_aux);
 
     if (P == 0) {
         F3DG_KLAUNCH(fill_background_kernel, dim3(1024), dim3(256), 0, s, n_views, HW, background,
@@ -339,12 +393,12 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     rc = run_geometry(s, ws, L, n_views, views_per_set, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                       tan_fovy, focal_x, focal_y, kernel_size, radii_used, save_aux,
-                      save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, g_f3dg_tile_cull, prof);
+                      save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, g_f3dg_tile_cull, prof, hinit, small);
     if (rc != F3DG_OK) return rc;
 
     rc = f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
                               reinterpret_cast<const uint2*>(ws + L.ranges),
-                              reinterpret_cast<const unsigned*>(ws + L.vals[0]),
+                              reinterpret_cast<const unsigned*>(ws + (small ? L.small_list : L.vals[0])),
                               reinterpret_cast<const F3dgRec*>(ws + L.rec),
                               reinterpret_cast<const float4*>(ws + L.bbox),
                               reinterpret_cast<const float4*>(ws + L.cull), background,
@@ -380,7 +434,7 @@ extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_
     char* ws = static_cast<char*>(workspace);
     F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
     if (h_needed) *h_needed = 0;
-    F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered);
+    const F3dgHeaderInit hinit = { hdr, (unsigned)max_rendered, 0u, 0u, 0u, { (unsigned)P, 1u, (unsigned)W, (unsigned)H } };
     int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                  view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
     if (rc != F3DG_OK) return rc;
@@ -390,7 +444,7 @@ extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_
     rc = run_geometry(s, ws, L, 1, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                       tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, 1 /* pass 1 culls by the box */,
-                      0 /* the points of a tile are not its pixel centres: the reference's tile lists */, nullptr);
+                      0 /* the points of a tile are not its pixel centres: the reference's tile lists */, nullptr, hinit);
     if (rc != F3DG_OK) return rc;
     rc = f3dg_launch_integrate_pass1(s, W, H, focal_x, focal_y, L, I, ws, background, out_color);
     if (rc != F3DG_OK) return rc;
@@ -464,6 +518,8 @@ extern "C" int f3dg_read_status(void* stream, const void* workspace, long long* 
     F3DG_HIP_CHECK(hipMemcpyAsync(&h, workspace, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
     F3DG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (h_num_rendered) *h_num_rendered = (long long)h.num_rendered;
+    if (h.small_overflow && !small_disabled(h.small_shape[0], h.small_shape[1], h.small_shape[2], h.small_shape[3]))
+        g_small_disabled.push_back({{h.small_shape[0], h.small_shape[1], h.small_shape[2], h.small_shape[3]}});     // the retry takes the general path
     return h.overflow ? F3DG_ERR_OVERFLOW : F3DG_OK;
 }
 
@@ -514,12 +570,19 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
     const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
     const char* ws = static_cast<const char*>(workspace);
     const size_t VP = (size_t)n_views * P, HW = (size_t)W * H;
-    if (means2D || conic || tiles || offsets || clamped || keys_sorted || final_T || n_contrib || depths) {
-        // these planes are written by a SAVE_AUX forward only (the keys are rebuilt from `depths`): refuse to hand out stale memory
-        F3dgHeader h;
-        F3DG_HIP_CHECK(hipMemcpyAsync(&h, ws + L.header, sizeof h, hipMemcpyDeviceToHost, s));
-        F3DG_HIP_CHECK(hipStreamSynchronize(s));
-        if (!h.save_aux) return F3DG_ERR_BAD_ARG;
+    F3dgHeader h;       // (BLOCKING: an inspection hook)
+    F3DG_HIP_CHECK(hipMemcpyAsync(&h, ws + L.header, sizeof h, hipMemcpyDeviceToHost, s));
+    F3DG_HIP_CHECK(hipStreamSynchronize(s));
+    // these planes are written by a SAVE_AUX forward only (the keys are rebuilt from `depths`): refuse to hand out stale memory
+    if ((means2D || conic || tiles || offsets || clamped || keys_sorted || final_T || n_contrib || depths) && !h.save_aux)
+        return F3DG_ERR_BAD_ARG;
+    if (h.small_path) {
+        // the small-call path keeps its lists in per-tile slots: hand them out in the general path's layout (gap-free, (view, tile) order)
+        if (h.overflow) return F3DG_ERR_OVERFLOW;
+        const int rcs = f3dg_launch_small_export(s, n_views, W, H, L, ws, point_list, ranges);
+        if (rcs != F3DG_OK) return rcs;
+        point_list = nullptr;
+        ranges = nullptr;
     }
     const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
     const size_t C = (size_t)max_rendered;

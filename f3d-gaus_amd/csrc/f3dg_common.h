@@ -56,7 +56,10 @@ struct F3dgHeader {
                                   // backward must repeat it to the bit
     unsigned int save_aux;        // 1 when the forward of this workspace ran with F3DG_FLAG_SAVE_AUX (the auxiliary planes are valid)
     unsigned long long bwd_pairs; // contributing (pixel, Gaussian) pairs of the last f3dg_backward on this workspace ("C" of SURVEY 8d)
-    unsigned int reserved[54];
+    unsigned int small_path;      // 1 when the forward of this workspace took the small-call path (per-tile lists in `small_list`)
+    unsigned int small_overflow;  // 1 when a tile of that path held more than F3DG_SMALL_CAP entries (the caller re-runs the general path)
+    unsigned int small_shape[4];  // P, n_views, W, H of that call (f3dg_read_status disables the path for a shape that overflowed)
+    unsigned int reserved[48];
 };
 
 // Per-(view, Gaussian) record consumed by the compositing kernel: one 64-byte line.
@@ -94,6 +97,10 @@ struct F3dgLayout {
     size_t final_T;        // [V][4][H*W] float
     size_t n_contrib;      // [V][2][H*W] u32
     size_t bwd_acc;        // [V*P][10] double: float64 accumulator of dL/dview2gaussian (backward only)
+    // small-call path (f3dg_small.hip; carved only for the shapes it serves, small_cap = 0 otherwise)
+    size_t small_cnt;      // [V*T] u32: length of every (view, tile) list
+    size_t small_list;     // [V*T][small_cap] u32: the sorted lists (the compositing kernel's point list on this path)
+    unsigned int small_cap;
     size_t total;
     unsigned int sort_blocks;
     unsigned int scan_tmp_elems;
@@ -119,7 +126,14 @@ F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap);
 
 // every kernel launch of the library goes through this macro: f3dg_debug_launch_count reports how many a call sequence issued
 extern unsigned long long g_f3dg_kernel_launches;
-#define F3DG_KLAUNCH(...) do { ++g_f3dg_kernel_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+// (host-side cost of every launch site: option "time_launches" + f3dg_debug_launch_times, a diagnostic of the small-call path)
+extern int g_f3dg_time_launches;
+void f3dg_note_launch_time(const char* file, int line, long long ns);
+long long f3dg_now_ns();
+#define F3DG_KLAUNCH(...) do { ++g_f3dg_kernel_launches;                                                                   \
+        if (g_f3dg_time_launches) { const long long t0_ = f3dg_now_ns(); hipLaunchKernelGGL(__VA_ARGS__);                  \
+                                    f3dg_note_launch_time(__FILE__, __LINE__, f3dg_now_ns() - t0_); }                      \
+        else hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 int f3dg_set_hip_error(hipError_t e, const char* where);
 #define F3DG_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return f3dg_set_hip_error(_e, #expr); } while (0)
@@ -130,6 +144,13 @@ struct F3dgViewConsts {           // passed by pointer: [V] of these are the cal
     const float* cam_pos;         // [V,3]
 };
 
+// Workspace header initialisation folded into the projection kernel's first workgroup (one launch less per call)
+struct F3dgHeaderInit {
+    F3dgHeader* hdr;              // null: the header is initialised elsewhere
+    unsigned capacity, alpha_fast, save_aux, small_path;
+    unsigned shape[4];            // P, n_views, W, H (recorded for the small-call path)
+};
+
 // ---- launchers (each returns F3DG_OK or a negative error) -------------------------------------------
 // views_per_set: the V views are n_sets = V / views_per_set groups, group i renders Gaussian set i of the [n_sets, P, ...] inputs
 int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D, int M, const float* means3D, const float* scales,
@@ -138,7 +159,18 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox /* may be null */, float4* cull, float4* conic,
-                           int* radii, unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull);
+                           int* radii, unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init);
+
+// Small-call path: entries per (view, tile) it can hold, and the shapes it serves (one or two views of at most 2^18 Gaussians on at
+// most 1024 tiles: the reference's one-view-per-call loops, visualize.py:293-314, 387-416)
+#define F3DG_SMALL_CAP 4096
+inline bool f3dg_small_shape(int P, int W, int H, int V)
+{
+    const long long T = (long long)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
+    return V >= 1 && V <= 2 && P >= 1 && P <= (1 << 18) && T <= 1024;
+}
+int f3dg_launch_small_bin(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws);
+int f3dg_launch_small_export(hipStream_t s, int V, int W, int H, const F3dgLayout& L, const char* ws, unsigned* point_list, unsigned* ranges);
 
 int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out, unsigned long long n,
                                unsigned* tmp, unsigned tmp_elems, int exclusive,
@@ -154,6 +186,8 @@ extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it 
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
 extern int g_f3dg_render_kernel;       // 3 (default): render3 (one wave64 per 8x8 quadrant, no barriers); 2: render2 (four waves per tile,
                                        // Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
+extern int g_f3dg_small_debug;         // timing experiments of small_bin_kernel: 1 return at once, 2 after the collection, 3 no sort passes
+extern int g_f3dg_small_path;          // 1 (default): inference calls of a small shape (f3dg_small_shape) take the three-launch path
 extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is compiled for: 4 (default: 10.4 ms at C5), 5 (10.6) or 6 (spills, 12.0)
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)

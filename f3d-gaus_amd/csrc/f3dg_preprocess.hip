@@ -211,8 +211,18 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
                   unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all, int tile_cull,
-                  double inv_focal_x, double inv_focal_y)
+                  double inv_focal_x, double inv_focal_y, F3dgHeaderInit init)
 {
+    if (init.hdr != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        // the workspace header (read by every later kernel of the call, by nothing in this one): zeroed, then its constants
+        reinterpret_cast<unsigned*>(init.hdr)[threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+            init.hdr->capacity = init.capacity; init.hdr->alpha_fast = init.alpha_fast; init.hdr->save_aux = init.save_aux;
+            init.hdr->small_path = init.small_path;
+            init.hdr->small_shape[0] = init.shape[0]; init.hdr->small_shape[1] = init.shape[1];
+            init.hdr->small_shape[2] = init.shape[2]; init.hdr->small_shape[3] = init.shape[3];
+        }
+    }
     const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
     const size_t gs = (size_t)(v / views_per_set) * P + g;       // this view's Gaussian set: inputs are [n_sets, P, ...]
@@ -526,7 +536,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox, float4* cull, float4* conic, int* radii,
-                           unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull)
+                           unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
@@ -534,7 +544,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                        rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
                        depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all, tile_cull,
-                       1.0 / (double)focal_x, 1.0 / (double)focal_y);
+                       1.0 / (double)focal_x, 1.0 / (double)focal_y, init);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -1,0 +1,259 @@
+// f3dg_small.hip -- the small-call path of the forward: ONE kernel between the projection and the compositing kernel.
+//
+// The reference renders one view per rasterizer call (visualize.py:293-314, 387-416: 8 cycle views and the orbit, 65,536 to
+// 589,824 Gaussians each). For such a call the general binning stage (f3dg_binning.hip: per-view depth sort, instance generation, tile
+// pass; 26 dependent launches built for hundreds of views per call) is all launch latency: ~4.5 us per kernel whatever it does,
+// ~150 us per call at 65,536 Gaussians. Here ONE kernel does the binning, one workgroup per (view, tile):
+//   1. its sixteen waves each scan a sixteenth of the view's Gaussians (tile rectangle + depth key, 12 B each, from L2) and compact those
+//      whose rectangle holds the tile, in id order -- no atomics, no lists in global memory;
+//   2. a stable LSD radix sort of the (depth bits, id) pairs in LDS (wave-ballot ranking, four 8-bit passes, passes whose digit is the
+//      same for every entry are skipped) -- exactly the order of the reference's stable sort of (tile | depth) keys
+//      (rasterizer_impl.cu:70-111, 358-363);
+//   3. the list goes to the tile's slot together with its range.
+// Four launches per call (header, projection, this, compositing) instead of 29.
+//
+// A slot holds F3DG_SMALL_CAP entries, a wave's share a sixteenth of that; a longer list sets the overflow flags and the caller
+// re-runs the call on the general path (f3dg_read_status remembers the shape). Inference calls only (no auxiliary planes).
+#include "f3dg_common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define SMALL_THREADS 1024
+#define SMALL_WAVES (SMALL_THREADS / 64)
+#define SMALL_QCAP (F3DG_SMALL_CAP / SMALL_WAVES)        // entries one wave may collect from its share of the Gaussians
+
+struct SmallShared {
+    u32 k[2][F3DG_SMALL_CAP];                  // depth bits, ping-pong
+    u32 v[2][F3DG_SMALL_CAP];                  // Gaussian id | quadrant mask << F3DG_ID_BITS
+    u32 hist[SMALL_WAVES][256];                // per-wave digit counts, then the waves' write offsets
+    u32 wave_n[SMALL_WAVES];
+    u32 wave_min[SMALL_WAVES], wave_max[SMALL_WAVES];
+    u32 wsum[4];
+    u32 skip;
+};
+
+// One workgroup of 16 waves per (view, tile): a single 256^2 view is 256 workgroups, one per CU, and the scan of the view's
+// Gaussians is a latency chain per wave -- the sixteen waves of a CU each take a sixteenth of it.
+__global__ void __launch_bounds__(SMALL_THREADS)
+small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const uint2* __restrict__ rects,
+                 const u32* __restrict__ sort_keys, u32* __restrict__ list, u32* __restrict__ cnt, uint2* __restrict__ ranges, int debug_stop)
+{
+    __shared__ SmallShared sh;
+    if (debug_stop == 1) return;
+    const u32 seg = blockIdx.x, view = seg / T, tile = seg % T;
+    const u32 tx = tile % grid_x, ty = tile / grid_x;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    const uint2* vrect = rects + (size_t)view * P;
+    const u32* vkey = sort_keys + (size_t)view * P;
+
+    // ---- 1. collect: wave w scans Gaussians [w Pq, (w + 1) Pq), 32 steps of 64 in flight. A step only tests the packed tile
+    // rectangle (rmin <= t < rmax in both halves of a word with one packed 16-bit subtraction) and notes the ids of the hits; the
+    // hits' depth keys and quadrant masks are gathered afterwards, densely.
+    const u32 Pq = ((P + 64u * SMALL_WAVES - 1u) / (64u * SMALL_WAVES)) * 64u;
+    const u32 g0 = min(P, wave * Pq), g1 = min(P, g0 + Pq);
+    u32 nw = 0;                                 // wave-uniform
+    u32* wk = &sh.k[1][wave * SMALL_QCAP];
+    u32* wv = &sh.v[1][wave * SMALL_QCAP];
+    typedef short pk16 __attribute__((ext_vector_type(2)));
+    const u32 cxw = (tx + 1u) | ((tx + 1u) << 16), cyw = (ty + 1u) | ((ty + 1u) << 16);
+    const pk16 cx = __builtin_bit_cast(pk16, cxw), cy = __builtin_bit_cast(pk16, cyw);
+    constexpr int UN = 32;                       // steps of 64 rectangles in flight per lane (the scan is a chain of memory round trips)
+    for (u32 base = g0; base < g1; base += 64u * UN) {
+        uint2 r[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++)        // (unconditional loads from a clamped index: a guarded load is a branch + a full wait each)
+            r[u] = vrect[min(base + 64u * u + lane, P - 1u)];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            // low half: rmin - (t + 1) < 0  <=>  rmin <= t;  high half: rmax - (t + 1) >= 0  <=>  t < rmax  (an empty rectangle fails the second)
+            const u32 dx = __builtin_bit_cast(u32, __builtin_bit_cast(pk16, r[u].x & 0x7FFF7FFFu) - cx);
+            const u32 dy = __builtin_bit_cast(u32, __builtin_bit_cast(pk16, r[u].y & 0x7FFF7FFFu) - cy);
+            const bool in = (((dx ^ 0x8000u) | (dy ^ 0x8000u)) & 0x80008000u) == 0u && base + 64u * u + lane < g1;
+            const u64 bal = __ballot(in);
+            if (in) {
+                const u32 slot = nw + (u32)__popcll(bal & lt);
+                if (slot < (u32)SMALL_QCAP) wv[slot] = base + 64u * u + lane;
+            }
+            nw += (u32)__popcll(bal);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;          // of the entries this lane collects
+    for (u32 i = lane; i < min(nw, (u32)SMALL_QCAP); i += 64u) {
+        const u32 g = wv[i];
+        const uint2 r = vrect[g];
+        const u32 key = vkey[g];
+        const u32 rminx = r.x & F3DG_RECT_COORD, rmaxx = (r.x >> 16) & F3DG_RECT_COORD;
+        const u32 rminy = r.y & F3DG_RECT_COORD, rmaxy = (r.y >> 16) & F3DG_RECT_COORD;
+        // quadrant mask of the instance, as duplicate_sorted_kernel (f3dg_binning.hip) derives it
+        u32 mx = 3u, my = 3u;
+        if (tx == rminx && (r.x & F3DG_RECT_SKIP_LO)) mx &= ~1u;
+        if (tx + 1u == rmaxx && (r.x & F3DG_RECT_SKIP_HI)) mx &= ~2u;
+        if (ty == rminy && (r.y & F3DG_RECT_SKIP_LO)) my &= ~1u;
+        if (ty + 1u == rmaxy && (r.y & F3DG_RECT_SKIP_HI)) my &= ~2u;
+        const u32 qm = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u);
+        wk[i] = key;
+        wv[i] = g | (qm << F3DG_ID_BITS);
+        kmin = min(kmin, key);
+        kmax = max(kmax, key);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (u32)__shfl_xor((int)kmin, o, 64));
+        kmax = max(kmax, (u32)__shfl_xor((int)kmax, o, 64));
+    }
+    if (lane == 0) { sh.wave_n[wave] = nw; sh.wave_min[wave] = kmin; sh.wave_max[wave] = kmax; }
+    __syncthreads();
+    u32 n = 0, off = 0;
+    bool over = false;
+    kmin = 0xFFFFFFFFu; kmax = 0u;
+#pragma unroll
+    for (u32 w = 0; w < SMALL_WAVES; w++) {
+        const u32 c = sh.wave_n[w];
+        if (w < wave) off += c;
+        n += c;
+        over = over || c > (u32)SMALL_QCAP;
+        kmin = min(kmin, sh.wave_min[w]);
+        kmax = max(kmax, sh.wave_max[w]);
+    }
+    const u32 slot_base = seg * (u32)F3DG_SMALL_CAP;
+    if (threadIdx.x == 0) {
+        const u32 before = atomicAdd(&hdr->num_rendered, n);            // the call's instance count, as on the general path
+        if (over) { hdr->overflow = 1u; hdr->small_overflow = 1u; }
+        if (before + n > hdr->capacity || before + n < before) hdr->overflow = 1u;
+        cnt[seg] = over ? 0u : n;
+        ranges[seg] = over ? make_uint2(0u, 0u) : make_uint2(slot_base, slot_base + n);
+    }
+    if (over || n == 0u || debug_stop == 2)
+        return;
+    // concatenate the waves' shares (id order) into buffer 0
+    // (keys relative to the list's smallest: the depths of a tile's list differ in ~22 bits, three 8-bit passes instead of four)
+    for (u32 i = lane; i < nw; i += 64u) { sh.k[0][off + i] = wk[i] - kmin; sh.v[0][off + i] = wv[i]; }
+    __syncthreads();
+    const u32 span = kmax - kmin;
+    const int key_bits = debug_stop == 3 ? 0 : span == 0u ? 0 : 32 - __builtin_clz(span);
+
+    // ---- 2. stable LSD radix sort by the depth bits; wave w owns entries [w q, (w + 1) q) of the current buffer
+    const u32 q = ((n + 64u * SMALL_WAVES - 1u) / (64u * SMALL_WAVES)) * 64u;
+    const u32 e0 = min(n, wave * q), e1 = min(n, e0 + q);
+    u32 cur = 0;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        sh.hist[wave][lane] = 0; sh.hist[wave][lane + 64] = 0; sh.hist[wave][lane + 128] = 0; sh.hist[wave][lane + 192] = 0;
+        if (threadIdx.x == 0) sh.skip = 0;
+        __syncthreads();
+        for (u32 i = e0 + lane; i < e1; i += 64u)
+            atomicAdd(&sh.hist[wave][(sh.k[cur][i] >> shift) & 255u], 1u);
+        __syncthreads();
+        // thread d < 256: total of digit d, exclusive scan over the digits, per-wave offsets
+        u32 tot = 0, x = 0;
+        if (threadIdx.x < 256u) {
+#pragma unroll
+            for (u32 w = 0; w < SMALL_WAVES; w++) tot += sh.hist[w][threadIdx.x];
+            if (tot == n) sh.skip = 1;                      // every entry has this digit: the pass is the identity
+            x = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 y = __shfl_up(x, o, 64);
+                if (lane >= (u32)o) x += y;
+            }
+            if (lane == 63) sh.wsum[wave] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256u) {
+            u32 run = x - tot;
+            for (u32 w = 0; w < wave; w++) run += sh.wsum[w];
+#pragma unroll
+            for (u32 w = 0; w < SMALL_WAVES; w++) {
+                const u32 h = sh.hist[w][threadIdx.x];
+                sh.hist[w][threadIdx.x] = run;
+                run += h;
+            }
+        }
+        __syncthreads();
+        if (sh.skip) {
+            __syncthreads();
+            continue;
+        }
+        for (u32 i0 = e0; i0 < e1; i0 += 64u) {
+            const u32 i = i0 + lane;
+            const bool valid = i < e1;
+            const u32 key = valid ? sh.k[cur][i] : 0u, val = valid ? sh.v[cur][i] : 0u;
+            const u32 d = (key >> shift) & 255u;
+            u64 m = __ballot(valid);                        // lanes of this step with my digit
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const u64 bal = __ballot((d >> b) & 1u);
+                m &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            if (valid) {
+                const u32 pos = sh.hist[wave][d] + (u32)__popcll(m & lt);
+                sh.k[cur ^ 1u][pos] = key;
+                sh.v[cur ^ 1u][pos] = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (valid && (m & lt) == 0ull)                  // the first lane of every digit group moves the wave's offset on
+                sh.hist[wave][d] += (u32)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        cur ^= 1u;
+        __syncthreads();
+    }
+
+    // ---- 3. the tile's list
+    for (u32 i = threadIdx.x; i < n; i += SMALL_THREADS)
+        list[(size_t)slot_base + i] = sh.v[cur][i];
+}
+
+// debug export: the lists in (view, tile) order without gaps, as the general path lays them out, and the matching ranges
+__global__ void __launch_bounds__(F3DG_BLOCK)
+small_export_kernel(const u32* __restrict__ cnt, const u32* __restrict__ list, u32* __restrict__ point_list, u32* __restrict__ ranges)
+{
+    __shared__ u32 part[F3DG_BLOCK];
+    const u32 seg = blockIdx.x;
+    u32 acc = 0;
+    for (u32 i = threadIdx.x; i < seg; i += F3DG_BLOCK) acc += cnt[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 s = F3DG_BLOCK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const u32 start = part[0], n = cnt[seg];
+    if (threadIdx.x == 0 && ranges) { ranges[2u * seg] = n ? start : 0u; ranges[2u * seg + 1u] = n ? start + n : 0u; }
+    if (point_list)
+        for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK)
+            point_list[start + i] = list[(size_t)seg * F3DG_SMALL_CAP + i] & F3DG_ID_MASK;
+}
+
+} // namespace
+
+int f3dg_launch_small_bin(hipStream_t s, int V, int P, int W, int H, const F3dgLayout& L, char* ws)
+{
+    const u32 grid_x = (u32)((W + F3DG_TILE - 1) / F3DG_TILE);
+    const u32 T = grid_x * (u32)((H + F3DG_TILE - 1) / F3DG_TILE);
+    F3DG_KLAUNCH(small_bin_kernel, dim3((u32)V * T), dim3(SMALL_THREADS), 0, s, (u32)P, T, grid_x, reinterpret_cast<F3dgHeader*>(ws + L.header),
+                 reinterpret_cast<const uint2*>(ws + L.rects), reinterpret_cast<const u32*>(ws + L.gsort),
+                 reinterpret_cast<u32*>(ws + L.small_list), reinterpret_cast<u32*>(ws + L.small_cnt), reinterpret_cast<uint2*>(ws + L.ranges),
+                 g_f3dg_small_debug);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+int f3dg_launch_small_export(hipStream_t s, int V, int W, int H, const F3dgLayout& L, const char* ws, unsigned* point_list, unsigned* ranges)
+{
+    const u32 T = (u32)(((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE));
+    F3DG_KLAUNCH(small_export_kernel, dim3((u32)V * T), dim3(F3DG_BLOCK), 0, s, reinterpret_cast<const u32*>(ws + L.small_cnt),
+                 reinterpret_cast<const u32*>(ws + L.small_list), point_list, ranges);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}

@@ -274,6 +274,9 @@ int f3dg_set_option(const char* name, int value);
 /* Diagnostic: number of kernels this library has launched from this process since the last reset (host-side counter, every
  * launch site counts; memsets / copies do not). bench.py reports launches per call from it. */
 long long f3dg_debug_launch_count(int reset);
+/* Diagnostic: with option "time_launches" = 1 every launch site measures the host time of its hipLaunchKernelGGL; this prints the
+ * per-site averages to stderr (tools/prof_small.py). */
+int f3dg_debug_launch_times(int reset);
 
 /* Optional per-stage timing of the forward path with HIP events recorded on the caller's stream (this is what
  * bench.py uses for the live roofline figure). f3dg_profile_enable(1) makes every following

@@ -1,0 +1,86 @@
+"""The small-call path (csrc/f3dg_small.hip: projection -> per-tile LDS sort -> compositing, taken by inference calls of one or two
+views of at most 2^18 Gaussians) against the general binning stage on the same inputs: identical images, radii, instance count,
+lists and ranges; overflow of a tile's slot falls back to the general path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import f3dgaus_amd as f3d
+from f3dgaus_amd import _lib
+from helpers import assert_render_parity, make_scene, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(scene, device):
+    dev = lambda t: None if t is None else t.to(device)
+    L = _lib.lib()
+    L.f3dg_debug_launch_count(1)
+    out, radii, ws = f3d.rasterize_views(
+        dev(scene["means3D"]), dev(scene["opacities"]), dev(scene["viewmatrix"]), dev(scene["projmatrix"]), dev(scene["campos"]),
+        dev(scene["bg"]), image_height=scene["H"], image_width=scene["W"], tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"],
+        sh=dev(scene["shs"]), colors_precomp=dev(scene["colors_precomp"]), scales=dev(scene["scales"]), rotations=dev(scene["rotations"]),
+        sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"], kernel_size=scene["kernel_size"], save_aux=False)
+    launches = int(L.f3dg_debug_launch_count(1))
+    V, W, H, P = scene["viewmatrix"].shape[0], scene["W"], scene["H"], scene["P"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    pl = torch.zeros(max(ws.max_rendered, 1), dtype=torch.int32, device=device)
+    rg = torch.zeros(V * T * 2, dtype=torch.int32, device=device)
+    rc = L.f3dg_debug_export(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), P, W, H, V,
+                             ws.max_rendered, None, None, None, None, None, None, None, C.c_void_p(pl.data_ptr()), C.c_void_p(rg.data_ptr()),
+                             None, None, None)
+    assert rc == 0
+    return out, radii, ws.num_rendered, pl[:ws.num_rendered].cpu().numpy(), rg.cpu().numpy().reshape(V * T, 2), launches
+
+
+CASES = {
+    "one_view": dict(P=5000, res=(128, 128), s0=0.02, view="oblique"),
+    "two_views_odd_size": dict(P=4001, res=(100, 72), s0=0.04, view=[2, 6], bg=(0.2, 0.1, 0.4)),
+    "aniso_behind": dict(P=6000, res=(96, 96), s0=0.02, view="oblique", aniso=True, behind_fraction=0.1),
+    "single_tile": dict(P=300, res=(16, 12), s0=0.05, view="canonical"),
+    "c1_size": dict(P=65536, res=(256, 256), s0=0.01, view="oblique"),
+}
+
+
+@pytest.mark.parametrize("tile_cull", [1, 0])
+@pytest.mark.parametrize("name", list(CASES))
+def test_small_path_equals_general_path(name, tile_cull, gpu_device):
+    scene = make_scene(**CASES[name])
+    L = _lib.lib()
+    L.f3dg_set_option(b"small_path", 2)          # on, and forget shapes disabled by earlier overflows
+    L.f3dg_set_option(b"tile_cull", tile_cull)
+    try:
+        a = _render(scene, gpu_device)
+        L.f3dg_set_option(b"small_path", 0)
+        b = _render(scene, gpu_device)
+    finally:
+        L.f3dg_set_option(b"small_path", 2)
+        L.f3dg_set_option(b"tile_cull", 1)
+    assert a[5] == 3 and b[5] > 20, (a[5], b[5])              # projection (+ header) + per-tile binning + compositing
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]), "lists differ"
+    assert np.array_equal(a[4], b[4]), "ranges differ"
+    if name == "one_view" and tile_cull == 0:
+        o = run_oracle(scene)
+        assert a[2] == o["num_rendered"] and np.array_equal(a[3].view(np.uint32), o["point_list"])
+        assert_render_parity(a[0][0].cpu().numpy(), o["out_color"], "small path")
+
+
+def test_small_path_overflow_falls_back(gpu_device):
+    """Tile lists longer than a slot (4096 entries): the call reports overflow, the wrapper re-runs it on the general path, and the
+    shape stays on the general path afterwards."""
+    scene = make_scene(P=30000, res=(128, 128), s0=0.05, view="oblique")      # tile lists of 4 k .. 16 k entries
+    L = _lib.lib()
+    L.f3dg_set_option(b"small_path", 2)
+    try:
+        a = _render(scene, gpu_device)
+        again = _render(scene, gpu_device)
+        L.f3dg_set_option(b"small_path", 0)
+        b = _render(scene, gpu_device)
+    finally:
+        L.f3dg_set_option(b"small_path", 2)
+    assert a[5] > b[5] and again[5] == b[5]                    # first: small attempt + general retry; then general at once
+    for r in (a, again):
+        assert torch.equal(r[0], b[0]) and torch.equal(r[1], b[1]) and r[2] == b[2] and np.array_equal(r[3], b[3])
