@@ -11,6 +11,9 @@ Workloads (`--workload`):
       and the RGB frames are gathered to rank 0 over RCCL inside the timed region.
   c5 (BASELINE config C5): 1,000,000 Gaussians, 32 views @512x512, SAVE_AUX forward + backward (random dL/dpix on channels 0-6
       and 8) per step; adds the roofline record of the compositing backward (80 R + 60 W H + 68 C bytes, C counted by the kernel).
+  dropin: the reference's OWN call pattern (visualize.py:293-314, 387-416): `render_predicted_more_v2_gof(pc, bb, wv[th:th+1], ...)`, one
+      view per rasterizer call, through this build's drop-in wrapper (the small-call path of the library: three launches per call).
+      --gaussians defaults to 65,536 here (one predicted view's set). A "step" = --views such calls.
   c4 (BASELINE config C4's shape per rank; C3 at N = 1): --images B input images per rank @256x256 through predictor (random
       weights) + cycle aggregation (8 novel views of all B images in one launch sequence, 8 re-predictions, in-place merge)
       + the 8 orbit views of every merged set + frame packing + the gather. A "step" = B x 8 final views.
@@ -47,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c4", "c5", "dropin"], default="c2")
     ap.add_argument("--gaussians", type=int, default=196608)
     ap.add_argument("--views", type=int, default=120)
     ap.add_argument("--res", type=int, default=256)
@@ -151,7 +154,7 @@ def main():
         if os.environ.get(env):
             _lib.check(L.f3dg_set_option(opt, int(os.environ[env])), "f3dg_set_option")
     _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
-    result = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, rank, world, dist, device, comm_device, f3d, L)
+    result = {"c2": run_c2, "c4": run_c4, "c5": run_c5, "dropin": run_dropin}[args.workload](args, rank, world, dist, device, comm_device, f3d, L)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -431,6 +434,81 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
                              "visualize.py:293-314 and :387-416"},
     }
 
+
+
+
+# ------------------------------------------------------------------------------------------------------------ drop-in
+def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
+    """The reference's per-view loop around the drop-in operator: one `render_predicted_more_v2_gof` call per view, exactly the
+    arguments visualize.py:394-399 passes ([th:th+1] slices of the camera stacks, a [1,3] background, the config dict)."""
+    from f3dgaus_amd import _lib, cameras, synthetic
+    P = args.gaussians if args.gaussians != 196608 else 65536
+    V, RES = args.views, args.res
+    cfg = cameras.default_cfg(RES)
+    g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)
+    pc = {"xyz": g["xyz"][None], "opacity": g["opacity"][None], "scaling": g["scaling"][None], "rotation": g["rotation"][None],
+          "features_dc": g["features_dc"][None], "features_rest": g["features_rest"][None]}
+    cams = synthetic.orbit_cameras(V, resolution=RES, device=device)
+    wv, fp, cc = cams["viewmatrix"].unsqueeze(1), cams["projmatrix"].unsqueeze(1), cams["campos"].unsqueeze(1)
+    bg = torch.zeros(1, 3, device=device)
+    frames = torch.empty((V, 3, RES, RES), dtype=torch.float32, device=device)
+    host = torch.empty((V, 3, RES, RES), dtype=torch.float32).pin_memory()
+
+    def step_device():          # frames stay on the device
+        with torch.no_grad():
+            for th in range(V):
+                o = f3d.render_predicted_more_v2_gof(pc, 0, wv[th:th + 1].contiguous(), fp[th:th + 1].contiguous(), cc[th:th + 1].contiguous(), bg, cfg)
+                frames[th] = o["render"]
+
+    def step_reference():       # as the reference: every frame goes to the host before the next call (visualize.py:400)
+        with torch.no_grad():
+            for th in range(V):
+                o = f3d.render_predicted_more_v2_gof(pc, 0, wv[th:th + 1].contiguous(), fp[th:th + 1].contiguous(), cc[th:th + 1].contiguous(), bg, cfg)
+                host[th] = o["render"].reshape(3, RES, RES).cpu()
+
+    sync = lambda: torch.cuda.synchronize()
+    # the rasterizer alone, same arguments (f3dg_forward_batched with one view): what the wrapper adds is the difference
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
+    out1 = torch.empty((1, 9, RES, RES), dtype=torch.float32, device=device)
+    rad1 = torch.empty((1, P), dtype=torch.int32, device=device)
+    _, _, ws = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"][:1], cams["projmatrix"][:1], cams["campos"][:1], bg[0],
+                                   image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs,
+                                   scales=g["scaling"], rotations=g["rotation"], sh_degree=1, out=out1, radii=rad1)
+
+    def step_raster():
+        for th in range(V):
+            f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"][th:th + 1], cams["projmatrix"][th:th + 1], cams["campos"][th:th + 1],
+                                bg[0], image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs,
+                                scales=g["scaling"], rotations=g["rotation"], sh_degree=1, workspace=ws, out=out1, radii=rad1, check=False)
+
+    e_ras = timed(step_raster, sync, args.warmup, args.steps)
+    timed(step_device, sync, args.warmup, 0)
+    L.f3dg_profile_enable(1)
+    L.f3dg_debug_launch_count(1)
+    e_dev = timed(step_device, sync, 0, args.steps)
+    launches = int(L.f3dg_debug_launch_count(1))
+    L.f3dg_profile_enable(0)
+    st = (C.c_double * 5)()
+    nc = C.c_int(0)
+    _lib.check(L.f3dg_profile_collect(st, C.byref(nc)), "f3dg_profile_collect")
+    e_ref = timed(step_reference, sync, 1, args.steps)      # (last: the blocking pageable copies leave the process in a slower state)
+    if rank != 0:
+        return None
+    n = V * args.steps
+    calls = max(int(nc.value), 1)
+    return {
+        "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)", "value": n / e_dev, "unit": "views/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * e_dev / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "drop-in: render_predicted_more_v2_gof one view per call (the reference's loop, visualize.py:387-416), %d Gaussians "
+                               "(sigma0=%g), %d calls per step @%dx%d, frames left on the device" % (P, args.sigma0, V, RES, RES),
+                   "gaussians": P, "views": V, "resolution": RES, "kernel_launches_per_call": launches / float(calls)},
+        "us_per_call": {"wrapper, frames on the device (= value)": 1e6 * e_dev / n,
+                        "wrapper + .cpu() of every frame before the next call (the reference's loop)": 1e6 * e_ref / n,
+                        "rasterizer alone (f3dg_forward_batched, one view, no host sync)": 1e6 * e_ras / n,
+                        "rasterizer stages per call (HIP events)": {"preprocess": 1e3 * st[0] / calls, "binning": 1e3 * st[1] / calls,
+                                                                     "compositing": 1e3 * st[2] / calls}},
+    }
 
 
 # ---------------------------------------------------------------------------------------------------------------- C5

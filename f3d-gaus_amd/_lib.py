@@ -45,6 +45,7 @@ SIGNATURES = {
     "f3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
     "f3dg_splat_head": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _ll, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "f3dg_render_epilogue": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),
+    "f3dg_render_epilogue_view": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),
     "f3dg_cycle_inputs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "f3dg_pack_frames": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "f3dg_group_norm_silu": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),

@@ -89,6 +89,35 @@ splat_head_kernel(int HW, const float* __restrict__ net_out, const float* __rest
     unet_depth[o] = d;
 }
 
+// inverse of a 4x4 (row-major) by cofactors in float64, rounded to float32 (the camera-to-world matrix of the epilogue: one thread)
+__device__ void invert4x4(const float* m_, float* out)
+{
+    double m[16], inv[16];
+    for (int i = 0; i < 16; i++) m[i] = m_[i];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    const double r = 1.0 / det;
+    for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] * r);
+}
+
+// from_view: `c2w` holds the world_view matrices (row-vector convention, as the renderer receives them) and the kernel inverts their
+// transposes itself -- the caller saves a torch.linalg.inv (a solver call and several launches per one-view call)
+template <bool FROM_VIEW>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 epilogue_kernel(int H, int W, const float* __restrict__ raster, const float* __restrict__ c2w, float fx, float fy,
                 float* __restrict__ normal_world, float* __restrict__ depth_normal)
@@ -96,10 +125,20 @@ epilogue_kernel(int H, int W, const float* __restrict__ raster, const float* __r
     const int HW = H * W;
     const int n = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     const int v = blockIdx.y;
+    __shared__ float s_c2w[16];
+    if (FROM_VIEW) {
+        if (threadIdx.x == 0) {
+            float t[16];
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) t[4 * r + c] = c2w[16 * v + 4 * c + r];      // world_view^T
+            invert4x4(t, s_c2w);
+        }
+        __syncthreads();
+    }
     if (n >= HW) return;
     const int y = n / W, x = n % W;
     const float* ras = raster + (size_t)v * F3DG_OUT_CHANNELS * HW;
-    const float* Cw = c2w + 16 * v;     // row-major 4x4
+    const float* Cw = FROM_VIEW ? s_c2w : c2w + 16 * v;     // row-major 4x4
 
     if (normal_world) {
         const float a = ras[3 * HW + n], b = ras[4 * HW + n], c = ras[5 * HW + n];
@@ -198,7 +237,20 @@ extern "C" int f3dg_render_epilogue(void* stream, int n_views, int H, int W, con
     if (n_views <= 0 || H <= 0 || W <= 0 || !raster || !c2w) return F3DG_ERR_BAD_ARG;
     if (!normal_world && !depth_normal) return F3DG_OK;
     dim3 grid((unsigned)(((long long)H * W + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)n_views);
-    F3DG_KLAUNCH(epilogue_kernel, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, H, W, raster, c2w, fx, fy,
+    F3DG_KLAUNCH(epilogue_kernel<false>, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, H, W, raster, c2w, fx, fy,
+                       normal_world, depth_normal);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+extern "C" int f3dg_render_epilogue_view(void* stream, int n_views, int H, int W, const float* raster,
+                                         const float* world_view, float fx, float fy,
+                                         float* normal_world, float* depth_normal)
+{
+    if (n_views <= 0 || H <= 0 || W <= 0 || !raster || !world_view) return F3DG_ERR_BAD_ARG;
+    if (!normal_world && !depth_normal) return F3DG_OK;
+    dim3 grid((unsigned)(((long long)H * W + F3DG_BLOCK - 1) / F3DG_BLOCK), (unsigned)n_views);
+    F3DG_KLAUNCH(epilogue_kernel<true>, grid, dim3(F3DG_BLOCK), 0, (hipStream_t)stream, H, W, raster, world_view, fx, fy,
                        normal_world, depth_normal);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

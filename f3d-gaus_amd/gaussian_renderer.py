@@ -32,15 +32,18 @@ def _epilogue(raster, world_view, W, H, FoVx, FoVy, want_normal=True, want_depth
     """raster [V,9,H,W], world_view [V,4,4] (row-vector convention). Returns (normal_world, depth_normal) [V,3,H,W]."""
     V = raster.shape[0]
     device = raster.device
-    c2w = torch.linalg.inv(world_view.reshape(V, 4, 4).transpose(1, 2)).contiguous().float()
+    wv = world_view.reshape(V, 16)
+    if wv.dtype != torch.float32 or not wv.is_contiguous():
+        wv = wv.float().contiguous()
     fx = W / (2 * math.tan(FoVx / 2.))
     fy = H / (2 * math.tan(FoVy / 2.))
     nw = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_normal else None
     dn = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_depth_normal else None
     raster = raster.contiguous()
-    rc = _lib.lib().f3dg_render_epilogue(_stream(), V, H, W, _lib.ptr(raster), _lib.ptr(c2w), float(fx), float(fy),
-                                         _lib.ptr(nw), _lib.ptr(dn))
-    _lib.check(rc, "f3dg_render_epilogue")
+    # (c2w = inverse(world_view^T) is formed inside the kernel: no torch.linalg.inv per call)
+    rc = _lib.lib().f3dg_render_epilogue_view(_stream(), V, H, W, _lib.ptr(raster), _lib.ptr(wv), float(fx), float(fy),
+                                              _lib.ptr(nw), _lib.ptr(dn))
+    _lib.check(rc, "f3dg_render_epilogue_view")
     return nw, dn
 
 
@@ -98,16 +101,37 @@ def depth_to_normal(world_view_transform, image_width, image_height, FoVx, FoVy,
     return dn[0].permute(1, 2, 0)
 
 
+_SH_CACHE = {}
+
+
+def _cat_sh(dc, rest):
+    """cat(features_dc, features_rest) along the coefficient axis. The reference concatenates on every call (gr.py:1008); its loops
+    render the same Gaussians from many cameras (visualize.py:387-416), so in inference the result is kept for as long as both inputs
+    are the same, unmodified tensors (storage address, shape and in-place version counter)."""
+    if torch.is_grad_enabled() and (dc.requires_grad or rest.requires_grad):
+        return torch.cat([dc, rest], dim=1).contiguous()
+    key = (dc.data_ptr(), rest.data_ptr(), tuple(dc.shape), tuple(rest.shape), dc._version, rest._version, dc.device)
+    hit = _SH_CACHE.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    shs = torch.cat([dc, rest], dim=1).contiguous()
+    _SH_CACHE["k"] = (key, shs, dc, rest)       # (keeps the inputs alive so that their addresses cannot be reused)
+    return shs
+
+
 def _render_one(get, bs, world_view_transform, full_proj_transform, camera_center, bg_color, cfg, kernel_size,
                 scaling_modifier, override_color, points3D=None):
     xyz = get("xyz")
     device = xyz.device
     # zero tensor whose gradient receives the screen-space mean gradients (reference :932-936)
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    else:       # inference: nothing will ever flow into it
+        screenspace_points = torch.zeros_like(xyz)
 
     tanfovx = math.tan(cfg['model']['fov'] * np.pi / 360)
     tanfovy = math.tan(cfg['model']['fov'] * np.pi / 360)
@@ -141,7 +165,7 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
             opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None, view2gaussian_precomp=None)
         extra = {"alpha_integrated": alpha_integrated, "color_integrated": color_integrated}
     elif override_color is None:
-        shs = torch.cat([get("features_dc"), get("features_rest")], dim=1).contiguous()
+        shs = _cat_sh(get("features_dc"), get("features_rest"))
         rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None,
                                            opacities=opacity, scales=scales, rotations=rotations,
                                            cov3D_precomp=None, view2gaussian_precomp=None)

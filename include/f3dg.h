@@ -221,6 +221,11 @@ int f3dg_splat_head(void* stream, int B, int H, int W, const float* net_out, con
 int f3dg_render_epilogue(void* stream, int n_views, int H, int W, const float* raster,
                          const float* c2w, float fx, float fy,
                          float* normal_world, float* depth_normal);
+/* The same from the world_view matrices themselves ([n_views,16], row-vector convention, as render_predicted_more_v2_gof receives
+ * them): every workgroup inverts world_view^T in float64 (cofactors), so the caller needs no matrix inverse per call. */
+int f3dg_render_epilogue_view(void* stream, int n_views, int H, int W, const float* raster,
+                              const float* world_view, float fx, float fy,
+                              float* normal_world, float* depth_normal);
 
 /* 8-bit RGB frames for the video writer and the multi-GPU gather: dst [n_frames,H,W,3] uint8 =
  * (uint8)(255 * clamp(src[:, 0:3], 0, 1)) with src [n_frames,src_channels,H,W] float32 planar (src_channels = 9 for the

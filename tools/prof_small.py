@@ -57,4 +57,9 @@ if mode == "sites":
     torch.cuda.synchronize()
     L.f3dg_debug_launch_times(1)
     L.f3dg_set_option(b"time_launches", 0)
-print(f"P={P} V={V} {mode}: host issue {t_issue / n * 1e6:.0f} us/call, wall {t_wall / n * 1e6:.0f} us/call")
+from f3dgaus_amd import _lib as _l
+_l.lib().f3dg_debug_launch_count(1)
+run()
+torch.cuda.synchronize()
+print(f"P={P} V={V} {mode}: host issue {t_issue / n * 1e6:.0f} us/call, wall {t_wall / n * 1e6:.0f} us/call, "
+      f"{_l.lib().f3dg_debug_launch_count(1)} kernel launches per call -> {V * n / t_wall:.0f} views/s")
