@@ -42,6 +42,10 @@ SIGNATURES = {
     "f3dg_integrate_prepare": (_ll, [_p, _p, _sz, _ll, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
                                      _p, _f, _f, _f, _p, _p, C.POINTER(_ll)]),
     "f3dg_integrate_points": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p]),
+    "f3dg_integrate_workspace_bytes_batched": (_sz, [_i, _i, _i, _i, _i, _ll]),
+    "f3dg_integrate_prepare_batched": (_ll, [_p, _p, _sz, _ll, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
+                                             _p, _f, _f, _f, _p, _p, C.POINTER(_ll)]),
+    "f3dg_integrate_points_view": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p]),
     "f3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
     "f3dg_splat_head": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _ll, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "f3dg_render_epilogue": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),

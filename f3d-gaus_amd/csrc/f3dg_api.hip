@@ -415,6 +415,52 @@ extern "C" size_t f3dg_integrate_workspace_bytes(int P, int PN, int W, int H, lo
     return f3dg_integ_layout(P, PN, W, H, max_rendered).total;
 }
 
+extern "C" size_t f3dg_integrate_workspace_bytes_batched(int P, int PN, int W, int H, int n_views, long long max_rendered)
+{
+    if (P < 0 || PN < 0 || W <= 0 || H <= 0 || n_views <= 0 || max_rendered < 0) return 0;
+    return f3dg_integ_layout(P, PN, W, H, max_rendered, n_views).total;
+}
+
+extern "C" long long f3dg_integrate_prepare_batched(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                                    int n_views, int PN_max, int P, int D, int M, const float* background, int W, int H,
+                                                    const float* means3D, const float* shs, const float* colors_precomp,
+                                                    const float* opacities, const float* scales, float scale_modifier,
+                                                    const float* rotations, const float* cov3D_precomp,
+                                                    const float* view2gaussian_precomp, const float* viewmatrix,
+                                                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                                    float kernel_size, float* out_color, int* radii, long long* h_needed)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n_views <= 0 || PN_max < 0 || P <= 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace || !background)
+        return F3DG_ERR_BAD_ARG;
+    if (max_rendered > 0xFFFFFFF0ll || (long long)n_views * P > 0xFFFFFFF0ll || P > (int)F3DG_ID_MASK) return F3DG_ERR_BAD_ARG;
+    const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
+    const F3dgIntegLayout I = f3dg_integ_layout(P, PN_max, W, H, max_rendered, n_views);
+    if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
+    if (h_needed) *h_needed = 0;
+    const F3dgHeaderInit hinit = { hdr, (unsigned)max_rendered, 0u, 0u, 0u, { (unsigned)P, (unsigned)n_views, (unsigned)W, (unsigned)H } };
+    int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                 view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
+    if (rc != F3DG_OK) return rc;
+    const float focal_y = H / (2.0f * tan_fovy);           // rasterizer_impl.cu:567-568
+    const float focal_x = W / (2.0f * tan_fovx);
+    int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
+    rc = run_geometry(s, ws, L, n_views, n_views, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                      rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, 1 /* pass 1 culls by the box */,
+                      0 /* the points of a tile are not its pixel centres: the reference's tile lists */, nullptr, hinit);
+    if (rc != F3DG_OK) return rc;
+    rc = f3dg_launch_integrate_pass1(s, n_views, P, W, H, focal_x, focal_y, L, I, ws, background, out_color);
+    if (rc != F3DG_OK) return rc;
+    long long n = 0;
+    rc = f3dg_read_status(stream, workspace, &n);
+    if (h_needed) *h_needed = n;
+    if (rc != F3DG_OK) return rc;
+    return n;
+}
+
 extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
                                             int PN_max, int P, int D, int M, const float* background, int W, int H,
                                             const float* means3D, const float* shs, const float* colors_precomp,
@@ -424,35 +470,30 @@ extern "C" long long f3dg_integrate_prepare(void* stream, void* workspace, size_
                                             const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                                             float kernel_size, float* out_color, int* radii, long long* h_needed)
 {
+    return f3dg_integrate_prepare_batched(stream, workspace, workspace_bytes, max_rendered, 1, PN_max, P, D, M, background, W, H, means3D,
+                                          shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                                          view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size,
+                                          out_color, radii, h_needed);
+}
+
+extern "C" int f3dg_integrate_points_view(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                          int n_views, int view, int PN, int P, int W, int H, const float* points3D,
+                                          const float* viewmatrix, float tan_fovx, float tan_fovy, float* out_color,
+                                          float* out_alpha_integrated, float* out_color_integrated, float* alpha_min)
+{
     hipStream_t s = (hipStream_t)stream;
-    if (PN_max < 0 || P <= 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace || !background)
+    if (PN < 0 || P <= 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace || !viewmatrix || n_views <= 0 ||
+        view < 0 || view >= n_views)
         return F3DG_ERR_BAD_ARG;
-    if (max_rendered > 0xFFFFFFF0ll) return F3DG_ERR_BAD_ARG;
-    const F3dgLayout L = f3dg_layout(P, W, H, 1, max_rendered);
-    const F3dgIntegLayout I = f3dg_integ_layout(P, PN_max, W, H, max_rendered);
+    if (PN == 0) return F3DG_OK;
+    if (!points3D) return F3DG_ERR_BAD_ARG;
+    const F3dgLayout L = f3dg_layout(P, W, H, n_views, max_rendered);
+    const F3dgIntegLayout I = f3dg_integ_layout(P, PN, W, H, max_rendered, n_views);
     if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
-    char* ws = static_cast<char*>(workspace);
-    F3dgHeader* hdr = reinterpret_cast<F3dgHeader*>(ws + L.header);
-    if (h_needed) *h_needed = 0;
-    const F3dgHeaderInit hinit = { hdr, (unsigned)max_rendered, 0u, 0u, 0u, { (unsigned)P, 1u, (unsigned)W, (unsigned)H } };
-    int rc = check_gaussian_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                 view2gaussian_precomp, viewmatrix, projmatrix, cam_pos);
-    if (rc != F3DG_OK) return rc;
-    const float focal_y = H / (2.0f * tan_fovy);           // rasterizer_impl.cu:567-568
+    const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
-    int* radii_used = radii ? radii : reinterpret_cast<int*>(ws + L.radii);
-    rc = run_geometry(s, ws, L, 1, 1, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
-                      rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                      tan_fovy, focal_x, focal_y, kernel_size, radii_used, 0, 1 /* pass 1 culls by the box */,
-                      0 /* the points of a tile are not its pixel centres: the reference's tile lists */, nullptr, hinit);
-    if (rc != F3DG_OK) return rc;
-    rc = f3dg_launch_integrate_pass1(s, W, H, focal_x, focal_y, L, I, ws, background, out_color);
-    if (rc != F3DG_OK) return rc;
-    long long n = 0;
-    rc = f3dg_read_status(stream, workspace, &n);
-    if (h_needed) *h_needed = n;
-    if (rc != F3DG_OK) return rc;
-    return n;
+    return f3dg_launch_integrate_points(s, view, P, PN, W, H, focal_x, focal_y, L, I, static_cast<char*>(workspace), points3D,
+                                        viewmatrix, out_color, out_alpha_integrated, out_color_integrated, alpha_min);
 }
 
 extern "C" int f3dg_integrate_points(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
@@ -460,18 +501,8 @@ extern "C" int f3dg_integrate_points(void* stream, void* workspace, size_t works
                                      float tan_fovx, float tan_fovy, float* out_color, float* out_alpha_integrated,
                                      float* out_color_integrated, float* alpha_min)
 {
-    hipStream_t s = (hipStream_t)stream;
-    if (PN < 0 || P <= 0 || W <= 0 || H <= 0 || max_rendered < 0 || !out_color || !workspace || !viewmatrix)
-        return F3DG_ERR_BAD_ARG;
-    if (PN == 0) return F3DG_OK;
-    if (!points3D) return F3DG_ERR_BAD_ARG;
-    const F3dgLayout L = f3dg_layout(P, W, H, 1, max_rendered);
-    const F3dgIntegLayout I = f3dg_integ_layout(P, PN, W, H, max_rendered);
-    if (workspace_bytes < I.total) return F3DG_ERR_WORKSPACE;
-    const float focal_y = H / (2.0f * tan_fovy);
-    const float focal_x = W / (2.0f * tan_fovx);
-    return f3dg_launch_integrate_points(s, PN, W, H, focal_x, focal_y, L, I, static_cast<char*>(workspace), points3D,
-                                        viewmatrix, out_color, out_alpha_integrated, out_color_integrated, alpha_min);
+    return f3dg_integrate_points_view(stream, workspace, workspace_bytes, max_rendered, 1, 0, PN, P, W, H, points3D, viewmatrix, tan_fovx,
+                                      tan_fovy, out_color, out_alpha_integrated, out_color_integrated, alpha_min);
 }
 
 extern "C" long long f3dg_integrate(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,

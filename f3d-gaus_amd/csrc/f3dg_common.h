@@ -122,7 +122,7 @@ struct F3dgIntegLayout {
     size_t total;
     unsigned scan_tmp_elems;
 };
-F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap);
+F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap, int V = 1);   // V cameras prepared together
 
 // every kernel launch of the library goes through this macro: f3dg_debug_launch_count reports how many a call sequence issued
 extern unsigned long long g_f3dg_kernel_launches;
@@ -205,8 +205,8 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
 
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated);
-int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+int f3dg_launch_integrate_pass1(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
                                 const F3dgIntegLayout& I, char* ws, const float* background, float* out_color);
-int f3dg_launch_integrate_points(hipStream_t s, int PN, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+int f3dg_launch_integrate_points(hipStream_t s, int view, int P, int PN, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
                                  const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
                                  float* out_color, float* out_alpha_integrated, float* out_color_integrated, float* alpha_min);

@@ -257,7 +257,7 @@ integrate_pass1_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, 
 // is scaled uniformly about its centre by 1 + 0.7072 px / semi-minor axis, which contains its Minkowski sum with that square
 // (a >= b: (a + r, b + r) fits inside (a, b) (b + r) / b). As everywhere, this only removes pairs the reference `continue`s on.
 __global__ void __launch_bounds__(F3DG_BLOCK)
-integrate_pass1_cull_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
+integrate_pass1_cull_kernel(int V, int P, int T, int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
                             const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
                             const F3dgRec* __restrict__ rec, const float4* __restrict__ cull,
                             const float* __restrict__ background, float* __restrict__ out_color,
@@ -265,7 +265,16 @@ integrate_pass1_cull_kernel(int W, int H, int tiles_x, float focal_x, float foca
                             unsigned short* __restrict__ contrib_ids, unsigned* __restrict__ contrib_n)
 {
     constexpr int ROUND = F3DG_BLOCK;             // staged entries per round (byte indices 0..255)
-    const unsigned tile = blockIdx.x;
+    // several cameras of the same Gaussians in one launch (f3dg_integrate_prepare_batched): one 256^2 camera is 256 workgroups,
+    // a wave per SIMD and nothing to overlap its latencies with; every per-camera array is the camera's slice of a [V, ...] array
+    unsigned view, tile;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, (unsigned)T, view, tile);
+    {
+        const size_t HWv = (size_t)H * W;
+        ranges += (size_t)view * T; rec += (size_t)view * P; cull += (size_t)view * P;
+        out_color += (size_t)view * F3DG_OUT_CHANNELS * HWv; final_T += (size_t)view * 4 * HWv; n_contrib += (size_t)view * 2 * HWv;
+        contrib_ids += (size_t)view * HWv * F3DG_MAX_CONTRIB; contrib_n += (size_t)view * HWv;
+    }
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned grp = lane >> 4, gi = lane & 15u;
@@ -629,10 +638,10 @@ __global__ void integrate_fill_kernel(size_t HW, size_t PN, float* __restrict__ 
 
 } // namespace
 
-F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap)
+F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap, int V)
 {
     F3dgIntegLayout I;
-    const F3dgLayout L = f3dg_layout(P, W, H, 1, cap);
+    const F3dgLayout L = f3dg_layout(P, W, H, V, cap);
     const size_t HW = (size_t)W * H;
     const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
     size_t off = (L.total + 255) & ~(size_t)255;
@@ -640,8 +649,8 @@ F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap)
     I.pix_points = take(HW * sizeof(unsigned));                       // pix_points and tile_last are cleared together
     I.tile_last = take(T * sizeof(unsigned long long));
     I.clear_bytes = off - I.pix_points;
-    I.contrib_n = take(HW * sizeof(unsigned));
-    I.contrib_ids = take(HW * F3DG_MAX_CONTRIB * sizeof(unsigned short));
+    I.contrib_n = take((size_t)V * HW * sizeof(unsigned));                            // per camera
+    I.contrib_ids = take((size_t)V * HW * F3DG_MAX_CONTRIB * sizeof(unsigned short));   // per camera
     const size_t PNn = (size_t)(PN > 0 ? PN : 1);
     I.pix_start = take(HW * sizeof(unsigned));
     I.scan_tmp_elems = (unsigned)((HW + F3DG_SCAN_CHUNK - 1) / F3DG_SCAN_CHUNK + 1);
@@ -664,11 +673,12 @@ int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_c
 
 // pass 1: depends on the Gaussians and the camera only (not on the points), so its result -- colours, last contributors and
 // the per-pixel contributor table inside the workspace -- can be kept and reused for any number of point sets
-int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+int f3dg_launch_integrate_pass1(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
                                 const F3dgIntegLayout& I, char* ws, const float* background, float* out_color)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
+    const size_t HW = (size_t)W * H;
     const F3dgHeader* hdr = reinterpret_cast<const F3dgHeader*>(ws + L.header);
     const uint2* ranges = reinterpret_cast<const uint2*>(ws + L.ranges);
     const unsigned* point_list = reinterpret_cast<const unsigned*>(ws + L.vals[0]);
@@ -678,36 +688,44 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int W, int H, float focal_x, floa
     unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
     unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
     if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 2)
-        F3DG_KLAUNCH(integrate_pass1_cull_kernel, dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+        F3DG_KLAUNCH(integrate_pass1_cull_kernel, dim3((unsigned)V * (unsigned)T), dim3(F3DG_BLOCK), 0, s, V, P, T, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n);
-    else if (g_f3dg_render_pretest && g_f3dg_render_cull)          // round 1's version: per-ray pre-test + block masks from the boxes
-        F3DG_KLAUNCH((integrate_pass1_kernel<true>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
-                           hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
-                           out_color, final_T, n_contrib, contrib_ids, contrib_n);
     else
-        F3DG_KLAUNCH((integrate_pass1_kernel<false>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
-                           hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.bbox), background,
-                           out_color, final_T, n_contrib, contrib_ids, contrib_n);
+        for (int v = 0; v < V; v++) {       // the A/B variants of the tests: one camera per launch
+            const float4* bbox = reinterpret_cast<const float4*>(ws + L.bbox) + (size_t)v * P;
+            if (g_f3dg_render_pretest && g_f3dg_render_cull)          // round 1's version: per-ray pre-test + block masks from the boxes
+                F3DG_KLAUNCH((integrate_pass1_kernel<true>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+                                   hdr, ranges + (size_t)v * T, point_list, rec + (size_t)v * P, bbox, background,
+                                   out_color + (size_t)v * F3DG_OUT_CHANNELS * HW, final_T + (size_t)v * 4 * HW, n_contrib + (size_t)v * 2 * HW,
+                                   contrib_ids + (size_t)v * HW * F3DG_MAX_CONTRIB, contrib_n + (size_t)v * HW);
+            else
+                F3DG_KLAUNCH((integrate_pass1_kernel<false>), dim3(T), dim3(F3DG_BLOCK), 0, s, W, H, tiles_x, focal_x, focal_y,
+                                   hdr, ranges + (size_t)v * T, point_list, rec + (size_t)v * P, bbox, background,
+                                   out_color + (size_t)v * F3DG_OUT_CHANNELS * HW, final_T + (size_t)v * 4 * HW, n_contrib + (size_t)v * 2 * HW,
+                                   contrib_ids + (size_t)v * HW * F3DG_MAX_CONTRIB, contrib_n + (size_t)v * HW);
+        }
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
 
 // the point stage against a prepared workspace: counting sort by pixel (bin, scan, perm), integration in pixel order,
 // points-per-pixel epilogue. Any of the three outputs may be null.
-int f3dg_launch_integrate_points(hipStream_t s, int PN, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
+int f3dg_launch_integrate_points(hipStream_t s, int view, int P, int PN, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,
                                  const F3dgIntegLayout& I, char* ws, const float* points3D, const float* viewmatrix,
                                  float* out_color, float* out_alpha_integrated, float* out_color_integrated, float* alpha_min)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
+    const size_t HWv = (size_t)W * H;
     const F3dgHeader* hdr = reinterpret_cast<const F3dgHeader*>(ws + L.header);
-    const uint2* ranges = reinterpret_cast<const uint2*>(ws + L.ranges);
+    // camera `view` of a batched preparation: its slice of every per-camera array (the instance list is shared, the ranges index it)
+    const uint2* ranges = reinterpret_cast<const uint2*>(ws + L.ranges) + (size_t)view * T;
     const unsigned* point_list = reinterpret_cast<const unsigned*>(ws + L.vals[0]);
-    const F3dgRec* rec = reinterpret_cast<const F3dgRec*>(ws + L.rec);
-    const unsigned* n_contrib = reinterpret_cast<const unsigned*>(ws + L.n_contrib);
-    const unsigned short* contrib_ids = reinterpret_cast<const unsigned short*>(ws + I.contrib_ids);
-    const unsigned* contrib_n = reinterpret_cast<const unsigned*>(ws + I.contrib_n);
+    const F3dgRec* rec = reinterpret_cast<const F3dgRec*>(ws + L.rec) + (size_t)view * P;
+    const unsigned* n_contrib = reinterpret_cast<const unsigned*>(ws + L.n_contrib) + (size_t)view * 2 * HWv;
+    const unsigned short* contrib_ids = reinterpret_cast<const unsigned short*>(ws + I.contrib_ids) + (size_t)view * HWv * F3DG_MAX_CONTRIB;
+    const unsigned* contrib_n = reinterpret_cast<const unsigned*>(ws + I.contrib_n) + (size_t)view * HWv;
     unsigned* pix_points = reinterpret_cast<unsigned*>(ws + I.pix_points);
     unsigned long long* tile_last = reinterpret_cast<unsigned long long*>(ws + I.tile_last);
     unsigned* pix_start = reinterpret_cast<unsigned*>(ws + I.pix_start);

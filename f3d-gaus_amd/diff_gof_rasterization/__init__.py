@@ -388,10 +388,59 @@ class PreparedIntegration:
     (MI355X-first: ~0.25 GB per camera at 589,824 Gaussians / 256^2, so the 129 cameras of a mesh-extraction sweep stay
     resident in the 288 GB of HBM instead of being recomputed for each of its 9 point sets.)"""
 
-    def __init__(self, buffer, capacity, max_points, P, W, H, tanfovx, tanfovy, viewmatrix, color, radii, num_rendered):
+    def __init__(self, buffer, capacity, max_points, P, W, H, tanfovx, tanfovy, viewmatrix, color, radii, num_rendered,
+                 n_views=1, view=0):
         self.buffer, self.capacity, self.max_points, self.P, self.W, self.H = buffer, capacity, max_points, P, W, H
         self.tanfovx, self.tanfovy, self.viewmatrix = tanfovx, tanfovy, viewmatrix
         self.color, self.radii, self.num_rendered = color, radii, num_rendered
+        self.n_views, self.view = n_views, view       # camera `view` of `n_views` prepared together in `buffer` (integrate_prepare_batched)
+
+
+def integrate_prepare_batched(means3D, sh, colors_precomp, opacities, scales, rotations, viewmatrices, projmatrices, camposs, bg, *,
+                              image_height, image_width, tanfovx, tanfovy, sh_degree, max_points, scale_modifier=1.0, kernel_size=0.0):
+    """``f3dg_integrate_prepare_batched``: projection + binning + per-pixel pass of ``integrate`` for V cameras of the same Gaussians
+    in ONE launch sequence (the per-pixel pass of one 256^2 camera is 256 workgroups: a wave per SIMD). Returns a list of V
+    ``PreparedIntegration`` sharing one workspace; each is bit-identical to ``integrate_prepare`` of its camera."""
+    L = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("f3dgaus_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
+    if means3D.ndim != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    with torch.no_grad():
+        P = means3D.size(0)
+        if P == 0:
+            raise RuntimeError("integrate_prepare needs at least one Gaussian")
+        H, W = int(image_height), int(image_width)
+        means3D_, sh, colors_precomp = _dev_f32(means3D, device), _dev_f32(sh, device), _dev_f32(colors_precomp, device)
+        opacities_, scales, rotations = _dev_f32(opacities, device), _dev_f32(scales, device), _dev_f32(rotations, device)
+        vm = _dev_f32(viewmatrices, device).reshape(-1, 16).clone()
+        V = vm.size(0)
+        pm = _dev_f32(projmatrices, device).reshape(V, 16)
+        cp = _dev_f32(camposs, device).reshape(V, 3)
+        bgt = _dev_f32(bg, device).reshape(-1)[:3].contiguous()
+        M = 0 if sh is None else (sh.size(1) if sh.ndim == 3 else sh.numel() // (3 * max(P, 1)))
+        color = torch.empty((V, 9, H, W), dtype=torch.float32, device=device)
+        radii = torch.zeros((V, P), dtype=torch.int32, device=device)
+        cap = V * _initial_capacity(P, W, H, 1)
+        while True:
+            nbytes = L.f3dg_integrate_workspace_bytes_batched(P, int(max_points), W, H, V, cap)
+            if nbytes == 0:
+                raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_integrate_workspace_bytes_batched")
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            needed = C.c_longlong(0)
+            rc = L.f3dg_integrate_prepare_batched(
+                _stream(), C.c_void_p(buf.data_ptr()), buf.numel(), cap, V, int(max_points), P, int(sh_degree), int(M),
+                _lib.ptr(bgt), W, H, _lib.ptr(means3D_), _lib.ptr(sh), _lib.ptr(colors_precomp), _lib.ptr(opacities_),
+                _lib.ptr(scales), float(scale_modifier), _lib.ptr(rotations), None, None, _lib.ptr(vm), _lib.ptr(pm), _lib.ptr(cp),
+                float(tanfovx), float(tanfovy), float(kernel_size), _lib.ptr(color), _lib.ptr(radii), C.byref(needed))
+            if rc == _lib.ERR_OVERFLOW:
+                cap = int(needed.value * 1.25) + 1024
+                continue
+            _lib.check(rc, "f3dg_integrate_prepare_batched")
+            _CAP_HINT[(P, W, H, 1)] = max(int(rc / V * 1.5) + 1024, 1 << 14)
+            return [PreparedIntegration(buf, cap, int(max_points), P, W, H, float(tanfovx), float(tanfovy), vm[v], color[v], radii[v],
+                                        int(rc), n_views=V, view=v) for v in range(V)]
 
 
 def integrate_prepare(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp,
@@ -468,8 +517,8 @@ def integrate_points(prepared, points3D, alpha_min=None, want_outputs=True):
         if alpha_min is not None and (alpha_min.dtype != torch.float32 or not alpha_min.is_contiguous() or alpha_min.numel() != PN
                                       or alpha_min.device != device):
             raise RuntimeError("alpha_min must be a contiguous float32 tensor of PN elements on the same device")
-        rc = _lib.lib().f3dg_integrate_points(
-            _stream(), C.c_void_p(pr.buffer.data_ptr()), pr.buffer.numel(), pr.capacity, PN, pr.P, pr.W, pr.H, _lib.ptr(pts),
+        rc = _lib.lib().f3dg_integrate_points_view(
+            _stream(), C.c_void_p(pr.buffer.data_ptr()), pr.buffer.numel(), pr.capacity, pr.n_views, pr.view, PN, pr.P, pr.W, pr.H, _lib.ptr(pts),
             _lib.ptr(pr.viewmatrix), pr.tanfovx, pr.tanfovy, _lib.ptr(pr.color), _lib.ptr(ai), _lib.ptr(ci), _lib.ptr(alpha_min))
         _lib.check(rc, "f3dg_integrate_points")
     return ai, ci

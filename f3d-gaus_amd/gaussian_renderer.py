@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF, _stream,
-                                     integrate_points, integrate_prepare, rasterize_views)
+                                     integrate_points, integrate_prepare, integrate_prepare_batched, rasterize_views)
 
 
 def focal2fov(focal, pixels):
@@ -228,7 +228,7 @@ class AlphaSweep:
     """
 
     def __init__(self, pc: dict, bs, world_view_transforms, full_proj_transforms, camera_centers, bg_color, cfg, max_points,
-                 kernel_size=0.0, scaling_modifier=1.0, override_color=None, streams=4):
+                 kernel_size=0.0, scaling_modifier=1.0, override_color=None, streams=4, cameras_per_call=16):
         get = lambda k: pc[k][bs]
         xyz = get("xyz")
         tanfov = math.tan(cfg['model']['fov'] * np.pi / 360)
@@ -239,58 +239,22 @@ class AlphaSweep:
         fp = full_proj_transforms.reshape(-1, 4, 4)
         cc = camera_centers.reshape(-1, 3)
         opacity, scaling, rotation = get("opacity"), get("scaling"), get("rotation")
-        empty = torch.empty((0,), device=xyz.device)
-
-        def prepare(v, buffer=None):
-            rs = GaussianRasterizationSettings_GOF(
-                image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, kernel_size=kernel_size,
-                subpixel_offset=empty, bg=bg_color, scale_modifier=scaling_modifier,
-                viewmatrix=wv[v], projmatrix=fp[v], sh_degree=cfg['model']['max_sh_degree'], campos=cc[v],
-                prefiltered=False, debug=False)
-            return integrate_prepare(xyz, shs, colors, opacity, scaling, rotation, None, None, rs, max_points, buffer=buffer)
-
+        # The cameras are prepared `cameras_per_call` at a time, each group in ONE launch sequence (f3dg_integrate_prepare_batched):
+        # the per-pixel pass of a single 256^2 camera is 256 workgroups, one wave per SIMD of an MI355X, so a camera alone is a chain
+        # of latencies; sixteen of them fill the chip. (Round 2 kept four cameras in flight from four host threads on four streams;
+        # `streams` is accepted and ignored.) A group shares one workspace: ~0.37 GB per camera at 589,824 Gaussians.
         V = wv.shape[0]
-        self.views = [prepare(0)]
-        n_streams = max(1, min(int(streams), V - 1))
-        if V == 1:
-            return
-        # The remaining cameras: ONE allocation for all their workspaces (a device allocation synchronises the whole device, and the
-        # per-pixel pass of one 256^2 camera is 256 workgroups = one wave per SIMD of an MI355X), sized like the first camera's plus
-        # a quarter; a camera that needs more allocates its own. The prepare call is blocking (it returns the instance count), so a
-        # few host threads, each on its own HIP stream, keep several cameras in flight (ctypes releases the GIL inside the call).
-        slot = (int(self.views[0].buffer.numel() * 1.25) + 255) // 256 * 256
-        self._pool = torch.empty((V - 1) * slot, dtype=torch.uint8, device=xyz.device)
-        carve = lambda v: self._pool[(v - 1) * slot:v * slot]
-        if n_streams == 1:
-            self.views += [prepare(v, carve(v)) for v in range(1, V)]
-            return
-        from concurrent.futures import ThreadPoolExecutor
-        main = torch.cuda.current_stream(xyz.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        pool = [torch.cuda.Stream(device=xyz.device) for _ in range(n_streams)]
-
-        def work(k):
-            out = []
-            torch.cuda.set_device(xyz.device)
-            with torch.cuda.stream(pool[k]):
-                pool[k].wait_event(ready)              # the Gaussians and the pool were produced on the caller's stream
-                for v in range(1 + k, V, n_streams):
-                    out.append((v, prepare(v, carve(v))))
-            return out
-
-        with ThreadPoolExecutor(max_workers=n_streams) as ex:
-            results = [r for part in ex.map(work, range(n_streams)) for r in part]
-        self.views += [p for _, p in sorted(results, key=lambda t: t[0])]
-        for st in pool:
-            main.wait_stream(st)
-        for p in self.views[1:]:                       # small tensors allocated on a side stream, used on the caller's from here on
-            for t in (p.buffer, p.color, p.radii, p.viewmatrix):
-                t.record_stream(main)
+        self.views = []
+        step = max(1, int(cameras_per_call))
+        for v0 in range(0, V, step):
+            self.views += integrate_prepare_batched(
+                xyz, shs, colors, opacity, scaling, rotation, wv[v0:v0 + step], fp[v0:v0 + step], cc[v0:v0 + step], bg_color,
+                image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, sh_degree=cfg['model']['max_sh_degree'],
+                max_points=max_points, scale_modifier=scaling_modifier, kernel_size=kernel_size)
 
     @property
     def nbytes(self):
-        return sum(v.buffer.numel() for v in self.views)
+        return sum(v.buffer.numel() for v in self.views if v.view == 0)
 
     def __call__(self, points3D):
         final_alpha = torch.ones((points3D.shape[0],), dtype=torch.float32, device=points3D.device)

@@ -192,6 +192,27 @@ int f3dg_integrate_points(void* stream, void* workspace, size_t workspace_bytes,
                           float tan_fovx, float tan_fovy, float* out_color, float* out_alpha_integrated,
                           float* out_color_integrated, float* alpha_min);
 
+/* The mesh extraction integrates its point sets through 129 cameras of the SAME Gaussians (visualize.py:449-505): n_views cameras
+ * prepared in ONE launch sequence (projection, binning and the per-pixel pass with grid = n_views x tiles: a single 256^2 camera is
+ * 256 workgroups, one wave per SIMD of an MI355X). viewmatrix / projmatrix [n_views,16], cam_pos [n_views,3], out_color
+ * [n_views,9,H,W], radii [n_views,P] or NULL; max_rendered is the capacity for the instances of all cameras together.
+ * Workspace: f3dg_integrate_workspace_bytes_batched. Every per-camera result is bit-identical to f3dg_integrate_prepare of that
+ * camera. Returns the total instance count or a negative error (BLOCKING, as f3dg_integrate_prepare). */
+size_t f3dg_integrate_workspace_bytes_batched(int P, int PN, int W, int H, int n_views, long long max_rendered);
+long long f3dg_integrate_prepare_batched(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                                         int n_views, int PN_max, int P, int D, int M, const float* background, int W, int H,
+                                         const float* means3D, const float* shs, const float* colors_precomp,
+                                         const float* opacities, const float* scales, float scale_modifier,
+                                         const float* rotations, const float* cov3D_precomp,
+                                         const float* view2gaussian_precomp, const float* viewmatrix,
+                                         const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                         float kernel_size, float* out_color, int* radii, long long* h_needed);
+/* One point set against camera `view` of a batched preparation (viewmatrix [16] and out_color [9,H,W] of THAT camera). */
+int f3dg_integrate_points_view(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
+                               int n_views, int view, int PN, int P, int W, int H, const float* points3D,
+                               const float* viewmatrix, float tan_fovx, float tan_fovy, float* out_color,
+                               float* out_alpha_integrated, float* out_color_integrated, float* alpha_min);
+
 /* present[i] = (view-space z of means3D[i] > 0.2), auxiliary.h:177-202. present is uint8 [P]. */
 int f3dg_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present);

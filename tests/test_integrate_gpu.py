@@ -151,3 +151,37 @@ def test_prepared_integration_and_alpha_sweep():
     assert abs(np.tan(cfg["model"]["fov"] * np.pi / 360) - scene["tanfovx"]) < 1e-12
     for k, pts in enumerate(sets):
         assert torch.equal(sweep(pts), loops[k]), k
+    # cameras prepared one per call and all in one call are the same bits
+    one = f3d.AlphaSweep(pc, 0, d(scene["viewmatrix"]), d(scene["projmatrix"]), d(scene["campos"]), d(scene["bg"]), cfg,
+                         max_points=9000, cameras_per_call=1)
+    assert len(one.views) == len(sweep.views) == 3 and sweep.views[0].buffer.data_ptr() == sweep.views[2].buffer.data_ptr()
+    assert torch.equal(one(sets[0]), sweep(sets[0]))
+    for a, b in zip(one.views, sweep.views):      # (after the same point set: channel 8 holds its points per pixel)
+        assert torch.equal(a.color, b.color) and torch.equal(a.radii, b.radii)
+
+
+def test_batched_prepare_many_cameras_full_size():
+    """f3dg_integrate_prepare_batched at the mesh extraction's size (589,824 Gaussians @256^2): 12 cameras in one launch sequence give
+    the per-pixel images, radii and point integrals of 12 single-camera preparations, bit for bit."""
+    from f3dgaus_amd import cameras, synthetic
+    from f3dgaus_amd.diff_gof_rasterization import integrate_points, integrate_prepare_batched
+    dev = torch.device("cuda:0")
+    P, V, RES, PN = 589824, 12, 256, 200000
+    g = synthetic.make_gaussians(P, s0=0.01, seed=3, device=dev)
+    oc = synthetic.orbit_cameras(V, resolution=RES, device=dev)
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
+    gen = torch.Generator().manual_seed(5)
+    pts = (g["xyz"][torch.randint(0, P, (PN,), generator=gen).to(dev)] + 0.03 * torch.randn(PN, 3, generator=gen).to(dev)).contiguous()
+    kw = dict(image_height=RES, image_width=RES, tanfovx=oc["tanfovx"], tanfovy=oc["tanfovy"], sh_degree=1, max_points=PN)
+    bg = torch.zeros(3, device=dev)
+    many = integrate_prepare_batched(g["xyz"], shs, None, g["opacity"], g["scaling"], g["rotation"], oc["viewmatrix"], oc["projmatrix"],
+                                     oc["campos"], bg, **kw)
+    assert len(many) == V
+    for v in (0, 5, 11):
+        single = integrate_prepare_batched(g["xyz"], shs, None, g["opacity"], g["scaling"], g["rotation"], oc["viewmatrix"][v:v + 1],
+                                           oc["projmatrix"][v:v + 1], oc["campos"][v:v + 1], bg, **kw)[0]
+        # (channel 8 is written by the point stage only: the points per pixel, forward.cu:1216)
+        assert torch.equal(single.color[:8], many[v].color[:8]) and torch.equal(single.radii, many[v].radii)
+        a1, c1 = integrate_points(single, pts)
+        a2, c2 = integrate_points(many[v], pts)
+        assert torch.equal(a1, a2) and torch.equal(c1, c2) and torch.equal(single.color, many[v].color)

@@ -73,11 +73,13 @@ for rep in range(2):                    # second repetition is timed (workspace 
         o = f3d.render_predicted_more_v2_gof_in(sets[0], pc, 0, oc["viewmatrix"][v], oc["projmatrix"][v], oc["campos"][v], bg, cfg)
         ref = torch.min(ref, o["alpha_integrated"])
     torch.cuda.synchronize(); t_loop = (time.perf_counter() - t0) / V
-for ns in (1, 4):                       # cameras prepared one after the other / four in flight (the default)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    sweep = f3d.AlphaSweep(pc, 0, oc["viewmatrix"], oc["projmatrix"], oc["campos"], bg, cfg, max_points=PN, streams=ns)
-    torch.cuda.synchronize(); t_prep = (time.perf_counter() - t0) / V
-    print(f"AlphaSweep of {V} cameras, streams={ns}: {t_prep * 1e3:.2f} ms per camera")
+for rep in range(2):
+    for k in (1, 4, 16):                # cameras prepared per launch sequence (f3dg_integrate_prepare_batched); 16 is the default
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sweep = f3d.AlphaSweep(pc, 0, oc["viewmatrix"], oc["projmatrix"], oc["campos"], bg, cfg, max_points=PN, cameras_per_call=k)
+        torch.cuda.synchronize(); t_prep = (time.perf_counter() - t0) / V
+        if rep:
+            print(f"AlphaSweep of {V} cameras, {k} per call: {t_prep * 1e3:.2f} ms per camera")
 a = sweep(sets[0]); torch.cuda.synchronize()
 assert torch.equal(a, ref)
 t0 = time.perf_counter()
