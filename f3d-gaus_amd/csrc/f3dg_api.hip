@@ -107,6 +107,7 @@ int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
+int g_f3dg_render_slide = 1;
 int g_f3dg_render_lds_pad = 0;
 int g_f3dg_bwd_occ = 4;
 int g_f3dg_render_round = 192;
@@ -124,6 +125,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = value == 5 ? 5 : value == 6 ? 6 : 4; return F3DG_OK; }
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
+    if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }

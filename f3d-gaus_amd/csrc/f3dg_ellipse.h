@@ -92,6 +92,37 @@ __device__ __forceinline__ void quad_ballots(int& lo, int& hi, float Ep, const f
     }
 }
 
+// Half-window variant (render3's sliding window): 32 entries, lanes e and e + 32 both hold entry e; lane e evaluates the pixels of
+// rows 0..3 (pixel P = 8 * row + column), lane e + 32 those of rows 4..7 (pixel P + 32) with its own dyy / cdy, so one comparison
+// carries both ballots: vcc_lo = entries reaching pixel P, vcc_hi = entries reaching pixel P + 32, each 32 bits wide.
+template <int P>
+__device__ __forceinline__ void half_ballots(int& m, float Ep, const float (&dxx)[8], const float (&adx)[8],
+                                             const float (&dyy)[4], const float (&cdy)[4], float eb)
+{
+    if constexpr (P < 31) {
+        float En;
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "v_fma_f32 %[en], %[eb], %[dy], %[ax]\n\t"
+            "v_fma_f32 %[en], %[dx], %[en], %[cy]\n\t"
+            "v_writelane_b32 %[m], vcc_lo, %[l0]\n\t"
+            "v_writelane_b32 %[m], vcc_hi, %[l1]"
+            : [m] "+v"(m), [en] "=&v"(En)
+            : [ep] "v"(Ep), [eb] "v"(eb), [dy] "v"(dyy[(P + 1) >> 3]), [ax] "v"(adx[(P + 1) & 7]), [dx] "v"(dxx[(P + 1) & 7]),
+              [cy] "v"(cdy[(P + 1) >> 3]), [l0] "n"(P), [l1] "n"(P + 32)
+            : "vcc");
+        half_ballots<P + 1>(m, En, dxx, adx, dyy, cdy, eb);
+    } else {
+        asm("v_cmp_ge_f32 vcc, 1.0, %[ep]\n\t"
+            "s_nop 1\n\t"
+            "v_writelane_b32 %[m], vcc_lo, %[l0]\n\t"
+            "v_writelane_b32 %[m], vcc_hi, %[l1]\n\t"
+            "s_nop 0"
+            : [m] "+v"(m)
+            : [ep] "v"(Ep), [l0] "n"(P), [l1] "n"(P + 32)
+            : "vcc");
+    }
+}
+
 // The same with a wave-level summary: `any` collects the OR of the 64 ballots, i.e. the mask of the window's entries that can reach
 // at least one pixel of the quadrant (the compositing backward walks entries in lock-step and skips the others outright).
 template <int P>

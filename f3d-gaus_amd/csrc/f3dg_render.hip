@@ -844,6 +844,186 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     }
 }
 
+// ---- render3 with a SLIDING window (the default) ----------------------------------------------------------------------------------
+// With fixed 64-entry windows every lane waits at the end of a window for the lane with the most passing entries: the CPU model
+// (tests/tools/wave1_model.py) puts the lane utilisation of phase 2 at 0.54. Here the 64 staged entries are two halves of 32; a slide
+// retires the older half -- which every live pixel has finished -- stages 32 new entries in its place and tests them (lanes e and
+// e + 32 share entry e and split the quadrant's rows: half_ballots), and phase 2 runs until the now-older half is finished by
+// everybody, pixels that are through with it already working on the newer half. Same LDS (4 KB of records), same phase-1 cost per
+// entry; the model gives 0.64 (15 % fewer phase-2 trips). Per pixel the sequence of blended entries is unchanged.
+template <bool SAVE_AUX, bool FAST, int OCC>
+__global__ void __launch_bounds__(64, OCC)
+render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x;
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const unsigned n = range.y - range.x;
+
+    __shared__ float4 sR[4][F3DG_R3_WIN];     // records, [16-byte chunk][slot]; slots 0..31 and 32..63 are the two halves of the window
+    __shared__ uint2 sQ[F3DG_R3_RING];        // kept (list position, Gaussian id) pairs not staged yet, ring
+    __shared__ unsigned sP[SAVE_AUX ? F3DG_R3_WIN : 1];   // list position of every staged slot (the reference's `contributor`)
+
+    const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vcull = cull + (size_t)view * P;
+    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned hl = lane & 31u;               // entry of a half this lane tests in phase 1 ...
+    const unsigned row4 = (lane >> 5) * 4u;       // ... against the pixels of rows row4 .. row4 + 3
+
+    bool done = !inside;
+    PixelState st;
+    st.Tr = 1.0f;
+    st.last_contributor = 0; st.max_contributor = (unsigned)-1;
+    st.C0 = st.C1 = st.C2 = st.C3 = st.C4 = st.C5 = st.C6 = st.C7 = 0;
+    st.dist1 = st.dist2 = st.distortion = 0;
+
+    auto translate = [&](unsigned half_or_all) {      // slots -> 1-based list positions for the slots of one physical half (2: both)
+        if (SAVE_AUX) {
+            const unsigned a = st.last_contributor - F3DG_R3_FLAG, b = st.max_contributor - F3DG_R3_FLAG;
+            if (a < (unsigned)F3DG_R3_WIN && (half_or_all == 2u || (a >> 5) == half_or_all)) st.last_contributor = sP[a] + 1u;
+            if (b < (unsigned)F3DG_R3_WIN && (half_or_all == 2u || (b >> 5) == half_or_all)) st.max_contributor = sP[b] + 1u;
+        }
+    };
+
+    unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
+    unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
+    unsigned long long pass = 0ull;               // per pixel: bits 0..31 older half, 32..63 newer half, in list order
+    unsigned idn = lane < n ? point_list[range.x + lane] : 0u;
+    if (__ballot(!done) != 0ull)
+    for (;;) {
+        // ---- scan: keep the entries whose box reaches this quadrant until 32 are pending
+        while (qpend < 32u && cursor < n) {
+            const unsigned idm = idn, pos = cursor + lane;
+            cursor += 64u;
+            idn = cursor + lane < n ? point_list[range.x + cursor + lane] : 0u;
+            const bool keep = pos < n && (idm & qbit) != 0u;
+            const unsigned long long kb = __ballot(keep);
+            if (keep) sQ[(qhead + qpend + (unsigned)__popcll(kb & lt)) & (F3DG_R3_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+            qpend += (unsigned)__popcll(kb);
+        }
+        const unsigned m = qpend < 32u ? qpend : 32u;
+        // every live pixel has finished the older half (bits 0..31 of `pass` are clear): retire it
+        translate(flip);
+        if (m == 0u && __ballot(pass != 0ull) == 0ull)
+            break;                                // nothing left to stage, nothing left in the newer half
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- stage m entries into the retired half; lanes e and e + 32 both take entry e
+        const unsigned base = flip * 32u;
+        float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float ec = 0.0f;
+        if (hl < m) {
+            const uint2 q = sQ[(qhead + hl) & (F3DG_R3_RING - 1)];
+            if (lane < 32u) {
+                const float4* src = reinterpret_cast<const float4*>(vrec + q.y);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                     (__attribute__((address_space(3))) void*)&sR[c][base], 16, 0, 0);
+                if (SAVE_AUX) sP[base + lane] = q.x;
+            }
+            e4 = vcull[q.y];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (hl < m) ec = sR[3][base + hl].w;
+        qhead += m;
+        qpend -= m;
+
+        // ---- phase 1: the 32 new entries against the quadrant's 64 pixels
+        int fresh = 0;
+        if (m != 0u) {
+            const float u0 = hl < m ? (float)qx0 - e4.x : __builtin_nanf("");     // NaN: every comparison below is false
+            const float v0 = (float)(qy0 + row4) - e4.y;
+            float dxx[8], adx[8], dyy[4], cdy[4];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                dxx[q] = u0 + (float)q;
+                adx[q] = e4.z * dxx[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                dyy[q] = v0 + (float)q;
+                cdy[q] = ec * dyy[q] * dyy[q];
+            }
+            half_ballots<0>(fresh, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+        }
+        // ---- slide: the newer half becomes the older one, the fresh bits the newer one
+        pass = (pass >> 32) | (done ? 0ull : ((unsigned long long)(unsigned)fresh << 32));
+        flip ^= 1u;
+        const unsigned xr = flip << 5;            // logical slot j (0..31 older, 32..63 newer) lives in physical slot j ^ xr
+
+        // ---- phase 2: until every live pixel has finished the older half; pixels that have go on with the newer one
+        // (a divergent loop: a pixel leaves it when its mask is empty -- it has nothing left in either half -- and the ballot, taken
+        // over the pixels still inside, ends it for everybody once no older-half bit is left)
+        while (pass != 0ull && __ballot((unsigned)pass != 0u) != 0ull) {
+            const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
+            pass &= pass - 1;
+            const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
+            const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+            const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+            const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+            const float aaf = ray_x * n0 + ray_y * n1 + n2;
+            const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+            done = (FAST ? blend_entry_fast : blend_entry)(st, F3DG_R3_FLAG | j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+            if (done) pass = 0ull;
+        }
+        if (__ballot(!done) == 0ull)
+            break;
+    }
+    translate(2u);
+
+    if (inside) {
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = distortion_before_normalized;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        out[8 * HW + pix_id] = distortion;
+    }
+}
+
 } // namespace
 
 int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f3dg_render_fast == 1 && !save_aux); }
@@ -867,6 +1047,16 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
                                                   out_color, final_T, n_contrib)
 #define F3DG_LAUNCH3(AUX, FST, OCC) do { if (g_f3dg_render_dma) F3DG_LAUNCH3D(AUX, FST, true, OCC); else F3DG_LAUNCH3D(AUX, FST, false, OCC); } while (0)
         // every variant fits 64 VGPRs without spills: 8 waves per SIMD, 32 x 5 KB = the CU's 160 KB of LDS
+        if (g_f3dg_render_slide) {
+#define F3DG_LAUNCH3S(AUX, FST, OCC) F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
+                                                  focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \
+                                                  out_color, final_T, n_contrib)
+            if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3S(true, true, 8); else F3DG_LAUNCH3S(true, false, 8); }
+            else { if (g_f3dg_render_fast) F3DG_LAUNCH3S(false, true, 8); else F3DG_LAUNCH3S(false, false, 8); }
+#undef F3DG_LAUNCH3S
+            F3DG_HIP_CHECK(hipGetLastError());
+            return F3DG_OK;
+        }
         if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3(true, true, 8); else F3DG_LAUNCH3(true, false, 8); }
         else { if (g_f3dg_render_fast) F3DG_LAUNCH3(false, true, 8); else F3DG_LAUNCH3(false, false, 8); }
 #undef F3DG_LAUNCH3

@@ -15,7 +15,7 @@ for d in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
         if "render" in k or "radix_scatter" in k:
-            agg[("render3" if "render3" in k else "render2" if "render2" in k else "render_fwd" if "render_fwd" in k else "radix_scatter")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[("render3s" if "render3s" in k else "render3" if "render3" in k else "render2" if "render2" in k else "render_fwd" if "render_fwd" in k else "radix_scatter")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
         print(d, k, {c: round(sum(v) / len(v)) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
 PY
