@@ -147,6 +147,29 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
     if (test_T < 0.0001f)
         return true;
 
+#ifdef F3DG_FAST_EXACT_DIST
+    // experiment (tools/ab_exact_dist.sh): the NDC depth and the three distortion accumulators in the reference's own operations
+    // (forward.cu:545-560) inside the fast path -- what it costs to take the distortion channel off the fast arithmetic
+    const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
+    {
+        const float Tr_ = st.Tr;
+        const float A_ = 1 - Tr_;
+        const float error_ = mapped_max_t * mapped_max_t * A_ + st.dist2 - 2 * mapped_max_t * st.dist1;
+        st.distortion += error_ * alpha * Tr_;
+        st.dist1 += mapped_max_t * alpha * Tr_;
+        st.dist2 += mapped_max_t * mapped_max_t * alpha * Tr_;
+    }
+    const float inv_len_ = __builtin_amdgcn_rsqf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)) + 1e-7f);
+    const float w_ = alpha * Tr;
+    const float wn_ = -w_ * inv_len_;
+    st.C0 = fmaf(cr, w_, st.C0); st.C1 = fmaf(cg, w_, st.C1); st.C2 = fmaf(cb, w_, st.C2);
+    st.C3 = fmaf(n0, wn_, st.C3); st.C4 = fmaf(n1, wn_, st.C4); st.C5 = fmaf(n2, wn_, st.C5);
+    if (Tr > 0.5f) { st.C6 = t; st.max_contributor = contributor; }
+    st.C7 += w_;
+    st.Tr = test_T;
+    st.last_contributor = contributor;
+    return false;
+#else
     // (FAR*t - FAR*NEAR) / ((FAR - NEAR)*t) = FAR/(FAR-NEAR) - (FAR*NEAR/(FAR-NEAR)) / t
     const float mapped_max_t = fmaf(-0.20040080160320642f, __builtin_amdgcn_rcpf(t), 1.0020040080160322f);
 
@@ -178,6 +201,7 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
     st.Tr = test_T;
     st.last_contributor = contributor;
     return false;
+#endif
 }
 
 #define F3DG_ROUND (F3DG_BLOCK - 1)     // list entries staged per round; LDS slot F3DG_ROUND is the sentinel

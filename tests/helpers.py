@@ -10,6 +10,9 @@ from f3dgaus_amd import _lib, synthetic
 from oracle import gof as oracle_gof
 
 
+RENDER_MODE = None      # "fast" / "exact" when a module's fixture forces the compositing arithmetic; None: the library default per call
+
+
 def make_scene(P, res=(64, 64), s0=0.05, seed=0, view="canonical", n_views=1, sh_degree=1, colors_precomp=False,
                kernel_size=0.0, scale_modifier=1.0, behind_fraction=0.0, bg=(0.0, 0.0, 0.0), aniso=False, depth_range=None):
     W, H = res
@@ -157,10 +160,16 @@ def assert_render_parity(hip_out, ora_out, label=""):
     assert frac_within(hip_out[7], ora_out[7], 1e-4) >= 0.999, f"{label} alpha"
     assert frac_within(hip_out[3:6], ora_out[3:6], 1e-4) >= 0.999, f"{label} normal"
     assert frac_within(hip_out[6], ora_out[6], 0.0, 1e-4) >= 0.999, f"{label} depth"
-    # distortion: values ~1e-7..1e-5 built from float32 accumulations (dist1, dist2, distortion) that cancel
-    # strongly; a 1-ulp expf difference is amplified to a few percent of the value (SURVEY appendix A.2 measured
-    # ~3 % relative / 3.5e-7 absolute between faithful implementations) -> 5 % relative with a 1e-6 floor
-    assert frac_within(hip_out[8], ora_out[8], 1e-6, 5e-2) >= 0.999, f"{label} distortion"
+    # distortion: values ~1e-7..1e-5 built from float32 accumulations (dist1, dist2, distortion) that cancel strongly; a 1-ulp
+    # difference of exp() is amplified to a few percent of the value (SURVEY appendix A.2 measured ~3 % relative / 3.5e-7 absolute
+    # between faithful implementations; the oracle against itself with tan_fov moved by one ulp: 4-17 % median relative). Stated per
+    # arithmetic mode (RENDER_MODE is set by the fixture of the modules that run both):
+    #   exact (the reference's operation order; only expf differs):  |d| <= 1e-6 + 1e-3 |ref|
+    #   fast  (hardware exp / rcp, FMA-contracted accumulations):    |d| <= 1e-6 + 5e-2 |ref|  -- 3-17 % median relative on the
+    #         sigma0 = 0.01 scenes (profiles/*/parity_report.md), absolute <= 2.5e-6; putting the reference's operations back into
+    #         the fast path costs 27 % of the kernel and still leaves 3-7 % (tools/ab_exact_dist.sh), so the deviation is declared
+    rtol_small = 1e-3 if RENDER_MODE == "exact" else 5e-2
+    assert frac_within(hip_out[8], ora_out[8], 1e-6, rtol_small) >= 0.999, f"{label} distortion ({RENDER_MODE})"
     # ... and where the channel is well conditioned (values above 1e-4: scenes with a real depth spread), SURVEY 8d's rel 1e-3
     big = np.abs(ora_out[8]) > 1e-4
     if big.any():

@@ -19,8 +19,11 @@ def render_mode(request):
     the same tolerances."""
     from f3dgaus_amd import _lib
     L = _lib.lib()
+    import helpers
     assert L.f3dg_set_option(b"render_fast", 2 if request.param == "fast" else 0) == 0      # 2: fast also in SAVE_AUX calls
+    helpers.RENDER_MODE = request.param
     yield request.param
+    helpers.RENDER_MODE = None
     L.f3dg_set_option(b"render_fast", 1)
 
 SCENES = {
