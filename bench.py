@@ -295,7 +295,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     b_pre = (92.0 * P + 96.0 * P * V) / nl
     b_bin = (108.0 * P * V + 18.0 * R_proc + 8.0 * T * V) / nl
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    prof = profiles_record(P, V, RES, args.views_per_call, args.render_mode, args.tile_cull)
+    prof = profiles_record(P, V, RES, args.views_per_call, args.render_mode, args.tile_cull, args.sigma0)
     kname = {3: "render3_fwd_kernel", 2: "render2_fwd_kernel", 1: "render_fwd_kernel"}[render_kernel_id()]
 
     def roofline(stage, mode_fast, n):
@@ -308,6 +308,10 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                 "units_reference": "the same formula on instances_per_step = the reference's num_rendered for this input (tile_cull 0)"}
 
     rf = roofline(stage_ms, args.render_mode == "fast", ncalls)
+    if rf["frac"] > 1.0:
+        rf["note"] = ("frac > 1: the byte formula counts every list entry, but a quadrant stops reading its tile's list when its 64 pixels are "
+                      "saturated -- with splats this large most of every list is never staged, so the algorithmic bytes are not moved; the "
+                      "kernel is bound by VALU issue, not by HBM (counter traffic: profiles/*/sigma005.md)")
     rf.update({"traffic": None,      # HBM bytes need PMC counters: see traffic_from_profiles
                "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
                "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
@@ -564,13 +568,13 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
                                "(random dL/dpix on channels 0-6, 8); views/s counts a forward + backward as one view" % (P, args.sigma0, V, RES, RES),
                    "gaussians": P, "views": V, "resolution": RES, "instances_per_step": R, "instances_processed_per_step": R_proc,
                    "tile_cull": args.tile_cull, "contributing_pairs_per_step": pairs.value},
-        "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel", "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": stage_ms[3] / n,
+        "roofline": {"bound": "hbm", "kernel": "render3_bwd_kernel", "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": stage_ms[3] / n,
                      "achieved": gbs(b_bwd, stage_ms[3] / n), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(b_bwd, stage_ms[3] / n) / HBM_PEAK_GBS,
                      "traffic": None, "formula": "80 R + 60 W H V + 68 C (R = instances_per_step, the reference's num_rendered; C = contributing "
                                                  "pairs, counted by the kernel)",
                      "frac_on_processed_instances": gbs(80.0 * R_proc + 60.0 * RES * RES * V + 68.0 * pairs.value, stage_ms[3] / n) / HBM_PEAK_GBS},
         "rooflines_other": {
-            "render2_fwd_kernel<SAVE_AUX=true, FAST=false>": {"bound": "hbm", "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": stage_ms[2] / n,
+            "render3s_fwd_kernel<SAVE_AUX=true, FAST=false>": {"bound": "hbm", "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": stage_ms[2] / n,
                                                                "achieved": gbs(b_fwd, stage_ms[2] / n), "unit": "GB/s",
                                                                "frac": gbs(b_fwd, stage_ms[2] / n) / HBM_PEAK_GBS}},
         "stage_ms_per_step": {"preprocess": stage_ms[0] / n, "binning": stage_ms[1] / n, "compositing": stage_ms[2] / n,
@@ -596,7 +600,7 @@ def measured_copy_bandwidth(device, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def profiles_record(P, V, RES, views_per_call, mode, tile_cull=1):
+def profiles_record(P, V, RES, views_per_call, mode, tile_cull=1, sigma0=0.01):
     """Counter-derived figures of the compositing kernel from the newest committed profile of THIS configuration
     (profiles/*/traffic.json, written by tools/make_profile.py from separate rocprofv3 --pmc passes of this same command):
     `traffic` = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md),
@@ -607,11 +611,12 @@ def profiles_record(P, V, RES, views_per_call, mode, tile_cull=1):
             t = json.load(open(path))
             c = t["config"]
             if (c["gaussians"], c["views"], c["resolution"], c["views_per_call"]) == (P, V, RES, views_per_call) and \
-                    c.get("render_mode", "exact") == mode and c.get("tile_cull", 0) == tile_cull:
+                    c.get("render_mode", "exact") == mode and c.get("tile_cull", 0) == tile_cull and abs(c.get("sigma0", 0.01) - sigma0) < 1e-9:
                 src = os.path.relpath(path, ROOT)
-                best = {"traffic": {"bytes_per_launch": t["traffic_bytes_per_launch"], "source": src,
+                best = {"traffic": {"bytes_per_launch": t["traffic_bytes_per_launch"], "kernel": t.get("kernel"), "source": src,
                                     "note": "builder-side PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run"},
-                        "valu": dict(t.get("valu") or {}, source=src)}
+                        "valu": dict(t.get("valu") or {}, source=src),
+                        "stages": {k: dict(v, source=src) for k, v in (t.get("stages") or {}).items()}}
         except Exception:
             pass
     return best

@@ -1,4 +1,4 @@
-"""Builds the whole committed profile directory from one `tools/collect_r02.sh <tag>` run:
+"""Builds the whole committed profile directory from one `tools/collect_r03.sh <tag>` run:
     python tools/assemble_profile.py gpurun_out/<tag> profiles/<name>
 = tools/make_profile.py (summary.md, bench_kernel_stats.csv, traffic.json) + c2_sq_counters.md (second SQ pass), c5.md and
 c5_kernel_stats.csv (C5 forward + backward: bench line, kernel table, PMC passes), bench_lines.md (every bench line of the run),
@@ -41,6 +41,49 @@ def main():
         out.append(f"| `{k}` | " + " | ".join(f"{mean(sq2[k].get(n, [])):.3g}" for n in names) + " |")
     open(os.path.join(dst, "c2_sq_counters.md"), "w").write("\n".join(out) + "\n")
 
+    # ---- effective clock of the compositing launch (GRBM_GUI_ACTIVE / duration) and the exact-arithmetic kernel
+    grbm = counters(os.path.join(src, "pmc_grbm"))
+    st_fast = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
+    st_exact = glob.glob(os.path.join(src, "stats_exact", "*kernel_stats.csv"))
+    extra = ["", "# Compositing kernel, both arithmetic modes (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-d2h`)", ""]
+    for label, st in (("fast (default)", st_fast), ("exact (--render-mode exact)", st_exact)):
+        if st:
+            for r in csv.DictReader(open(st[0])):
+                if short(r["Name"]).startswith(("render3s_fwd_kernel", "render3_fwd_kernel")):
+                    extra.append(f"* {label}: `{short(r['Name'])}` {r['Calls']} launches, average {float(r['AverageNs']) / 1e3:.1f} us")
+    for k, c in grbm.items():
+        if k.startswith(("render3s_fwd_kernel", "render3_fwd_kernel")) and c.get("GRBM_GUI_ACTIVE"):
+            cyc = mean(c["GRBM_GUI_ACTIVE"])
+            us = [float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(st_fast[0])) if short(r["Name"]) == k]
+            if us:
+                extra.append(f"* `{k}`: GRBM_GUI_ACTIVE {cyc:.3g} cycles per launch (summed over the 8 XCDs) / 8 / {us[0]:.1f} us = "
+                             f"{cyc / 8 / us[0] / 1e3:.2f} GHz effective clock during the launch (2.4 GHz peak: the chip clocks to its power budget)")
+    open(os.path.join(dst, "c2_sq_counters.md"), "a").write("\n".join(extra) + "\n")
+
+    # ---- sigma0 = 0.05 (SURVEY 8d's second sweep), the larger set, the small-call path: bench line + kernel table each
+    for tag, title, log, stats in (
+            ("sigma005", "C2 at sigma0 = 0.05 -- `python bench.py --sigma0 0.05`", "bench_sigma005.log", "s005_stats"),
+            ("larger_set", "589,824 Gaussians x 128 views @256x256 -- `python bench.py --gaussians 589824 --views 128`", "bench_589k.log", "l589_stats"),
+            ("small_calls", "One view of 65,536 Gaussians per call (the small-call path) -- `python tools/prof_small.py 65536 1`", "small_calls.log", "small_stats")):
+        st = glob.glob(os.path.join(src, stats, "*kernel_stats.csv"))
+        path = os.path.join(src, log)
+        out = ["# " + title, ""]
+        if os.path.exists(path):
+            line = last_json(path)
+            out += ["```", line if line else "\n".join(l for l in open(path).read().splitlines() if l.startswith("P=")), "```", ""]
+        if st:
+            out += ["rocprofv3 --kernel-trace --stats (3-5 steps):", ""] + kernel_table(st[0], 28) + [""]
+        if tag == "sigma005":
+            fetch, write, sq = (counters(os.path.join(src, d)) for d in ("s005_pmc_fetch", "s005_pmc_write", "s005_pmc_sq"))
+            out += ["PMC, separate passes (per dispatch, mean; FETCH x2 = gfx950 correction, WRITE_SIZE uncalibrated):", "",
+                    "| kernel | FETCH x2 MB | WRITE MB | SQ_INSTS_VALU | lane utilisation |", "|---|---:|---:|---:|---:|"]
+            for k in sorted(fetch, key=lambda k: -sum(fetch[k]["FETCH_SIZE"]))[:8]:
+                m = {n: mean(sq.get(k, {}).get(n, [])) for n in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")}
+                lanes = m["SQ_THREAD_CYCLES_VALU"] / (64 * m["SQ_ACTIVE_INST_VALU"]) if m["SQ_ACTIVE_INST_VALU"] else 0.0
+                out.append(f"| `{k}` | {2 * mean(fetch[k]['FETCH_SIZE']) * 1024 / 1e6:.1f} | {mean(write.get(k, {}).get('WRITE_SIZE', [])) * 1024 / 1e6:.1f} | "
+                           f"{m['SQ_INSTS_VALU']:.3g} | {lanes:.2f} |")
+        open(os.path.join(dst, tag + ".md"), "w").write("\n".join(out) + "\n")
+
     # ---- C5
     c5_stats = glob.glob(os.path.join(src, "c5_stats", "*kernel_stats.csv"))
     if c5_stats:
@@ -63,18 +106,25 @@ def main():
     ilog = os.path.join(src, "bench_integrate.log")
     if os.path.exists(ilog):
         out = ["# integrate (Gaussians -> points), 1 M points @256x256 -- `python tools/bench_integrate.py`", "", "```"] + \
-              [l for l in open(ilog).read().splitlines() if l.startswith(("integrate P", "  pass 1", "mesh-extraction"))] + ["```", ""]
+              [l for l in open(ilog).read().splitlines() if l.startswith(("integrate P", "  pass 1", "mesh-extraction", "AlphaSweep"))] + ["```", ""]
         for c, label in ((0, "196,608 Gaussians, sigma0 = 0.01"), (1, "589,824 Gaussians, sigma0 = 0.01")):
             st = glob.glob(os.path.join(src, f"int_stats{c}", "*kernel_stats.csv"))
             if st:
                 out += [f"rocprofv3 --kernel-trace --stats of `CFG={c} python tools/bench_integrate.py` ({label}; 7 calls):", ""] + kernel_table(st[0], 12) + [""]
+        st = glob.glob(os.path.join(src, "int_sweep_stats", "*kernel_stats.csv"))
+        if st:
+            out += ["rocprofv3 --kernel-trace --stats of `V=16 python tools/bench_integrate.py` (the whole script incl. the AlphaSweep preparations of 16 cameras, "
+                    "1 / 4 / 16 per call: the 16-camera launch of integrate_pass1_cull_kernel is its maximum):", ""] + kernel_table(st[0], 8) + [""]
         open(os.path.join(dst, "integrate.md"), "w").write("\n".join(out))
 
     # ---- every bench line of the run
     out = ["# Bench lines of the evidence run (tools/collect_r02.sh), one MI355X", ""]
-    for log, cmd in (("bench_default", "python bench.py` (C2, fast arithmetic = the default)"),
-                     ("bench_exact", "python bench.py --render-mode exact --no-cpu-baseline`"),
+    for log, cmd in (("bench_default", "python bench.py` (C2; fast arithmetic, the reference arithmetic and the D2H-inclusive rate in one line)"),
+                     ("bench_sigma005", "python bench.py --sigma0 0.05 --no-cpu-baseline` (SURVEY 8d's second sweep)"),
                      ("bench_nocull", "python bench.py --tile-cull 0 --no-cpu-baseline` (the reference's tile lists)"),
+                     ("bench_589k", "python bench.py --gaussians 589824 --views 128 --no-cpu-baseline` (the merged set of a final orbit)"),
+                     ("bench_dropin", "python bench.py --workload dropin --views 60` (render_predicted_more_v2_gof, one view per call, 65,536 Gaussians)"),
+                     ("bench_dropin_589k", "python bench.py --workload dropin --views 60 --gaussians 589824`"),
                      ("bench_c5", "python bench.py --workload c5 --steps 3 --warmup 1`"),
                      ("bench_c4_fp32", "python bench.py --workload c4 --images 16 --steps 2 --warmup 1`"),
                      ("bench_c4_bf16", "python bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone bf16`"),
