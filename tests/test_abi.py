@@ -92,3 +92,51 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
                 assert "libgof_oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_round3_host_logic(f3d):
+    """Options, diagnostics, the small-call path's workspace carving and the integrate layouts: pure host arithmetic."""
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    for name in (b"render_kernel", b"render_slide", b"render_dma", b"render_lds_pad", b"bwd_occ", b"small_path", b"small_debug",
+                 b"tile_cull", b"render_fast", b"time_launches"):
+        assert L.f3dg_set_option(name, 1) == 0, name
+    for name, v in ((b"render_kernel", 3), (b"bwd_occ", 4), (b"render_lds_pad", 0), (b"small_debug", 0), (b"time_launches", 0), (b"small_path", 2)):
+        assert L.f3dg_set_option(name, v) == 0
+    assert L.f3dg_set_option(b"no_such_option", 1) == _lib.ERR_BAD_ARG
+    assert L.f3dg_debug_launch_count(1) >= 0 and L.f3dg_debug_launch_count(0) == 0
+    # the per-tile slots of the small-call path exist for one or two views of at most 2^18 Gaussians only: 4096 x 4 B per (view, tile)
+    T = 256
+    two = L.f3dg_workspace_bytes(65536, 256, 256, 2, 100000)
+    three = L.f3dg_workspace_bytes(65536, 256, 256, 3, 100000)
+    one = L.f3dg_workspace_bytes(65536, 256, 256, 1, 100000)
+    assert two - one > T * 4096 * 4                  # a second view's slots on top of its per-view arrays
+    assert three < two + (two - one) - T * 4096 * 4 + 4096      # the third view brings no slots (and frees those of the other two)
+    assert L.f3dg_workspace_bytes((1 << 18) + 1, 256, 256, 1, 100000) - L.f3dg_workspace_bytes(1 << 18, 256, 256, 1, 100000) < 1 << 20
+    # batched integrate workspaces grow by the per-camera tables (2 KB of contributor ids per pixel)
+    i1 = L.f3dg_integrate_workspace_bytes_batched(1000, 100, 64, 64, 1, 50000)
+    i4 = L.f3dg_integrate_workspace_bytes_batched(1000, 100, 64, 64, 4, 50000)
+    assert i1 == L.f3dg_integrate_workspace_bytes(1000, 100, 64, 64, 50000) and i4 - i1 >= 3 * 64 * 64 * 2048
+    assert L.f3dg_integrate_workspace_bytes_batched(1000, 100, 64, 64, 0, 50000) == 0
+    # more than 2^28 Gaussians do not fit a list entry (28-bit id + quadrant mask)
+    buf = (C.c_char * 1024)()
+    one_p = C.cast(buf, C.c_void_p)
+    rc = L.f3dg_forward_batched(None, one_p, 1024, 1000, 1, (1 << 28) + 5, 1, 4, one_p, 64, 64, one_p, one_p, None, one_p, one_p, 1.0,
+                                one_p, None, None, one_p, one_p, one_p, 0.1, 0.1, 0.0, one_p, None, 0)
+    assert rc == _lib.ERR_BAD_ARG
+    # several Gaussian sets are an inference path
+    rc = L.f3dg_forward_sets(None, one_p, 1 << 40, 1000, 2, 1, 100, 1, 4, one_p, 64, 64, one_p, one_p, None, one_p, one_p, 1.0,
+                             one_p, None, None, one_p, one_p, one_p, 0.1, 0.1, 0.0, one_p, None, _lib.FLAG_SAVE_AUX)
+    assert rc == _lib.ERR_BAD_ARG
+
+
+def test_stream_cache_and_alias_modules(f3d):
+    from f3dgaus_amd.diff_gof_rasterization import _StreamCache
+    c = _StreamCache(limit=3)
+    for i in range(5):
+        c[i] = i
+    assert list(c) == [2, 3, 4] and c.get(2) == 2
+    c[9] = 9
+    assert list(c) == [4, 2, 9] and c.get(77) is None
+    import f3dgaus_amd.diff_gof_rasterization.backward as b
+    assert b.__spec__.name == "f3d-gaus_amd.diff_gof_rasterization.backward" and b.__package__ == "f3d-gaus_amd.diff_gof_rasterization"
