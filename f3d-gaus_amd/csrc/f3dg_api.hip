@@ -109,7 +109,7 @@ int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
 int g_f3dg_render_slide = 1;
 int g_f3dg_render_lds_pad = 0;
-int g_f3dg_bwd_occ = 4;
+int g_f3dg_bwd_occ = 5;
 int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
@@ -123,7 +123,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) g_small_disabled.clear(); return F3DG_OK; }
     if (name && strcmp(name, "small_debug") == 0) { g_f3dg_small_debug = value; return F3DG_OK; }
     if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = value == 5 ? 5 : value == 6 ? 6 : 4; return F3DG_OK; }
+    if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = (value >= 2 && value <= 6) ? value : 5; return F3DG_OK; }
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }

@@ -728,7 +728,7 @@ render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                    const float* __restrict__ final_T, const unsigned* __restrict__ n_contrib,
                    const float* __restrict__ dL_dpixels,
                    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
-                   double* __restrict__ dL_dv2g_acc)
+                   double* __restrict__ dL_dv2g_acc, int debug_no_atomics)
 {
     unsigned view, unit;
     f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
@@ -791,6 +791,14 @@ render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
     const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned n_pairs = 0;                 // contributing (pixel, Gaussian) pairs of this wave
+
+    // Where lane 15 of row r adds its totals (see the reduction below): everything but the Gaussian id is fixed per lane, so the
+    // address of an atomic is one multiply-add -- base + id * stride -- instead of per-row selects among four arrays.
+    const unsigned row = lane >> 4;
+    char* const add0 = row < 3 ? reinterpret_cast<char*>(dL_dcolors + vP * 3 + row) : reinterpret_cast<char*>(dL_dmean2D + vP * 3);   // stride 12
+    char* const add1 = row < 2 ? reinterpret_cast<char*>(dL_dmean2D + vP * 3 + 1 + row) : reinterpret_cast<char*>(dL_dopacity);
+    const unsigned stride1 = row < 2 ? 12u : 4u;
+    char* const addD = reinterpret_cast<char*>(dL_dv2g_acc + vP * 10 + row);                                                           // stride 80
 
     unsigned cursor = (unsigned)wave_last, qhead = 0, qcount = 0;     // list positions [0, cursor) are still to be scanned
     unsigned idn = lane < cursor ? point_list[range.x + cursor - 1u - lane] : 0u;       // back to front: lane l reads position cursor - 1 - l
@@ -1015,14 +1023,11 @@ render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             const float d0 = row_total(pair16(pair32(g_v0, g_v2), pair32(g_v1, g_v3)));           // v0 v1 v2 v3
             const float d1 = row_total(pair16(pair32(g_v4, g_v6), pair32(g_v5, g_v7)));           // v4 v5 v6 v7
             const float d2 = row_total(pair16(pair32(g_v8, 0.0f), pair32(g_v9, 0.0f)));           // v8 v9 -  -
-            if ((lane & 15u) == 15u) {
-                const unsigned row = lane >> 4;
-                const unsigned id = pe.y;
-                const size_t gi = vP + id;
-                float* mm = dL_dmean2D + gi * 3;
-                unsafeAtomicAdd(row < 3 ? dL_dcolors + gi * 3 + row : mm, f0);
-                if (row < 3) unsafeAtomicAdd(row < 2 ? mm + 1 + row : dL_dopacity + id, f1);
-                double* acc = dL_dv2g_acc + gi * 10 + row;
+            if ((lane & 15u) == 15u && !debug_no_atomics) {
+                const size_t id = pe.y;
+                unsafeAtomicAdd(reinterpret_cast<float*>(add0 + id * 12u), f0);
+                if (row < 3) unsafeAtomicAdd(reinterpret_cast<float*>(add1 + id * stride1), f1);
+                double* acc = reinterpret_cast<double*>(addD + id * 80u);
                 unsafeAtomicAdd(acc, (double)d0);
                 unsafeAtomicAdd(acc + 4, (double)d1);
                 if (row < 2) unsafeAtomicAdd(acc + 8, (double)d2);
@@ -1383,8 +1388,9 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
                            reinterpret_cast<const float4*>(ws + L.cull),                                                                            \
                            reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),                         \
                            background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),                    \
-                           reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor, acc)
-        if (g_f3dg_bwd_occ == 5) F3DG_LAUNCH_BWD3(5); else if (g_f3dg_bwd_occ == 6) F3DG_LAUNCH_BWD3(6); else F3DG_LAUNCH_BWD3(4);
+                           reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor, acc, g_f3dg_small_debug == 9)
+        if (g_f3dg_bwd_occ == 4) F3DG_LAUNCH_BWD3(4); else if (g_f3dg_bwd_occ == 6) F3DG_LAUNCH_BWD3(6); else if (g_f3dg_bwd_occ == 3) F3DG_LAUNCH_BWD3(3);
+        else if (g_f3dg_bwd_occ == 2) F3DG_LAUNCH_BWD3(2); else F3DG_LAUNCH_BWD3(5);
 #undef F3DG_LAUNCH_BWD3
     } else if (g_f3dg_render_cull)
         F3DG_KLAUNCH(render_bwd_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,

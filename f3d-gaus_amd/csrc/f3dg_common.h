@@ -188,7 +188,7 @@ extern int g_f3dg_render_kernel;       // 3 (default): render3 (one wave64 per 8
                                        // Gaussians across the lanes in phase 1); 1: the pixel-lane kernel with its filters
 extern int g_f3dg_small_debug;         // timing experiments of small_bin_kernel: 1 return at once, 2 after the collection, 3 no sort passes
 extern int g_f3dg_small_path;          // 1 (default): inference calls of a small shape (f3dg_small_shape) take the three-launch path
-extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is compiled for: 4 (default: 10.4 ms at C5), 5 (10.6) or 6 (spills, 12.0)
+extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is compiled for: 5 (default: 10.0 ms at C5), 2..4 (10.2-10.4: the kernel is VALU-bound at any of them) or 6 (spills, 12.0)
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
 extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding half-window (render3s_fwd_kernel); 0: fixed 64-entry windows
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)

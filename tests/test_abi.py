@@ -101,7 +101,7 @@ def test_round3_host_logic(f3d):
     for name in (b"render_kernel", b"render_slide", b"render_dma", b"render_lds_pad", b"bwd_occ", b"small_path", b"small_debug",
                  b"tile_cull", b"render_fast", b"time_launches"):
         assert L.f3dg_set_option(name, 1) == 0, name
-    for name, v in ((b"render_kernel", 3), (b"bwd_occ", 4), (b"render_lds_pad", 0), (b"small_debug", 0), (b"time_launches", 0), (b"small_path", 2)):
+    for name, v in ((b"render_kernel", 3), (b"bwd_occ", 5), (b"render_lds_pad", 0), (b"small_debug", 0), (b"time_launches", 0), (b"small_path", 2)):
         assert L.f3dg_set_option(name, v) == 0
     assert L.f3dg_set_option(b"no_such_option", 1) == _lib.ERR_BAD_ARG
     assert L.f3dg_debug_launch_count(1) >= 0 and L.f3dg_debug_launch_count(0) == 0
