@@ -108,6 +108,7 @@ int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
 int g_f3dg_render_slide = 1;
+int g_f3dg_render_lowocc = 1;
 int g_f3dg_render_lds_pad = 0;
 int g_f3dg_bwd_occ = 5;
 int g_f3dg_render_round = 192;
@@ -125,6 +126,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = (value >= 2 && value <= 6) ? value : 5; return F3DG_OK; }
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
+    if (name && strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }

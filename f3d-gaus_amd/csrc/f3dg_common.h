@@ -190,6 +190,7 @@ extern int g_f3dg_small_debug;         // timing experiments of small_bin_kernel
 extern int g_f3dg_small_path;          // 1 (default): inference calls of a small shape (f3dg_small_shape) take the three-launch path
 extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is compiled for: 5 (default: 10.0 ms at C5), 2..4 (10.2-10.4: the kernel is VALU-bound at any of them) or 6 (spills, 12.0)
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
+extern int g_f3dg_render_lowocc;       // 1 (default): launches of at most 2048 quadrant waves take render3l_fwd_kernel (next window's gathers in flight)
 extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding half-window (render3s_fwd_kernel); 0: fixed 64-entry windows
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);

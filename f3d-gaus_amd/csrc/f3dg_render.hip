@@ -1048,6 +1048,176 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     }
 }
 
+// ---- render3 for SMALL launches: the next window's gathers in flight behind phase 2 ------------------------------------------------
+// A call of one or two 256^2 views is 1,024-2,048 waves on a chip that holds 8,192: every wave is alone on its SIMD and its time is a
+// chain of latencies -- list ids, record gathers, the dependent instructions of a phase-2 trip -- that no other wave fills. At that
+// occupancy LDS is free, so this variant keeps TWO 64-entry windows of records: window k + 1 is scanned for and its records are
+// requested (global_load_lds) right after phase 1 of window k, and they land while phase 2 of window k runs; two 64-id chunks of the
+// list are always in flight. Fixed windows (lane utilisation is irrelevant for a latency-bound wave). Same images to the bit.
+#define F3DG_R3L_RING 256
+template <bool SAVE_AUX, bool FAST>
+__global__ void __launch_bounds__(64, 2)
+render3l_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x;
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const unsigned n = range.y - range.x;
+
+    __shared__ float4 sR[2][4][F3DG_R3_WIN];  // two windows of records, [window][16-byte chunk][entry]
+    __shared__ uint2 sQ[F3DG_R3L_RING];       // (list position, Gaussian id) of the kept entries: the current window, the next one, the backlog
+
+    const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vcull = cull + (size_t)view * P;
+    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    bool done = !inside;
+    PixelState st;
+    st.Tr = 1.0f;
+    st.last_contributor = 0; st.max_contributor = (unsigned)-1;
+    st.C0 = st.C1 = st.C2 = st.C3 = st.C4 = st.C5 = st.C6 = st.C7 = 0;
+    st.dist1 = st.dist2 = st.distortion = 0;
+
+    unsigned cursor = 0, qhead = 0, qcount = 0;                       // ring: [qhead, qhead + qcount) = current window + everything behind it
+    unsigned id0 = lane < n ? point_list[range.x + lane] : 0u;       // the 64 list entries at `cursor` ...
+    unsigned id1 = 64u + lane < n ? point_list[range.x + 64u + lane] : 0u;   // ... and the 64 after them, always in flight
+    auto scan_until = [&](unsigned want) {      // keep scanning until `want` entries are queued (or the list ends)
+        while (qcount < want && cursor < n) {
+            const unsigned idm = id0, pos = cursor + lane;
+            cursor += 64u;
+            id0 = id1;
+            id1 = cursor + 64u + lane < n ? point_list[range.x + cursor + 64u + lane] : 0u;
+            const bool keep = pos < n && (idm & qbit) != 0u;
+            const unsigned long long kb = __ballot(keep);
+            if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R3L_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+            qcount += (unsigned)__popcll(kb);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto request = [&](unsigned buf, unsigned first, unsigned m, float4& e4) {   // records of ring entries [first, first + m) -> window `buf`
+        e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (lane < m) {
+            const unsigned id = sQ[(first + lane) & (F3DG_R3L_RING - 1)].y;
+            const float4* src = reinterpret_cast<const float4*>(vrec + id);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                 (__attribute__((address_space(3))) void*)&sR[buf][c][0], 16, 0, 0);
+            e4 = vcull[id];
+        }
+    };
+
+    if (__ballot(!done) != 0ull) {
+        scan_until(F3DG_R3_WIN);
+        unsigned m = qcount < F3DG_R3_WIN ? qcount : F3DG_R3_WIN, buf = 0;
+        float4 e4;
+        request(0, qhead, m, e4);
+        while (m != 0u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float ec = lane < m ? sR[buf][3][lane].w : 0.0f;
+            // ---- phase 1 of the current window
+            int pass_lo = 0, pass_hi = 0;
+            {
+                const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
+                const float v0 = (float)qy0 - e4.y;
+                float dxx[8], adx[8], dyy[8], cdy[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    dxx[q] = u0 + (float)q;
+                    adx[q] = e4.z * dxx[q];
+                    dyy[q] = v0 + (float)q;
+                    cdy[q] = ec * dyy[q] * dyy[q];
+                }
+                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+            }
+            // ---- the next window: scan for it and request its records; they land during phase 2
+            scan_until(m + F3DG_R3_WIN);
+            const unsigned m_next = qcount - m < F3DG_R3_WIN ? qcount - m : F3DG_R3_WIN;
+            float4 e4n;
+            request(buf ^ 1u, qhead + m, m_next, e4n);
+
+            // ---- phase 2 of the current window
+            unsigned long long pass = done ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+            while (pass != 0 && !done) {
+                const int j = __builtin_ctzll(pass);
+                pass &= pass - 1;
+                const float4 q0 = sR[buf][0][j], q1 = sR[buf][1][j], q2 = sR[buf][2][j], q3 = sR[buf][3][j];
+                const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+                const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+                const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+                const float aaf = ray_x * n0 + ray_y * n1 + n2;
+                const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+                done = (FAST ? blend_entry_fast : blend_entry)(st, F3DG_R3_FLAG | (unsigned)j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+            }
+            if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
+                if (st.last_contributor - F3DG_R3_FLAG < (unsigned)F3DG_R3_WIN)
+                    st.last_contributor = sQ[(qhead + (st.last_contributor - F3DG_R3_FLAG)) & (F3DG_R3L_RING - 1)].x + 1u;
+                if (st.max_contributor - F3DG_R3_FLAG < (unsigned)F3DG_R3_WIN)
+                    st.max_contributor = sQ[(qhead + (st.max_contributor - F3DG_R3_FLAG)) & (F3DG_R3L_RING - 1)].x + 1u;
+            }
+            qhead += m;
+            qcount -= m;
+            m = m_next;
+            e4 = e4n;
+            buf ^= 1u;
+            if (__ballot(!done) == 0ull)
+                break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write of this wave may still be in flight when it ends
+    }
+
+    if (inside) {
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = distortion_before_normalized;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        out[8 * HW + pix_id] = distortion;
+    }
+}
+
 } // namespace
 
 int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f3dg_render_fast == 1 && !save_aux); }
@@ -1071,6 +1241,17 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
                                                   out_color, final_T, n_contrib)
 #define F3DG_LAUNCH3(AUX, FST, OCC) do { if (g_f3dg_render_dma) F3DG_LAUNCH3D(AUX, FST, true, OCC); else F3DG_LAUNCH3D(AUX, FST, false, OCC); } while (0)
         // every variant fits 64 VGPRs without spills: 8 waves per SIMD, 32 x 5 KB = the CU's 160 KB of LDS
+        // small launches (at most two waves per SIMD: one or two 256^2 views) are latency chains: the prefetching variant
+        if (g_f3dg_render_lowocc && (long long)V * T * 4 <= 2048ll) {
+#define F3DG_LAUNCH3L(AUX, FST) F3DG_KLAUNCH((render3l_fwd_kernel<AUX, FST>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T,  \
+                                                  focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \
+                                                  out_color, final_T, n_contrib)
+            if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3L(true, true); else F3DG_LAUNCH3L(true, false); }
+            else { if (g_f3dg_render_fast) F3DG_LAUNCH3L(false, true); else F3DG_LAUNCH3L(false, false); }
+#undef F3DG_LAUNCH3L
+            F3DG_HIP_CHECK(hipGetLastError());
+            return F3DG_OK;
+        }
         if (g_f3dg_render_slide) {
 #define F3DG_LAUNCH3S(AUX, FST, OCC) F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \

@@ -98,7 +98,7 @@ def test_round3_host_logic(f3d):
     """Options, diagnostics, the small-call path's workspace carving and the integrate layouts: pure host arithmetic."""
     from f3dgaus_amd import _lib
     L = _lib.lib()
-    for name in (b"render_kernel", b"render_slide", b"render_dma", b"render_lds_pad", b"bwd_occ", b"small_path", b"small_debug",
+    for name in (b"render_kernel", b"render_slide", b"render_lowocc", b"render_dma", b"render_lds_pad", b"bwd_occ", b"small_path", b"small_debug",
                  b"tile_cull", b"render_fast", b"time_launches"):
         assert L.f3dg_set_option(name, 1) == 0, name
     for name, v in ((b"render_kernel", 3), (b"bwd_occ", 5), (b"render_lds_pad", 0), (b"small_debug", 0), (b"time_launches", 0), (b"small_path", 2)):

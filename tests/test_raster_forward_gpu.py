@@ -251,7 +251,9 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
             L.f3dg_set_option(b"render_round", rnd)
             variants.append(run_hip(scene, gpu_device))
         L.f3dg_set_option(b"render_kernel", 3)      # render3 (default): one wave64 per 8x8 quadrant, quadrant masks from the binning stage
-        variants.append(run_hip(scene, gpu_device))   # the default: sliding half-windows (render3s_fwd_kernel)
+        variants.append(run_hip(scene, gpu_device))   # the default for launches this small: render3l_fwd_kernel (prefetching windows)
+        L.f3dg_set_option(b"render_lowocc", 0)
+        variants.append(run_hip(scene, gpu_device))   # the default for everything larger: sliding half-windows (render3s_fwd_kernel)
         L.f3dg_set_option(b"render_slide", 0)         # fixed 64-entry windows,
         for dma in (1, 0):                          # records staged by global_load_lds / through registers
             L.f3dg_set_option(b"render_dma", dma)
@@ -259,6 +261,7 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
     finally:
         L.f3dg_set_option(b"render_kernel", 3)
         L.f3dg_set_option(b"render_slide", 1)
+        L.f3dg_set_option(b"render_lowocc", 1)
         L.f3dg_set_option(b"render_dma", 1)
         L.f3dg_set_option(b"render_round", 192)
         for o in (b"render_pretest", b"render_cull", b"render_queue"):

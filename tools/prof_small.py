@@ -23,6 +23,9 @@ call = lambda: f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], c
 for _ in range(5):
     call()
 torch.cuda.synchronize()
+if os.environ.get("F3DG_RENDER_LOWOCC"):
+    from f3dgaus_amd import _lib
+    _lib.lib().f3dg_set_option(b"render_lowocc", int(os.environ["F3DG_RENDER_LOWOCC"]))
 if os.environ.get("F3DG_SMALL_DEBUG"):
     from f3dgaus_amd import _lib
     _lib.lib().f3dg_set_option(b"small_debug", int(os.environ["F3DG_SMALL_DEBUG"]))
