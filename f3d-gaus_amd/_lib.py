@@ -46,6 +46,7 @@ SIGNATURES = {
     "f3dg_integrate_prepare_batched": (_ll, [_p, _p, _sz, _ll, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
                                              _p, _f, _f, _f, _p, _p, C.POINTER(_ll)]),
     "f3dg_integrate_points_view": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p]),
+    "f3dg_debug_integrate_redo": (_i, [_p, _p, _i, _i, _i, _i, _i, _ll, C.POINTER(_i)]),
     "f3dg_mark_visible": (_i, [_p, _i, _p, _p, _p, _p]),
     "f3dg_splat_head": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _ll, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "f3dg_render_epilogue": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),

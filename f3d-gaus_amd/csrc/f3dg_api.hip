@@ -500,6 +500,22 @@ extern "C" int f3dg_integrate_points_view(void* stream, void* workspace, size_t 
                                         viewmatrix, out_color, out_alpha_integrated, out_color_integrated, alpha_min);
 }
 
+extern "C" int f3dg_debug_integrate_redo(void* stream, const void* workspace, int P, int PN_max, int W, int H, int n_views,
+                                         long long max_rendered, int* h_tiles)
+{
+    if (!workspace || !h_tiles || P <= 0 || W <= 0 || H <= 0 || n_views <= 0 || PN_max < 0 || max_rendered < 0) return F3DG_ERR_BAD_ARG;
+    const F3dgIntegLayout I = f3dg_integ_layout(P, PN_max, W, H, max_rendered, n_views);
+    const size_t T = (size_t)((W + F3DG_TILE - 1) / F3DG_TILE) * ((H + F3DG_TILE - 1) / F3DG_TILE);
+    std::vector<unsigned> flags((size_t)n_views * T);
+    F3DG_HIP_CHECK(hipMemcpyAsync(flags.data(), static_cast<const char*>(workspace) + I.redo, flags.size() * sizeof(unsigned),
+                                  hipMemcpyDeviceToHost, (hipStream_t)stream));
+    F3DG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    int n = 0;
+    for (unsigned f : flags) n += f != 0u;
+    *h_tiles = n;
+    return F3DG_OK;
+}
+
 extern "C" int f3dg_integrate_points(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,
                                      int PN, int P, int W, int H, const float* points3D, const float* viewmatrix,
                                      float tan_fovx, float tan_fovy, float* out_color, float* out_alpha_integrated,

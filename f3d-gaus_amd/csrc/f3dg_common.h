@@ -119,6 +119,7 @@ struct F3dgIntegLayout {
     size_t pix_start;      // [H*W] u32: exclusive scan of pix_points
     size_t scan_tmp;       // block sums of that scan
     size_t pt_pix, pt_rank, perm;   // [PN] u32 each: pixel of a point (~0: not integrated), its rank in the pixel, pixel order
+    size_t redo;           // [V*T] u32: tiles of pass 1 that integrate_pass1_rays_kernel hands to the per-pixel kernel (1,024 contributors reached)
     size_t total;
     unsigned scan_tmp_elems;
 };

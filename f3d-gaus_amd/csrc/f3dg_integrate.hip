@@ -262,9 +262,15 @@ integrate_pass1_cull_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
                             const F3dgRec* __restrict__ rec, const float4* __restrict__ cull,
                             const float* __restrict__ background, float* __restrict__ out_color,
                             float* __restrict__ final_T, unsigned* __restrict__ n_contrib,
-                            unsigned short* __restrict__ contrib_ids, unsigned* __restrict__ contrib_n)
+                            unsigned short* __restrict__ contrib_ids, unsigned* __restrict__ contrib_n,
+                            const unsigned* __restrict__ only /* null, or [V*T] flags: the tiles to compute */)
 {
     constexpr int ROUND = F3DG_BLOCK;             // staged entries per round (byte indices 0..255)
+    if (only != nullptr) {                        // the tiles integrate_pass1_rays_kernel handed back (a pixel reached 1,024 contributors)
+        unsigned view_, tile_;
+        f3dg_xcd_map(blockIdx.x, (unsigned)V, (unsigned)T, view_, tile_);
+        if (only[(size_t)view_ * T + tile_] == 0u) return;
+    }
     // several cameras of the same Gaussians in one launch (f3dg_integrate_prepare_batched): one 256^2 camera is 256 workgroups,
     // a wave per SIMD and nothing to overlap its latencies with; every per-camera array is the camera's slice of a [V, ...] array
     unsigned view, tile;
@@ -444,6 +450,219 @@ integrate_pass1_cull_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
         out_color[4 * HW + pix_id] = 0.0f;
         out_color[5 * HW + pix_id] = 0.0f;
         out_color[6 * HW + pix_id] = st.C6;
+        out_color[7 * HW + pix_id] = st.C7;
+    }
+}
+
+// ---- pass 1 by RAYS ----------------------------------------------------------------------------------------------------------------
+// The five rays of a pixel are its centre and its four corners (forward.cu:880-901), and a corner belongs to four pixels: the ray
+// through (x - 0.5, y - 0.5) is ray 1 of pixel (x, y), ray 2 of (x - 1, y), ray 3 of (x, y - 1) and ray 4 of (x - 1, y - 1) -- the same
+// float32 direction to the bit ((x + 0.5f) - 0.5f and (x - 1 + 0.5f) + 0.5f are both exactly x) walking the same tile list, hence the
+// same alphas, the same transmittance recurrence T[K] and the same "used" decisions in each of the four. The reference evaluates it
+// four times; here a 16x16 tile is 256 centre rays + 17x17 corner rays = 545 rays instead of 1,280, in the reference's arithmetic.
+// What is per PIXEL is cheap and derived afterwards: the contributor list = the entries any of its five rays used (in list order),
+// the last contributor, max depth = the maximum over its rays; colour, alpha and final T come from the centre ray alone.
+//
+// One 576-thread workgroup per (camera, tile): waves 0-3 hold the centre rays of the four 8x8 quadrants (lane = pixel), waves 4-7 the
+// corners (cx, cy) in 0..15 x 0..15 of the 17x17 grid, wave 8 the 33 corners of its last column and row. A round stages 256 list
+// entries (waves 4-7, while waves 0-3 still merge the previous round); every wave then takes the round in four 64-entry windows:
+// phase 1 with the Gaussians across the lanes (the record's conservative ellipse at the wave's 64 ray positions -- corners are half-
+// integer positions of the same grid, no inflation as in integrate_pass1_cull_kernel --, quad_ballots), phase 2 with the rays
+// across the lanes, each through its own passing entries; the "used" bits of a (ray, window) go to LDS, and after the round's second
+// barrier the pixel lanes OR their five rays' masks and append the contributors.
+// The one thing a shared ray cannot reproduce is a pixel that stops at 1,024 contributors (forward.cu:972-976: its rays end there
+// while its neighbours' go on): such a tile raises its `redo` flag and integrate_pass1_cull_kernel, launched behind this kernel on
+// the flagged tiles only, computes it pixel by pixel.
+#define F3DG_RAYS_THREADS 576
+__global__ void __launch_bounds__(F3DG_RAYS_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
+                            const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
+                            const F3dgRec* __restrict__ rec, const float4* __restrict__ cull,
+                            const float* __restrict__ background, float* __restrict__ out_color,
+                            float* __restrict__ final_T, unsigned* __restrict__ n_contrib,
+                            unsigned short* __restrict__ contrib_ids, unsigned* __restrict__ contrib_n, unsigned* __restrict__ redo)
+{
+    constexpr int ROUND = 256;
+    unsigned view, tile;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, (unsigned)T, view, tile);
+    const size_t HW = (size_t)H * W;
+    ranges += (size_t)view * T; rec += (size_t)view * P; cull += (size_t)view * P;
+    out_color += (size_t)view * F3DG_OUT_CHANNELS * HW; final_T += (size_t)view * 4 * HW; n_contrib += (size_t)view * 2 * HW;
+    contrib_ids += (size_t)view * HW * F3DG_MAX_CONTRIB; contrib_n += (size_t)view * HW;
+    redo += (size_t)view * T;
+
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned px0 = tile_x * F3DG_TILE, py0 = tile_y * F3DG_TILE;
+
+    // this lane's ray: grid position (gx, gy) inside the tile, centre (waves 0-3: 0..15) or corner (0..16, half a pixel up and left)
+    const bool centre = wave < 4u;
+    unsigned gx, gy;
+    bool exists = true;
+    if (wave < 8u) {
+        gx = (wave & 1u) * 8u + (lane & 7u);
+        gy = ((wave >> 1) & 1u) * 8u + (lane >> 3);
+    } else {
+        gx = lane < 17u ? 16u : lane - 17u;
+        gy = lane < 17u ? lane : 16u;
+        exists = lane < 33u;
+    }
+    // a corner is walked when the pixel up and left of it (or, on the tile's first column / row, the pixel it is the corner of) is in the image
+    const unsigned ax = px0 + (centre || gx == 0u ? gx : gx - 1u), ay = py0 + (centre || gy == 0u ? gy : gy - 1u);
+    const bool active = exists && ax < (unsigned)W && ay < (unsigned)H;
+    const float off = centre ? 0.0f : -0.5f;
+    const float pixf_x = (float)(px0 + gx) + 0.5f, pixf_y = (float)(py0 + gy) + 0.5f;
+    const float ray_x = (float)((pixf_x + off - W / 2.) / focal_x), ray_y = (float)((pixf_y + off - H / 2.) / focal_y);
+    // origin of the wave's 8x8 grid in the ellipse records' pixel-index coordinates
+    const float org_x = (float)(px0 + ((wave & 1u) * 8u)) + off, org_y = (float)(py0 + (((wave >> 1) & 1u) * 8u)) + off;
+
+    uint2 range = ranges[tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const unsigned n = range.y - range.x;
+    const int rounds = (int)((n + ROUND - 1) / ROUND);
+
+    __shared__ float4 sq0[ROUND], sq1[ROUND], sq2[ROUND], sq3[ROUND];      // v0..v3 | v4..v7 | v8 v9 opac K | r g b c
+    __shared__ float4 sE[ROUND];                                           // conservative ellipse: cx cy a b (c = sq3.w)
+    __shared__ unsigned long long sUsedC[4][256];                          // [window][centre ray]: entries of the window the ray used
+    __shared__ unsigned long long sUsedK[4][289];                          // [window][corner ray]
+    __shared__ float sMaxK[289];
+    __shared__ int s_over;
+    if (threadIdx.x == 0) s_over = 0;
+
+    Pass1State st;
+#pragma unroll
+    for (int k = 0; k < 5; k++) st.Ts[k] = 1.0f;
+    st.C0 = st.C1 = st.C2 = st.C6 = st.C7 = 0;
+    st.last_contributor = 0; st.nloc = 0;
+    // (pixel lanes = the centre-ray lanes)
+    const bool inside = centre && active;
+    const size_t pix_id = (size_t)W * (py0 + gy) + (px0 + gx);
+    unsigned short* my_ids = contrib_ids + pix_id * F3DG_MAX_CONTRIB;
+    const unsigned kidx = gy * 17u + gx, cidx = gy * 16u + gx;
+
+    auto merge = [&](int i) {          // pixel lanes: contributors of round i = the entries any of the five rays used, in list order
+        const unsigned in_round = min((unsigned)ROUND, n - (unsigned)i * ROUND);
+        for (unsigned w = 0; w * 64u < in_round; w++) {
+            unsigned long long m = sUsedC[w][cidx] | sUsedK[w][kidx] | sUsedK[w][kidx + 1u] | sUsedK[w][kidx + 17u] | sUsedK[w][kidx + 18u];
+            if (!inside || st.nloc >= F3DG_MAX_CONTRIB) m = 0ull;
+            while (m != 0ull) {
+                const unsigned j = (unsigned)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const unsigned contributor = (unsigned)i * ROUND + w * 64u + j + 1u;
+                st.last_contributor = contributor;
+                my_ids[st.nloc] = (unsigned short)contributor;         // (u_int16_t) cast of forward.cu:969
+                st.nloc += 1;
+                if (st.nloc >= F3DG_MAX_CONTRIB) {                      // "Maximal contributors are met": this tile is redone per pixel
+                    s_over = 1;
+                    break;
+                }
+            }
+        }
+    };
+
+    for (int i = 0; i < rounds; i++) {
+        if (wave >= 4u && wave < 8u) {                       // stage round i
+            const unsigned t = threadIdx.x - 256u, progress = (unsigned)i * ROUND + t;
+            if (progress < n) {
+                const unsigned id = point_list[range.x + progress] & F3DG_ID_MASK;
+                const float4* src = reinterpret_cast<const float4*>(rec + id);
+                sq0[t] = src[0]; sq1[t] = src[1]; sq2[t] = src[2]; sq3[t] = src[3];
+                sE[t] = cull[id];
+            }
+        } else if (centre && i > 0) {
+            merge(i - 1);
+        }
+        __syncthreads();
+        if (s_over)
+            break;
+        const unsigned in_round = min((unsigned)ROUND, n - (unsigned)i * ROUND);
+        for (unsigned w = 0; w * 64u < in_round; w++) {
+            // ---- phase 1: lane e holds entry 64 w + e and tests it at the wave's ray positions
+            const unsigned j1 = w * 64u + lane;
+            const float4 e = sE[j1];
+            const float ec = sq3[j1].w;
+            const bool valid = j1 < in_round;
+            int pass_lo = 0, pass_hi = 0;
+            if (wave < 8u) {
+                const float u0 = valid ? org_x - e.x : __builtin_nanf("");      // NaN: every comparison below is false
+                const float v0 = org_y - e.y;
+                float dxx[8], adx[8], dyy[8], cdy[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    dxx[q] = u0 + (float)q;
+                    adx[q] = e.z * dxx[q];
+                    dyy[q] = v0 + (float)q;
+                    cdy[q] = ec * dyy[q] * dyy[q];
+                }
+                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e.w);
+            } else {
+                const float ex = valid ? e.x : __builtin_nanf("");
+#pragma unroll
+                for (int k = 0; k < 33; k++) {
+                    const float lx = (float)px0 + (float)(k < 17 ? 16 : k - 17) - 0.5f, ly = (float)py0 + (float)(k < 17 ? k : 16) - 0.5f;
+                    const float dx = lx - ex, dy = ly - e.y;
+                    const float E = fmaf(dx, fmaf(e.w, dy, e.z * dx), ec * dy * dy);
+                    const unsigned long long b = __ballot(1.0f >= E);
+                    // (s_nop: the wait states between the comparison's SGPR write and a VALU read of it, which the compiler cannot
+                    // see inside inline assembly)
+                    asm volatile("s_nop 1\n\tv_writelane_b32 %[lo], %[bl], %[l]\n\tv_writelane_b32 %[hi], %[bh], %[l]\n\ts_nop 0"
+                                 : [lo] "+v"(pass_lo), [hi] "+v"(pass_hi)
+                                 : [bl] "s"((unsigned)b), [bh] "s"((unsigned)(b >> 32)), [l] "n"(k));
+                }
+            }
+            // ---- phase 2: lane = ray, through its own passing entries in list order
+            unsigned long long pass = active ? ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo : 0ull;
+            unsigned long long used = 0ull;
+            if (centre) {
+                while (pass != 0ull) {
+                    const int jj = __builtin_ctzll(pass);
+                    pass &= pass - 1ull;
+                    const unsigned j = w * 64u + (unsigned)jj;
+                    if (ray_entry<true, 0>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j]))
+                        used |= 1ull << jj;
+                }
+                sUsedC[w][cidx] = used;
+            } else {
+                while (pass != 0ull) {
+                    const int jj = __builtin_ctzll(pass);
+                    pass &= pass - 1ull;
+                    const unsigned j = w * 64u + (unsigned)jj;
+                    if (ray_entry<true, 1>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j]))
+                        used |= 1ull << jj;
+                }
+                if (exists) sUsedK[w][kidx] = used;
+            }
+        }
+        __syncthreads();
+    }
+    if (centre && rounds > 0 && !s_over)
+        merge(rounds - 1);
+    if (!centre && exists)
+        sMaxK[kidx] = st.C6;
+    __syncthreads();
+    if (s_over) {
+        if (threadIdx.x == 0) redo[tile] = 1u;
+        return;
+    }
+    if (threadIdx.x == 0) redo[tile] = 0u;
+
+    if (inside) {                                                  // forward.cu:984-996
+        float c6 = st.C6;
+        const float k0 = sMaxK[kidx], k1 = sMaxK[kidx + 1u], k2 = sMaxK[kidx + 17u], k3 = sMaxK[kidx + 18u];
+        if (k0 > c6) c6 = k0;
+        if (k1 > c6) c6 = k1;
+        if (k2 > c6) c6 = k2;
+        if (k3 > c6) c6 = k3;
+        final_T[pix_id] = st.Ts[0];
+        n_contrib[pix_id] = st.last_contributor;
+        contrib_n[pix_id] = st.nloc;
+        out_color[0 * HW + pix_id] = st.C0 + st.Ts[0] * background[0];
+        out_color[1 * HW + pix_id] = st.C1 + st.Ts[0] * background[1];
+        out_color[2 * HW + pix_id] = st.C2 + st.Ts[0] * background[2];
+        out_color[3 * HW + pix_id] = 0.0f;                         // the caller's zero fill, rasterize_points.cu:273
+        out_color[4 * HW + pix_id] = 0.0f;
+        out_color[5 * HW + pix_id] = 0.0f;
+        out_color[6 * HW + pix_id] = c6;
         out_color[7 * HW + pix_id] = st.C7;
     }
 }
@@ -658,6 +877,7 @@ F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap, in
     I.pt_pix = take(PNn * sizeof(unsigned));
     I.pt_rank = take(PNn * sizeof(unsigned));
     I.perm = take(PNn * sizeof(unsigned));
+    I.redo = take((size_t)V * T * sizeof(unsigned));
     I.total = off;
     return I;
 }
@@ -668,6 +888,14 @@ int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_c
     F3DG_KLAUNCH(integrate_fill_kernel, dim3(1024), dim3(256), 0, s, (size_t)W * H, (size_t)PN, out_color,
                        out_alpha_integrated, out_color_integrated);
     F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+// diagnostic (tools): resident workgroups per CU of the two pass-1 kernels as the runtime computes it
+extern "C" int f3dg_debug_pass1_occupancy(int* rays_blocks, int* cull_blocks)
+{
+    F3DG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(rays_blocks, integrate_pass1_rays_kernel, F3DG_RAYS_THREADS, 0));
+    F3DG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(cull_blocks, integrate_pass1_cull_kernel, F3DG_BLOCK, 0));
     return F3DG_OK;
 }
 
@@ -687,10 +915,19 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int V, int P, int W, int H, float
     unsigned* n_contrib = reinterpret_cast<unsigned*>(ws + L.n_contrib);
     unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
     unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
-    if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 2)
+    if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 3) {
+        // the default: 545 shared rays per tile, then the per-pixel kernel on the tiles that hit the contributor limit (normally none)
+        unsigned* redo = reinterpret_cast<unsigned*>(ws + I.redo);
+        F3DG_KLAUNCH(integrate_pass1_rays_kernel, dim3((unsigned)V * (unsigned)T), dim3(F3DG_RAYS_THREADS), 0, s, V, P, T, W, H, tiles_x, focal_x, focal_y,
+                           hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
+                           out_color, final_T, n_contrib, contrib_ids, contrib_n, redo);
         F3DG_KLAUNCH(integrate_pass1_cull_kernel, dim3((unsigned)V * (unsigned)T), dim3(F3DG_BLOCK), 0, s, V, P, T, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
-                           out_color, final_T, n_contrib, contrib_ids, contrib_n);
+                           out_color, final_T, n_contrib, contrib_ids, contrib_n, redo);
+    } else if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 2)
+        F3DG_KLAUNCH(integrate_pass1_cull_kernel, dim3((unsigned)V * (unsigned)T), dim3(F3DG_BLOCK), 0, s, V, P, T, W, H, tiles_x, focal_x, focal_y,
+                           hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
+                           out_color, final_T, n_contrib, contrib_ids, contrib_n, (const unsigned*)nullptr);
     else
         for (int v = 0; v < V; v++) {       // the A/B variants of the tests: one camera per launch
             const float4* bbox = reinterpret_cast<const float4*>(ws + L.bbox) + (size_t)v * P;

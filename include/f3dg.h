@@ -213,6 +213,12 @@ int f3dg_integrate_points_view(void* stream, void* workspace, size_t workspace_b
                                const float* viewmatrix, float tan_fovx, float tan_fovy, float* out_color,
                                float* out_alpha_integrated, float* out_color_integrated, float* alpha_min);
 
+/* Diagnostic, BLOCKING: how many (camera, tile) pairs of the last preparation on this workspace reached the reference's limit of 1,024
+ * contributors in some pixel (forward.cu:972-976) and were therefore computed by the per-pixel kernel behind the shared-ray kernel
+ * (f3dg_integrate.hip: integrate_pass1_rays_kernel). Same shape arguments as the preparation. */
+int f3dg_debug_integrate_redo(void* stream, const void* workspace, int P, int PN_max, int W, int H, int n_views, long long max_rendered,
+                              int* h_tiles);
+
 /* present[i] = (view-space z of means3D[i] > 0.2), auxiliary.h:177-202. present is uint8 [P]. */
 int f3dg_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present);

@@ -56,7 +56,8 @@ def test_integrate_filters_are_bit_identical(kw):
     try:
         # (2, 1): the default, per-pixel ellipse test with Gaussians across the lanes; (1, 1): round 1's per-ray pre-test + box masks;
         # (2, 0): the plain transcription every variant must match bit for bit
-        for kernel, on in ((2, 1), (1, 1), (2, 0)):
+        # (3, 1): the default, 545 shared rays per tile (integrate_pass1_rays_kernel); (2, 1): round 2's per-pixel pass
+        for kernel, on in ((3, 1), (2, 1), (1, 1), (2, 0)):
             L.f3dg_set_option(b"render_kernel", kernel)
             L.f3dg_set_option(b"render_pretest", on)
             L.f3dg_set_option(b"render_cull", on)
@@ -65,9 +66,41 @@ def test_integrate_filters_are_bit_identical(kw):
         L.f3dg_set_option(b"render_kernel", 3)
         L.f3dg_set_option(b"render_pretest", 1)
         L.f3dg_set_option(b"render_cull", 1)
-    for r in res[:2]:
+    for r in res[:3]:
         for k in ("out", "ai", "ci", "radii"):
-            assert np.array_equal(r[k].view(np.uint32), res[2][k].view(np.uint32)), k
+            assert np.array_equal(r[k].view(np.uint32), res[3][k].view(np.uint32)), k
+
+
+def test_contributor_limit_tiles_are_redone_per_pixel():
+    """Pixels that reach the reference's 1,024 contributors (forward.cu:972-976) stop there while the rays they share with their
+    neighbours go on: the shared-ray kernel hands such tiles to the per-pixel kernel. Thousands of nearly transparent, large
+    splats per pixel; the result must be the plain transcription's bit for bit and the oracle's within tolerance."""
+    import ctypes as C
+    from f3dgaus_amd.diff_gof_rasterization import GaussianRasterizationSettings_GOF, integrate_prepare
+    dev = torch.device("cuda:0")
+    scene = make_scene(P=30000, res=(40, 36), s0=0.2, view="canonical")
+    scene["opacities"] = torch.full_like(scene["opacities"], 0.011)
+    pts = make_points(scene, 8000)
+    L = _lib.lib()
+    d = lambda t: None if t is None else t.to(dev)
+    rs = GaussianRasterizationSettings_GOF(36, 40, scene["tanfovx"], scene["tanfovy"], 0.0, torch.zeros(0), d(scene["bg"]), 1.0,
+                                           d(scene["viewmatrix"][0]), d(scene["projmatrix"][0]), scene["sh_degree"],
+                                           d(scene["campos"][0]), False, False)
+    prep = integrate_prepare(d(scene["means3D"]), d(scene["shs"]), None, d(scene["opacities"]), d(scene["scales"]),
+                             d(scene["rotations"]), None, None, rs, max_points=8000)
+    n = C.c_int(-1)
+    assert L.f3dg_debug_integrate_redo(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(prep.buffer.data_ptr()),
+                                       prep.P, prep.max_points, prep.W, prep.H, 1, prep.capacity, C.byref(n)) == 0
+    assert 0 < n.value <= 9, n.value                       # some of the 3 x 3 tiles, i.e. the limit was reached
+    o, h = run_both(scene, pts, dev)
+    assert_integrate_parity(o, h, "contributor limit")
+    try:
+        L.f3dg_set_option(b"render_pretest", 0); L.f3dg_set_option(b"render_cull", 0)
+        plain = hip_integrate(scene, pts, dev)
+    finally:
+        L.f3dg_set_option(b"render_pretest", 1); L.f3dg_set_option(b"render_cull", 1)
+    for k in ("out", "ai", "ci", "radii"):
+        assert np.array_equal(h[k].view(np.uint32), plain[k].view(np.uint32)), k
 
 
 def test_integrate_empty_inputs():
