@@ -463,17 +463,23 @@ integrate_pass1_cull_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
 // What is per PIXEL is cheap and derived afterwards: the contributor list = the entries any of its five rays used (in list order),
 // the last contributor, max depth = the maximum over its rays; colour, alpha and final T come from the centre ray alone.
 //
-// One 576-thread workgroup per (camera, tile): waves 0-3 hold the centre rays of the four 8x8 quadrants (lane = pixel), waves 4-7 the
-// corners (cx, cy) in 0..15 x 0..15 of the 17x17 grid, wave 8 the 33 corners of its last column and row. A round stages 256 list
-// entries (waves 4-7, while waves 0-3 still merge the previous round); every wave then takes the round in four 64-entry windows:
-// phase 1 with the Gaussians across the lanes (the record's conservative ellipse at the wave's 64 ray positions -- corners are half-
+// One 512-thread workgroup per (camera, tile): waves 0-3 hold the centre rays of the four 8x8 quadrants (lane = pixel), waves 4-7 the
+// corners (cx, cy) in 0..15 x 0..15 of the 17x17 grid; the 33 corners of its last column and row are a second, short pass of ONE of
+// the eight waves (which one rotates with the tile, so that no SIMD of a CU collects them all). A round stages 256 list entries
+// (waves 4-7, while waves 0-3 still merge the previous round) with a 5-bit mask per entry: which quadrants' ray positions / the edge
+// the box of its conservative ellipse reaches. Every wave compacts the round to the entries of its region and takes them in 64-entry
+// windows: phase 1 with the Gaussians across the lanes (the record's ellipse at the wave's 64 ray positions -- corners are half-
 // integer positions of the same grid, no inflation as in integrate_pass1_cull_kernel --, quad_ballots), phase 2 with the rays
-// across the lanes, each through its own passing entries; the "used" bits of a (ray, window) go to LDS, and after the round's second
-// barrier the pixel lanes OR their five rays' masks and append the contributors.
+// across the lanes, each through its own passing entries; a used entry sets its bit in the ray's 256-bit mask of the round (LDS),
+// and after the round's second barrier the pixel lanes OR their five rays' masks and append the contributors.
+// A ray is FINISHED once fl(T fl(1 - 1/255)) < 0.0001: every later entry either has alpha < 1/255 or fails `test_T < 0.0001`
+// (forward.cu:934-938; rounding is monotone and 1 - alpha <= 1 - 1/255), both a bare `continue` before anything is written -- the
+// reference walks on through the rest of the list for nothing. Finished rays leave phase 2, a tile whose rays are all finished
+// stops staging: the saturation exit of the compositing kernel, which integrate_pass1_cull_kernel does not have.
 // The one thing a shared ray cannot reproduce is a pixel that stops at 1,024 contributors (forward.cu:972-976: its rays end there
 // while its neighbours' go on): such a tile raises its `redo` flag and integrate_pass1_cull_kernel, launched behind this kernel on
 // the flagged tiles only, computes it pixel by pixel.
-#define F3DG_RAYS_THREADS 576
+#define F3DG_RAYS_THREADS 512
 __global__ void __launch_bounds__(F3DG_RAYS_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
                             const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
@@ -494,27 +500,23 @@ integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned px0 = tile_x * F3DG_TILE, py0 = tile_y * F3DG_TILE;
+    const unsigned quad = wave & 3u;
+    const bool edge_wave = wave == ((tile + view) & 7u);     // this wave also walks the 33 rays of the corner grid's last column and row
 
     // this lane's ray: grid position (gx, gy) inside the tile, centre (waves 0-3: 0..15) or corner (0..16, half a pixel up and left)
     const bool centre = wave < 4u;
-    unsigned gx, gy;
-    bool exists = true;
-    if (wave < 8u) {
-        gx = (wave & 1u) * 8u + (lane & 7u);
-        gy = ((wave >> 1) & 1u) * 8u + (lane >> 3);
-    } else {
-        gx = lane < 17u ? 16u : lane - 17u;
-        gy = lane < 17u ? lane : 16u;
-        exists = lane < 33u;
-    }
+    const unsigned gx = (quad & 1u) * 8u + (lane & 7u), gy = (quad >> 1) * 8u + (lane >> 3);
     // a corner is walked when the pixel up and left of it (or, on the tile's first column / row, the pixel it is the corner of) is in the image
     const unsigned ax = px0 + (centre || gx == 0u ? gx : gx - 1u), ay = py0 + (centre || gy == 0u ? gy : gy - 1u);
-    const bool active = exists && ax < (unsigned)W && ay < (unsigned)H;
+    const bool active = ax < (unsigned)W && ay < (unsigned)H;
     const float off = centre ? 0.0f : -0.5f;
-    const float pixf_x = (float)(px0 + gx) + 0.5f, pixf_y = (float)(py0 + gy) + 0.5f;
-    const float ray_x = (float)((pixf_x + off - W / 2.) / focal_x), ray_y = (float)((pixf_y + off - H / 2.) / focal_y);
+    const float ray_x = (float)(((float)(px0 + gx) + 0.5f + off - W / 2.) / focal_x), ray_y = (float)(((float)(py0 + gy) + 0.5f + off - H / 2.) / focal_y);
     // origin of the wave's 8x8 grid in the ellipse records' pixel-index coordinates
-    const float org_x = (float)(px0 + ((wave & 1u) * 8u)) + off, org_y = (float)(py0 + (((wave >> 1) & 1u) * 8u)) + off;
+    const float org_x = (float)(px0 + (quad & 1u) * 8u) + off, org_y = (float)(py0 + (quad >> 1) * 8u) + off;
+    // the edge ray of lanes 0..32 of the edge wave: corners (16, 0..16), then (0..15, 16)
+    const unsigned egx = lane < 17u ? 16u : lane - 17u, egy = lane < 17u ? lane : 16u;
+    const bool eactive = edge_wave && lane < 33u && (px0 + (egx == 0u ? 0u : egx - 1u)) < (unsigned)W && (py0 + (egy == 0u ? 0u : egy - 1u)) < (unsigned)H;
+    const float eray_x = (float)(((float)(px0 + egx) + 0.5f + -0.5f - W / 2.) / focal_x), eray_y = (float)(((float)(py0 + egy) + 0.5f + -0.5f - H / 2.) / focal_y);
 
     uint2 range = ranges[tile];
     if (hdr->overflow) range = make_uint2(0, 0);
@@ -523,22 +525,29 @@ integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
 
     __shared__ float4 sq0[ROUND], sq1[ROUND], sq2[ROUND], sq3[ROUND];      // v0..v3 | v4..v7 | v8 v9 opac K | r g b c
     __shared__ float4 sE[ROUND];                                           // conservative ellipse: cx cy a b (c = sq3.w)
-    __shared__ unsigned long long sUsedC[4][256];                          // [window][centre ray]: entries of the window the ray used
-    __shared__ unsigned long long sUsedK[4][289];                          // [window][corner ray]
+    __shared__ unsigned char sM[ROUND];                                    // bit q: its box reaches quadrant q's ray positions; bit 4: the edge
+    __shared__ __align__(16) unsigned char lists[9][ROUND];                // per wave (8: the edge pass): the round's entries of its region
+    __shared__ unsigned long long sUsedC[4][256];                          // [64 entries of the round][centre ray]: the entries the ray used
+    __shared__ unsigned long long sUsedK[4][289];                          // [..][corner ray]
     __shared__ float sMaxK[289];
-    __shared__ int s_over;
-    if (threadIdx.x == 0) s_over = 0;
+    __shared__ int s_over, s_alive[2];
+    if (threadIdx.x == 0) { s_over = 0; s_alive[0] = 0; s_alive[1] = 0; }
+    __syncthreads();
+    const float kFinished = 1.0f - 1.0f / 255.0f;       // fl(1 - alpha) of the smallest alpha that is not skipped
+    bool dead = !active, edead = !eactive;
 
-    Pass1State st;
+    Pass1State st, se;                                                     // se: the edge ray (Ts[1], C6 only)
 #pragma unroll
-    for (int k = 0; k < 5; k++) st.Ts[k] = 1.0f;
+    for (int k = 0; k < 5; k++) { st.Ts[k] = 1.0f; se.Ts[k] = 1.0f; }
     st.C0 = st.C1 = st.C2 = st.C6 = st.C7 = 0;
+    se.C0 = se.C1 = se.C2 = se.C6 = se.C7 = 0;
     st.last_contributor = 0; st.nloc = 0;
     // (pixel lanes = the centre-ray lanes)
     const bool inside = centre && active;
     const size_t pix_id = (size_t)W * (py0 + gy) + (px0 + gx);
     unsigned short* my_ids = contrib_ids + pix_id * F3DG_MAX_CONTRIB;
-    const unsigned kidx = gy * 17u + gx, cidx = gy * 16u + gx;
+    const unsigned kidx = gy * 17u + gx, cidx = gy * 16u + gx, eidx = egy * 17u + egx;
+    const unsigned long long lt = (1ull << lane) - 1ull;
 
     auto merge = [&](int i) {          // pixel lanes: contributors of round i = the entries any of the five rays used, in list order
         const unsigned in_round = min((unsigned)ROUND, n - (unsigned)i * ROUND);
@@ -560,30 +569,80 @@ integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
         }
     };
 
+    bool merged_all = false;
     for (int i = 0; i < rounds; i++) {
-        if (wave >= 4u && wave < 8u) {                       // stage round i
+        {
+            const int alive = __popcll(__ballot(!dead)) + __popcll(__ballot(!edead));
+            if (lane == 0 && alive) atomicAdd(&s_alive[i & 1], alive);
+        }
+        if (wave >= 4u) {                                    // stage round i
             const unsigned t = threadIdx.x - 256u, progress = (unsigned)i * ROUND + t;
+            unsigned m5 = 0;
             if (progress < n) {
                 const unsigned id = point_list[range.x + progress] & F3DG_ID_MASK;
                 const float4* src = reinterpret_cast<const float4*>(rec + id);
-                sq0[t] = src[0]; sq1[t] = src[1]; sq2[t] = src[2]; sq3[t] = src[3];
-                sE[t] = cull[id];
+                const float4 d3 = src[3];
+                sq0[t] = src[0]; sq1[t] = src[1]; sq2[t] = src[2]; sq3[t] = d3;
+                const float4 e = cull[id];
+                sE[t] = e;
+                // box of the ellipse (as ellipse_block_mask) against the ray positions: quadrant q's are q8 - 0.5 .. q8 + 7, the edge's 15.5
+                const float det = fmaf(e.z, d3.w, -0.25f * e.w * e.w);
+                m5 = 31u;
+                if (det > 0.0f) {
+                    const float hx = sqrtf(d3.w / det) * 1.0005f + 2e-3f, hy = sqrtf(e.z / det) * 1.0005f + 2e-3f;
+                    const float x0 = e.x - hx - (float)px0, x1 = e.x + hx - (float)px0, y0 = e.y - hy - (float)py0, y1 = e.y + hy - (float)py0;
+                    const unsigned mx = ((x0 <= 7.0f && x1 >= -0.5f) ? 1u : 0u) | ((x0 <= 15.0f && x1 >= 7.5f) ? 2u : 0u);
+                    const unsigned my = ((y0 <= 7.0f && y1 >= -0.5f) ? 1u : 0u) | ((y0 <= 15.0f && y1 >= 7.5f) ? 2u : 0u);
+                    m5 = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u);
+                    if ((x1 >= 15.5f && x0 <= 15.5f && y1 >= -0.5f && y0 <= 15.5f) || (y1 >= 15.5f && y0 <= 15.5f && x1 >= -0.5f && x0 <= 15.5f)) m5 |= 16u;
+                }
             }
-        } else if (centre && i > 0) {
+            sM[t] = (unsigned char)m5;
+        } else if (i > 0) {
             merge(i - 1);
         }
         __syncthreads();
         if (s_over)
             break;
-        const unsigned in_round = min((unsigned)ROUND, n - (unsigned)i * ROUND);
-        for (unsigned w = 0; w * 64u < in_round; w++) {
-            // ---- phase 1: lane e holds entry 64 w + e and tests it at the wave's ray positions
-            const unsigned j1 = w * 64u + lane;
+        if (s_alive[i & 1] == 0) {                           // every ray of the tile is finished (round i - 1 is merged)
+            merged_all = true;
+            break;
+        }
+        if (threadIdx.x == 0) s_alive[(i + 1) & 1] = 0;
+
+        // this wave's entries of the round (and, for the edge wave, the edge's), in list order; the rays' masks of the round start empty
+        unsigned cnt = 0, ecnt = 0;
+#pragma unroll
+        for (int c = 0; c < ROUND / 64; c++) {
+            const unsigned e = c * 64 + lane;
+            const unsigned m = sM[e];
+            const bool b = (m >> quad) & 1u;
+            const unsigned long long l = __ballot(b);
+            if (b) lists[wave][cnt + (unsigned)__popcll(l & lt)] = (unsigned char)e;
+            cnt += (unsigned)__popcll(l);
+            if (edge_wave) {
+                const bool be = (m >> 4) & 1u;
+                const unsigned long long le = __ballot(be);
+                if (be) lists[8][ecnt + (unsigned)__popcll(le & lt)] = (unsigned char)e;
+                ecnt += (unsigned)__popcll(le);
+            }
+            if (centre) sUsedC[c][cidx] = 0ull; else sUsedK[c][kidx] = 0ull;
+            if (edge_wave && lane < 33u) sUsedK[c][eidx] = 0ull;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        for (unsigned w0 = 0; w0 < cnt; w0 += 64u) {
+            if (__ballot(!dead) == 0ull)
+                break;
+            // ---- phase 1: lane e holds entry w0 + e of the wave's list and tests it at the wave's ray positions
+            const bool valid = w0 + lane < cnt;
+            const unsigned j1 = lists[wave][(w0 + lane) & 255u];
             const float4 e = sE[j1];
             const float ec = sq3[j1].w;
-            const bool valid = j1 < in_round;
             int pass_lo = 0, pass_hi = 0;
-            if (wave < 8u) {
+            {
                 const float u0 = valid ? org_x - e.x : __builtin_nanf("");      // NaN: every comparison below is false
                 const float v0 = org_y - e.y;
                 float dxx[8], adx[8], dyy[8], cdy[8];
@@ -595,8 +654,41 @@ integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
                     cdy[q] = ec * dyy[q] * dyy[q];
                 }
                 quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e.w);
+            }
+            // ---- phase 2: lane = ray, through its own passing entries in list order
+            unsigned long long pass = dead ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+            if (centre) {
+                while (pass != 0ull && !dead) {
+                    const int jj = __builtin_ctzll(pass);
+                    pass &= pass - 1ull;
+                    const unsigned j = lists[wave][w0 + (unsigned)jj];
+                    if (ray_entry<true, 0>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j])) {
+                        sUsedC[j >> 6][cidx] |= 1ull << (j & 63u);
+                        dead = st.Ts[0] * kFinished < 0.0001f;
+                    }
+                }
             } else {
+                while (pass != 0ull && !dead) {
+                    const int jj = __builtin_ctzll(pass);
+                    pass &= pass - 1ull;
+                    const unsigned j = lists[wave][w0 + (unsigned)jj];
+                    if (ray_entry<true, 1>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j])) {
+                        sUsedK[j >> 6][kidx] |= 1ull << (j & 63u);
+                        dead = st.Ts[1] * kFinished < 0.0001f;
+                    }
+                }
+            }
+        }
+        if (edge_wave) {
+            for (unsigned w0 = 0; w0 < ecnt; w0 += 64u) {
+                if (__ballot(!edead) == 0ull)
+                    break;
+                const bool valid = w0 + lane < ecnt;
+                const unsigned j1 = lists[8][(w0 + lane) & 255u];
+                const float4 e = sE[j1];
+                const float ec = sq3[j1].w;
                 const float ex = valid ? e.x : __builtin_nanf("");
+                int pass_lo = 0, pass_hi = 0;
 #pragma unroll
                 for (int k = 0; k < 33; k++) {
                     const float lx = (float)px0 + (float)(k < 17 ? 16 : k - 17) - 0.5f, ly = (float)py0 + (float)(k < 17 ? k : 16) - 0.5f;
@@ -609,36 +701,26 @@ integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
                                  : [lo] "+v"(pass_lo), [hi] "+v"(pass_hi)
                                  : [bl] "s"((unsigned)b), [bh] "s"((unsigned)(b >> 32)), [l] "n"(k));
                 }
-            }
-            // ---- phase 2: lane = ray, through its own passing entries in list order
-            unsigned long long pass = active ? ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo : 0ull;
-            unsigned long long used = 0ull;
-            if (centre) {
-                while (pass != 0ull) {
+                unsigned long long pass = edead ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+                while (pass != 0ull && !edead) {
                     const int jj = __builtin_ctzll(pass);
                     pass &= pass - 1ull;
-                    const unsigned j = w * 64u + (unsigned)jj;
-                    if (ray_entry<true, 0>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j]))
-                        used |= 1ull << jj;
+                    const unsigned j = lists[8][w0 + (unsigned)jj];
+                    if (ray_entry<true, 1>(se, eray_x, eray_y, sq0[j], sq1[j], sq2[j], sq3[j])) {
+                        sUsedK[j >> 6][eidx] |= 1ull << (j & 63u);
+                        edead = se.Ts[1] * kFinished < 0.0001f;
+                    }
                 }
-                sUsedC[w][cidx] = used;
-            } else {
-                while (pass != 0ull) {
-                    const int jj = __builtin_ctzll(pass);
-                    pass &= pass - 1ull;
-                    const unsigned j = w * 64u + (unsigned)jj;
-                    if (ray_entry<true, 1>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j]))
-                        used |= 1ull << jj;
-                }
-                if (exists) sUsedK[w][kidx] = used;
             }
         }
         __syncthreads();
     }
-    if (centre && rounds > 0 && !s_over)
+    if (centre && rounds > 0 && !s_over && !merged_all)
         merge(rounds - 1);
-    if (!centre && exists)
+    if (!centre)
         sMaxK[kidx] = st.C6;
+    if (edge_wave && lane < 33u)
+        sMaxK[eidx] = se.C6;
     __syncthreads();
     if (s_over) {
         if (threadIdx.x == 0) redo[tile] = 1u;
