@@ -86,6 +86,50 @@ __device__ __forceinline__ bool ray_entry(Pass1State& st, float rx, float ry, co
     return true;
 }
 
+// ray_entry split into its stateless part (everything up to alpha: branch-free, so that the compiler can interleave the evaluations of
+// TWO entries -- the dependent chain of one is a float32 division, a float64 island and an exponential) and the recurrence. The same
+// values and the same decisions: `hit` is the conjunction of the three tests ray_entry leaves on, evaluated on the same operands.
+struct RayEval { float alpha, t; bool hit; };
+__device__ __forceinline__ RayEval ray_eval(float rx, float ry, const float4& q0, const float4& q1, const float4& q2)
+{
+    const float n0 = q0.x * rx + q0.y * ry + q0.z;
+    const float n1 = q0.y * rx + q0.w * ry + q1.x;
+    const float n2 = q0.z * rx + q1.x * ry + q1.y;
+    const float AA = rx * n0 + ry * n1 + n2;
+    const float bhalf = q1.z * rx + q1.w * ry + q2.x;
+    const bool pre = bhalf * bhalf < q2.w * AA;          // certainly alpha < 1/255 (see ray_entry)
+    const float BB = 2 * bhalf;
+    const float CC = q2.y;
+    const float q = BB / AA;
+    RayEval r;
+    r.t = -0.5f * q;
+    const double min_value = -q * (BB / 4.) + CC;
+    float power = (float)(-0.5f * min_value);
+    if (power > 0.0f)
+        power = 0.0f;
+    r.alpha = fminf(0.99f, q2.z * expf(power));
+    r.hit = !pre && !(r.t <= F3DG_NEAR_PLANE) && !(r.alpha < 1.0f / 255.0f);
+    return r;
+}
+template <int K>
+__device__ __forceinline__ bool ray_apply(Pass1State& st, const RayEval& e, const float4& q3)
+{
+    const float test_T = st.Ts[K] * (1 - e.alpha);
+    if (!e.hit || test_T < 0.0001f)
+        return false;                                   // `continue`, NOT done (forward.cu:934-938)
+    if (K == 0) {
+        st.C0 += q3.x * e.alpha * st.Ts[0];
+        st.C1 += q3.y * e.alpha * st.Ts[0];
+        st.C2 += q3.z * e.alpha * st.Ts[0];
+    }
+    if (e.t > st.C6)
+        st.C6 = e.t;
+    if (K == 0)
+        st.C7 += e.alpha * st.Ts[0];
+    st.Ts[K] = test_T;
+    return true;
+}
+
 template <bool FILTER>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 integrate_pass1_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
@@ -480,7 +524,7 @@ integrate_pass1_cull_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
 // while its neighbours' go on): such a tile raises its `redo` flag and integrate_pass1_cull_kernel, launched behind this kernel on
 // the flagged tiles only, computes it pixel by pixel.
 #define F3DG_RAYS_THREADS 512
-__global__ void __launch_bounds__(F3DG_RAYS_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+__global__ void __launch_bounds__(F3DG_RAYS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
                             const uint2* __restrict__ ranges, const unsigned* __restrict__ point_list,
                             const F3dgRec* __restrict__ rec, const float4* __restrict__ cull,
@@ -657,25 +701,22 @@ integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
             }
             // ---- phase 2: lane = ray, through its own passing entries in list order
             unsigned long long pass = dead ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
-            if (centre) {
-                while (pass != 0ull && !dead) {
-                    const int jj = __builtin_ctzll(pass);
-                    pass &= pass - 1ull;
-                    const unsigned j = lists[wave][w0 + (unsigned)jj];
-                    if (ray_entry<true, 0>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j])) {
-                        sUsedC[j >> 6][cidx] |= 1ull << (j & 63u);
-                        dead = st.Ts[0] * kFinished < 0.0001f;
-                    }
-                }
-            } else {
-                while (pass != 0ull && !dead) {
-                    const int jj = __builtin_ctzll(pass);
-                    pass &= pass - 1ull;
-                    const unsigned j = lists[wave][w0 + (unsigned)jj];
-                    if (ray_entry<true, 1>(st, ray_x, ray_y, sq0[j], sq1[j], sq2[j], sq3[j])) {
-                        sUsedK[j >> 6][kidx] |= 1ull << (j & 63u);
-                        dead = st.Ts[1] * kFinished < 0.0001f;
-                    }
+            // (two entries per trip: their evaluations are independent and interleave; the recurrence takes them in list order)
+            while (pass != 0ull && !dead) {
+                const int ja = __builtin_ctzll(pass);
+                pass &= pass - 1ull;
+                const bool two = pass != 0ull;
+                const int jb = two ? __builtin_ctzll(pass) : ja;
+                pass &= pass - 1ull;                             // (0 stays 0)
+                const unsigned a = lists[wave][w0 + (unsigned)ja], b = lists[wave][w0 + (unsigned)jb];
+                const RayEval ea = ray_eval(ray_x, ray_y, sq0[a], sq1[a], sq2[a]);
+                const RayEval eb = ray_eval(ray_x, ray_y, sq0[b], sq1[b], sq2[b]);
+                if (centre) {
+                    if (ray_apply<0>(st, ea, sq3[a])) { sUsedC[a >> 6][cidx] |= 1ull << (a & 63u); dead = st.Ts[0] * kFinished < 0.0001f; }
+                    if (two && !dead && ray_apply<0>(st, eb, sq3[b])) { sUsedC[b >> 6][cidx] |= 1ull << (b & 63u); dead = st.Ts[0] * kFinished < 0.0001f; }
+                } else {
+                    if (ray_apply<1>(st, ea, sq3[a])) { sUsedK[a >> 6][kidx] |= 1ull << (a & 63u); dead = st.Ts[1] * kFinished < 0.0001f; }
+                    if (two && !dead && ray_apply<1>(st, eb, sq3[b])) { sUsedK[b >> 6][kidx] |= 1ull << (b & 63u); dead = st.Ts[1] * kFinished < 0.0001f; }
                 }
             }
         }
@@ -703,13 +744,16 @@ integrate_pass1_rays_kernel(int V, int P, int T, int W, int H, int tiles_x, floa
                 }
                 unsigned long long pass = edead ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
                 while (pass != 0ull && !edead) {
-                    const int jj = __builtin_ctzll(pass);
+                    const int ja = __builtin_ctzll(pass);
                     pass &= pass - 1ull;
-                    const unsigned j = lists[8][w0 + (unsigned)jj];
-                    if (ray_entry<true, 1>(se, eray_x, eray_y, sq0[j], sq1[j], sq2[j], sq3[j])) {
-                        sUsedK[j >> 6][eidx] |= 1ull << (j & 63u);
-                        edead = se.Ts[1] * kFinished < 0.0001f;
-                    }
+                    const bool two = pass != 0ull;
+                    const int jb = two ? __builtin_ctzll(pass) : ja;
+                    pass &= pass - 1ull;
+                    const unsigned a = lists[8][w0 + (unsigned)ja], b = lists[8][w0 + (unsigned)jb];
+                    const RayEval ea = ray_eval(eray_x, eray_y, sq0[a], sq1[a], sq2[a]);
+                    const RayEval eb = ray_eval(eray_x, eray_y, sq0[b], sq1[b], sq2[b]);
+                    if (ray_apply<1>(se, ea, sq3[a])) { sUsedK[a >> 6][eidx] |= 1ull << (a & 63u); edead = se.Ts[1] * kFinished < 0.0001f; }
+                    if (two && !edead && ray_apply<1>(se, eb, sq3[b])) { sUsedK[b >> 6][eidx] |= 1ull << (b & 63u); edead = se.Ts[1] * kFinished < 0.0001f; }
                 }
             }
         }
