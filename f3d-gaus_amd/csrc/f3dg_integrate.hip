@@ -901,15 +901,29 @@ integrate_points_kernel(int PN, const float* __restrict__ points3D, const float*
     float point_alpha = 0.f, point_T = 1.f;
     // second loop of integrateCUDA (forward.cu:1111-1176) for this point. num_iterated only ever matches the next
     // stored id when that id is larger (the u16 ids wrap beyond 65535 entries exactly as in the reference).
+    // (a contributor is three dependent loads -- its list position, the Gaussian id at that position, the record -- and the wave's time
+    // was that chain: the loop is software-pipelined, positions three contributors ahead, ids two, records one, so that the three
+    // loads of an iteration are independent of each other and of its arithmetic. Positions past the list or past the last contributor
+    // read entry 0 instead; they end the loop when their turn comes, exactly as before.)
     unsigned num_iterated = 0;
+    auto position = [&](unsigned p) -> unsigned { return p < nloc ? (unsigned)ids[p] : 0u; };
+    auto gaussian = [&](unsigned t) -> unsigned { return (t >= 1u && t <= last_contributor) ? point_list[range_x + t - 1u] & F3DG_ID_MASK : 0u; };
+    unsigned tA = position(0), tB = position(1), tC = position(2);
+    unsigned gB = gaussian(tB);
+    float4 q0, q1, q2;
+    {
+        const float4* src = reinterpret_cast<const float4*>(rec + gaussian(tA));
+        q0 = src[0]; q1 = src[1]; q2 = src[2];
+    }
     for (unsigned ptr = 0; ptr < nloc; ptr++) {
-        const unsigned target = ids[ptr];
+        const unsigned target = tA;
         if (target <= num_iterated || target > last_contributor)
             break;
         num_iterated = target;
-        const unsigned g = point_list[range_x + target - 1u] & F3DG_ID_MASK;
-        const float4* src = reinterpret_cast<const float4*>(rec + g);
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+        const float4* nsrc = reinterpret_cast<const float4*>(rec + gB);
+        const float4 n0q = nsrc[0], n1q = nsrc[1], n2q = nsrc[2];          // the next contributor's record
+        const unsigned gC = gaussian(tC);
+        const unsigned tD = position(ptr + 3u);
         const float n0 = q0.x * rx + q0.y * ry + q0.z;
         const float n1 = q0.y * rx + q0.w * ry + q1.x;
         const float n2 = q0.z * rx + q1.x * ry + q1.y;
@@ -921,11 +935,13 @@ integrate_points_kernel(int PN, const float* __restrict__ points3D, const float*
             t = depth;
         const float power = -0.5f * (AA * t * t + BB * t + CC);
         const float alpha = fminf(0.99f, q2.z * expf(power));
-        if (alpha < 1.0f / 255.0f)
-            continue;
-        const float test_T = point_T * (1 - alpha);
-        point_alpha += alpha * point_T;
-        point_T = test_T;
+        if (!(alpha < 1.0f / 255.0f)) {
+            const float test_T = point_T * (1 - alpha);
+            point_alpha += alpha * point_T;
+            point_T = test_T;
+        }
+        q0 = n0q; q1 = n1q; q2 = n2q;
+        tA = tB; tB = tC; tC = tD; gB = gC;
     }
     if (out_alpha_integrated)
         out_alpha_integrated[idx] = point_alpha;
