@@ -114,7 +114,27 @@ def main():
         st = glob.glob(os.path.join(src, "int_sweep_stats", "*kernel_stats.csv"))
         if st:
             out += ["rocprofv3 --kernel-trace --stats of `V=16 python tools/bench_integrate.py` (the whole script incl. the AlphaSweep preparations of 16 cameras, "
-                    "1 / 4 / 16 per call: the 16-camera launch of integrate_pass1_cull_kernel is its maximum):", ""] + kernel_table(st[0], 8) + [""]
+                    "1 / 4 / 16 per call: the 16-camera launch of integrate_pass1_rays_kernel is its maximum):", ""] + kernel_table(st[0], 8) + [""]
+        # the per-pixel pass of a 16-camera preparation on its own (tools/prof_pass1.py, tools/pmc_pass1.sh): kernel time and SQ counters
+        st = glob.glob(os.path.join(src, "p1_stats", "*kernel_stats.csv"))
+        if st:
+            out += ["rocprofv3 --kernel-trace --stats of `python tools/prof_pass1.py` (three preparations of 16 cameras of 589,824 Gaussians; "
+                    "integrate_pass1_cull_kernel behind the ray kernel only computes tiles that reached 1,024 contributors: none here):", ""] + kernel_table(st[0], 6) + [""]
+        rows = {}
+        for d in ("sq1", "sq2"):
+            f = glob.glob(os.path.join(src, "p1_pmc", d, "*counter_collection.csv"))
+            if f:
+                for r in csv.DictReader(open(f[0])):
+                    if "integrate_pass1_rays" in r["Kernel_Name"]:
+                        rows.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if rows:
+            m = {k: sum(v) / len(v) for k, v in rows.items()}
+            out += ["`integrate_pass1_rays_kernel`, SQ counters per 16-camera launch (rocprofv3 --pmc, PMC-only passes; round 2's "
+                    "integrate_pass1_cull_kernel on the same input: SQ_INSTS_VALU 9.0e9, SQ_INSTS_VALU_MUL_F64 2.46e8, lane utilisation 0.58, 13.4 ms):", "",
+                    "| counter | value |", "|---|---:|"] + [f"| {k} | {v:.4g} |" for k, v in sorted(m.items())]
+            if m.get("SQ_ACTIVE_INST_VALU"):
+                out += [f"| VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) | {m.get('SQ_THREAD_CYCLES_VALU', 0) / (64 * m['SQ_ACTIVE_INST_VALU']):.2f} |"]
+            out += [""]
         open(os.path.join(dst, "integrate.md"), "w").write("\n".join(out))
 
     # ---- every bench line of the run

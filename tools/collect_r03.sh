@@ -54,6 +54,9 @@ python $R/bench.py --workload c4 --images 64 --steps 1 --warmup 1 --backbone bf1
 python $R/tools/bench_integrate.py > $O/bench_integrate.log 2>&1
 for c in 0 1; do CFG=$c rocprofv3 --kernel-trace --stats --output-format csv -d $O/int_stats$c -o int -- python $R/tools/bench_integrate.py > $O/int_stats$c.log 2>&1; rm -f $O/int_stats$c/int_kernel_trace.csv; done
 V=16 rocprofv3 --kernel-trace --stats --output-format csv -d $O/int_sweep_stats -o int -- python $R/tools/bench_integrate.py > /dev/null 2>&1; rm -f $O/int_sweep_stats/int_kernel_trace.csv
+# the per-pixel pass of a 16-camera preparation on its own: kernel time, then two PMC-only passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p1_stats -o p1 -- python $R/tools/prof_pass1.py > $O/p1_stats.log 2>&1; rm -f $O/p1_stats/p1_kernel_trace.csv
+PASS=1 bash $R/tools/pmc_pass1.sh $TAG/p1_pmc > /dev/null 2>&1; PASS=2 bash $R/tools/pmc_pass1.sh $TAG/p1_pmc > /dev/null 2>&1
 cd $R
 python tests/tools/parity_report.py > $O/parity_report.md 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
