@@ -608,7 +608,7 @@ gsort_gather_rects_kernel(int P, u32* __restrict__ gv0, u32* __restrict__ gv1, c
 
 // duplicateWithKeys in (view, depth, id) order: sorted position k of view v emits the tiles of Gaussian perm[v][k]. The runs of a
 // workgroup's 256 Gaussians are consecutive in the output (a few instances each), so they are assembled in LDS and written out as
-// whole lines; a workgroup whose Gaussians cover more than DUP_CAP tiles writes its runs directly.
+// whole lines, DUP_CAP instances per window.
 #define F3DG_DUP_CAP 3072
 template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
@@ -630,53 +630,52 @@ duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict_
     const int in_block = min(F3DG_BLOCK, P - (int)(blockIdx.x * F3DG_BLOCK));
     const u32 base = first == 0 ? 0u : offsets_sorted[first - 1];
     const u32 n = offsets_sorted[first + in_block - 1] - base;
-    const bool staged = n <= (u32)F3DG_DUP_CAP;
+    // the workgroup's output range [base, base + n) is assembled in LDS one window of F3DG_DUP_CAP instances at a time and written out
+    // as whole lines: a thread emits the part of its Gaussian's run that falls into the window. (Until round 3 a workgroup whose
+    // Gaussians cover more than one window wrote its runs directly -- a few bytes per lane, lines apart: with large splats, 24 tiles
+    // per Gaussian at sigma0 = 0.05, that was every workgroup and the kernel ran at 1 TB/s.)
+    u32 off0 = 0, cnt = 0, x = 0, y = 0, g = 0;
     if (k < P) {
         const size_t pos = (size_t)v * P + k;
-        const u32 x = rx[pos], y = ry[pos];
+        x = rx[pos]; y = ry[pos];
         const u32 rminx = x & F3DG_RECT_COORD, rmaxx = (x >> 16) & F3DG_RECT_COORD, rminy = y & F3DG_RECT_COORD, rmaxy = (y >> 16) & F3DG_RECT_COORD;
         if (rmaxx > rminx && rmaxy > rminy) {
-            const u32 g = perm[pos];
-            u32 off = (pos == 0) ? 0 : offsets_sorted[pos - 1];
-            const u32 view_base = (u32)v << tile_bits;
-            // quadrant mask of an instance (f3dg_common.h: F3DG_ID_BITS): the halves of the first / last tile column and row that the
-            // conservative box misses are cleared
-            auto halves = [](u32 t, u32 tmin, u32 tmax, u32 word) -> u32 {
-                u32 m = 3u;
-                if (t == tmin && (word & F3DG_RECT_SKIP_LO)) m &= ~1u;
-                if (t + 1u == tmax && (word & F3DG_RECT_SKIP_HI)) m &= ~2u;
-                return m;
-            };
-            if (staged) {
-                off -= base;
-                for (u32 ty = rminy; ty < rmaxy; ty++) {
-                    const u32 my = halves(ty, rminy, rmaxy, y);
-                    for (u32 tx = rminx; tx < rmaxx; tx++) {
-                        const u32 mx = halves(tx, rminx, rmaxx, x);
-                        sk[off] = (G)(view_base | (ty * (u32)grid_x + tx));
-                        sv[off] = g | ((((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u)) << F3DG_ID_BITS);
-                        off++;
-                    }
-                }
-            } else {
-                for (u32 ty = rminy; ty < rmaxy; ty++) {
-                    const u32 my = halves(ty, rminy, rmaxy, y);
-                    for (u32 tx = rminx; tx < rmaxx; tx++) {
-                        const u32 mx = halves(tx, rminx, rmaxx, x);
-                        kgrp[off] = (G)(view_base | (ty * (u32)grid_x + tx));
-                        vals[off] = g | ((((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u)) << F3DG_ID_BITS);
-                        off++;
-                    }
-                }
-            }
+            g = perm[pos];
+            off0 = ((pos == 0) ? 0 : offsets_sorted[pos - 1]) - base;
+            cnt = (rmaxx - rminx) * (rmaxy - rminy);
         }
     }
-    if (staged) {
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < n; i += F3DG_BLOCK) {
-            kgrp[base + i] = sk[i];
-            vals[base + i] = sv[i];
+    const u32 rminx = x & F3DG_RECT_COORD, rmaxx = (x >> 16) & F3DG_RECT_COORD, rminy = y & F3DG_RECT_COORD, rmaxy = (y >> 16) & F3DG_RECT_COORD;
+    const u32 view_base = (u32)v << tile_bits;
+    // quadrant mask of an instance (f3dg_common.h: F3DG_ID_BITS): the halves of the first / last tile column and row that the
+    // conservative box misses are cleared
+    auto halves = [](u32 t, u32 tmin, u32 tmax, u32 word) -> u32 {
+        u32 m = 3u;
+        if (t == tmin && (word & F3DG_RECT_SKIP_LO)) m &= ~1u;
+        if (t + 1u == tmax && (word & F3DG_RECT_SKIP_HI)) m &= ~2u;
+        return m;
+    };
+    for (u32 wb = 0; wb < n; wb += (u32)F3DG_DUP_CAP) {
+        const u32 lo = off0 > wb ? off0 : wb;
+        const u32 hi = off0 + cnt < wb + (u32)F3DG_DUP_CAP ? off0 + cnt : wb + (u32)F3DG_DUP_CAP;
+        if (lo < hi) {
+            const u32 w = rmaxx - rminx, j0 = lo - off0;
+            u32 ty = rminy + j0 / w, tx = rminx + j0 % w;
+            u32 my = halves(ty, rminy, rmaxy, y);
+            for (u32 j = lo; j < hi; j++) {
+                const u32 mx = halves(tx, rminx, rmaxx, x);
+                sk[j - wb] = (G)(view_base | (ty * (u32)grid_x + tx));
+                sv[j - wb] = g | ((((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u)) << F3DG_ID_BITS);
+                if (++tx == rmaxx) { tx = rminx; ty++; my = halves(ty, rminy, rmaxy, y); }
+            }
         }
+        __syncthreads();
+        const u32 in_win = n - wb < (u32)F3DG_DUP_CAP ? n - wb : (u32)F3DG_DUP_CAP;
+        for (u32 i = threadIdx.x; i < in_win; i += F3DG_BLOCK) {
+            kgrp[base + wb + i] = sk[i];
+            vals[base + wb + i] = sv[i];
+        }
+        __syncthreads();
     }
 }
 
