@@ -288,8 +288,16 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
  * every list entry, from the box of the conservative alpha >= 1/255 ellipse), stages 64 records per window by global_load_lds, tests
  * them with the Gaussians across the lanes and blends with the pixels across the lanes; 2 = render2, four coupled waves per tile
  * with per-4x4-block lists; 1 = the round-1 pixel-lane kernel (its plain variant is the transcription-order baseline of the tests).
+ * "render_slide" (default 1): render3 with sliding half-windows (render3s_fwd_kernel) or fixed 64-entry windows (0).
+ * "render_lowocc" (default 1): launches of at most 2,048 quadrant waves (one or two 256^2 views) take render3l_fwd_kernel, which
+ * keeps the next window's gathers in flight behind phase 2; 0 = the general kernel for every launch.
  * "render_dma" (default 1): render3 stages records by global_load_lds_dwordx4 (1) or through registers (0); "render_lds_pad"
  * (default 0): extra dynamic LDS bytes per render3 workgroup (occupancy experiments).
+ * "bwd_occ" (default 5): waves per SIMD the compositing backward (render3_bwd_kernel) is compiled for (2..6).
+ * "small_path" (default 1): inference calls of one or two views of at most 2^18 Gaussians on at most 1,024 tiles take the three-launch
+ * path of f3dg_small.hip (2 = on, and forget the shapes an earlier overflow disabled); "small_debug", "time_launches": diagnostics.
+ * The render_kernel value also selects the per-pixel pass of f3dg_integrate: 3 = shared rays (integrate_pass1_rays_kernel), 2 = one
+ * pixel per lane with the culled lists, 1 = round 1's per-ray pre-test; all bit-identical.
  * "render_round" (default 192): list entries a workgroup of render2 stages per round (192 at 7 waves/SIMD or 256 at 6).
  * "render_fast" (default 1): arithmetic of the compositing forward: 0 = the reference's float32 / float64 operation order,
  * 1 = error-free float32 pairs for the float64 island and FMA-contracted accumulations downstream of alpha, in inference calls (no
