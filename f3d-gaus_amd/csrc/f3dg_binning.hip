@@ -274,13 +274,16 @@ __device__ __forceinline__ void scatter_chunk(const K* __restrict__ keys_in, con
         const u64 i = wave_base + (u64)r * 64 + lane;
         const bool valid = i < n;
         const u32 d = digit(key[r]);
-        u64 same = __ballot(valid);
+        // lanes with the same digit: a lane differs from lane L in bit b exactly where ballot(bit b) disagrees with L's own bit
+        // (sign-extended over the mask: one v_bfe_i32); the eight mismatch masks are OR-ed (v_or3) and inverted once
+        u64 diff = 0;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
+            const u32 own = (u32)((int)(d << (31 - b)) >> 31);
+            const u64 bal = __ballot(own != 0u);
+            diff |= bal ^ (((u64)own << 32) | own);
         }
+        const u64 same = __ballot(valid) & ~diff;
         const u32 below = (u32)__popcll(same & lane_lt);
         const u32 prev = sh.cnt[wave][d];
         rank[r] = prev + below;
