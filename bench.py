@@ -312,7 +312,9 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         rf["note"] = ("frac > 1: the byte formula counts every list entry, but a quadrant stops reading its tile's list when its 64 pixels are "
                       "saturated -- with splats this large most of every list is never staged, so the algorithmic bytes are not moved; the "
                       "kernel is bound by VALU issue, not by HBM (counter traffic: profiles/*/sigma005.md)")
-    rf.update({"traffic": None,      # HBM bytes need PMC counters: see traffic_from_profiles
+    # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes, which cannot run inside this process): the figure is
+    # the one of the newest committed profile of THIS configuration (see traffic_from_profiles for kernel, source and how), else null
+    rf.update({"traffic": (prof.get("traffic") or {}).get("bytes_per_launch"),
                "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
                "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
                "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
