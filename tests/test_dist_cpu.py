@@ -37,20 +37,38 @@ def _worker(rank, world, port, n_items, q):
     dist.destroy_process_group()
 
 
+
+def _run_world2(target, extra_args, attempts=2):
+    """Two spawned ranks on a free local port; rank 0's result from the queue. An ephemeral port can be taken between its
+    probe and the rendezvous (or a loaded host can miss a timeout): one retry on a fresh port before failing."""
+    import queue as _queue
+    last = None
+    for _ in range(attempts):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=(r, 2, port) + tuple(extra_args) + (q,)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            out = q.get(timeout=120)
+        except _queue.Empty as e:
+            out, last = None, e
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.terminate()
+        if out is not None and all(p.exitcode == 0 for p in procs):
+            return out
+        last = last or RuntimeError("exit codes %s" % [p.exitcode for p in procs])
+    raise AssertionError("world_size-2 gloo run failed twice: %r" % (last,))
+
+
 @pytest.mark.parametrize("n_items", [5, 8])
 def test_gather_frames_gloo_world2(n_items):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    out = _run_world2(_worker, (n_items,))
     assert out.shape == (n_items, 3, 4, 4)
     assert torch.equal(out[:, 0, 0, 0], torch.arange(n_items, dtype=torch.float32))
 
@@ -79,18 +97,7 @@ def _c4_worker(rank, world, port, n_images, q):
 
 
 def test_c4_step_gather_gloo_world2():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     n_images = 6
-    procs = [ctx.Process(target=_c4_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    out = _run_world2(_c4_worker, (n_images,))
     assert out.shape == (n_images * 8, 4, 4, 3)
     assert torch.equal(out[:, 0, 0, 0].long(), (torch.arange(n_images * 8) + 2) % 251)      # the last step's frames, in image order
