@@ -449,10 +449,11 @@ gsort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
     } else {
         u32 kbase;
         const bool compact = gsort_compact(minmax, ck.seg, kbase);
+        // (the keys are not read again after a view's LAST pass -- pass 2 of a compact view, pass 3 otherwise --: it does not write them)
         if (!compact)
-            scatter_chunk<u32, false, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{8 * PASS}, offsets, sh, skey);
+            scatter_chunk<u32, false, ShiftDigit>(keys_in, vals_in, PASS == 3 ? (u32*)nullptr : keys_out, vals_out, ck, ShiftDigit{8 * PASS}, offsets, sh, skey);
         else if constexpr (PASS == 2)
-            scatter_chunk<u32, false, CompactDigit>(keys_in, vals_in, keys_out, vals_out, ck, CompactDigit{kbase}, offsets, sh, skey);
+            scatter_chunk<u32, false, CompactDigit>(keys_in, vals_in, (u32*)nullptr, vals_out, ck, CompactDigit{kbase}, offsets, sh, skey);
     }
 }
 
