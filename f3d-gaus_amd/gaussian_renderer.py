@@ -62,14 +62,17 @@ def _epilogue_autograd(rendered_image, world_view_transform, W, H, FoVx, FoVy):
     return normal_world, output.permute(2, 0, 1)
 
 
-def pack_frames(raster):
+def pack_frames(raster, out=None):
     """raster [n,C>=3,H,W] float32 on the HIP device -> uint8 [n,H,W,3] = (255 * clip(raster[:, :3], 0, 1)).astype(uint8),
-    the frame format of visualize.py:416, in one kernel (f3dg_pack_frames)."""
+    the frame format of visualize.py:416, in one kernel (f3dg_pack_frames). ``out``: a contiguous uint8 [n,H,W,3] tensor to fill."""
     if raster.device.type != "cuda":
         raise RuntimeError("pack_frames needs a tensor on a HIP device (no CPU fallback)")
     r = raster.contiguous().float()
     n, Cc, H, W = r.shape
-    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=r.device)
+    if out is None:
+        out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=r.device)
+    elif out.dtype != torch.uint8 or out.device != r.device or not out.is_contiguous() or out.numel() != n * H * W * 3:
+        raise RuntimeError(f"out must be a contiguous uint8 tensor of shape ({n}, {H}, {W}, 3) on {r.device}")
     rc = _lib.lib().f3dg_pack_frames(_stream(), n, H, W, Cc, _lib.ptr(r), _lib.ptr(out))
     _lib.check(rc, "f3dg_pack_frames")
     return out
