@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libf3dg_hip.so")
 
-OK, ERR_BAD_ARG, ERR_WORKSPACE, ERR_OVERFLOW, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+OK, ERR_BAD_ARG, ERR_WORKSPACE, ERR_OVERFLOW, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 FLAG_SAVE_AUX, FLAG_BG_PER_VIEW = 1, 2
 
 _ERR_TEXT = {
@@ -16,6 +16,7 @@ _ERR_TEXT = {
     ERR_OVERFLOW: "instance capacity (max_rendered) exceeded",
     ERR_HIP: "HIP runtime error",
     ERR_UNSUPPORTED: "unsupported configuration",
+    ERR_STATE: "backward on a workspace whose last forward kept no auxiliary planes (not a save_aux call of the general path)",
 }
 
 _p, _i, _f, _ll, _sz, _u = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t, C.c_uint

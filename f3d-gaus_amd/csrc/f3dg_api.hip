@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <time.h>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -91,22 +92,33 @@ int g_f3dg_small_path = 1;
 int g_f3dg_small_debug = 0;
 namespace {
 // shapes (P, n_views, W, H) whose small-call path overflowed a tile list: they take the general path from then on
+// (the library is called from several host threads -- ctypes releases the GIL -- so the process-global tables take a mutex)
 struct SmallShape { unsigned v[4]; };
 std::vector<SmallShape> g_small_disabled;
+std::mutex g_small_mutex, g_sites_mutex;
 bool small_disabled(unsigned P, unsigned V, unsigned W, unsigned H)
 {
+    std::lock_guard<std::mutex> lock(g_small_mutex);
     for (const SmallShape& d : g_small_disabled)
         if (d.v[0] == P && d.v[1] == V && d.v[2] == W && d.v[3] == H) return true;
     return false;
 }
+void small_disable(unsigned P, unsigned V, unsigned W, unsigned H)
+{
+    std::lock_guard<std::mutex> lock(g_small_mutex);
+    for (const SmallShape& d : g_small_disabled)
+        if (d.v[0] == P && d.v[1] == V && d.v[2] == W && d.v[3] == H) return;
+    g_small_disabled.push_back({{P, V, W, H}});
+}
 } // namespace
-unsigned long long g_f3dg_kernel_launches = 0;      // host-side counter of F3DG_KLAUNCH (not thread-safe: a diagnostic)
+std::atomic<unsigned long long> g_f3dg_kernel_launches{0};      // host-side counter of F3DG_KLAUNCH
 int g_f3dg_render_pretest = 1;
 int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
+int g_f3dg_render_wpb = 1;
 int g_f3dg_render_slide = 1;
 int g_f3dg_render_lowocc = 1;
 int g_f3dg_render_lds_pad = 0;
@@ -121,13 +133,14 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; return F3DG_OK; }
-    if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) g_small_disabled.clear(); return F3DG_OK; }
+    if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) { std::lock_guard<std::mutex> lock(g_small_mutex); g_small_disabled.clear(); } return F3DG_OK; }
     if (name && strcmp(name, "small_debug") == 0) { g_f3dg_small_debug = value; return F3DG_OK; }
     if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = (value >= 2 && value <= 6) ? value : 5; return F3DG_OK; }
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_wpb") == 0) { g_f3dg_render_wpb = value == 4 ? 4 : 1; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
@@ -148,6 +161,7 @@ long long f3dg_now_ns()
 }
 void f3dg_note_launch_time(const char* file, int line, long long ns)
 {
+    std::lock_guard<std::mutex> lock(g_sites_mutex);
     for (LaunchSite& s : g_sites)
         if (s.file == file && s.line == line) { s.ns += ns; s.n++; if (ns > s.max_ns) s.max_ns = ns; return; }
     g_sites.push_back({file, line, ns, 1, ns});
@@ -155,6 +169,7 @@ void f3dg_note_launch_time(const char* file, int line, long long ns)
 // diagnostic: prints (stderr) the host time spent inside hipLaunchKernelGGL per launch site since the last reset
 extern "C" int f3dg_debug_launch_times(int reset)
 {
+    std::lock_guard<std::mutex> lock(g_sites_mutex);
     for (const LaunchSite& s : g_sites) {
         const char* base = strrchr(s.file, '/');
         fprintf(stderr, "%-22s:%4d  %6lld launches  %8.2f us avg  %9.1f us max\n", base ? base + 1 : s.file, s.line, s.n,
@@ -166,9 +181,7 @@ extern "C" int f3dg_debug_launch_times(int reset)
 
 extern "C" long long f3dg_debug_launch_count(int reset)
 {
-    const long long n = (long long)g_f3dg_kernel_launches;
-    if (reset) g_f3dg_kernel_launches = 0;
-    return n;
+    return (long long)(reset ? g_f3dg_kernel_launches.exchange(0ull) : g_f3dg_kernel_launches.load());
 }
 
 extern "C" int f3dg_profile_enable(int on)
@@ -569,8 +582,7 @@ extern "C" int f3dg_read_status(void* stream, const void* workspace, long long* 
     F3DG_HIP_CHECK(hipMemcpyAsync(&h, workspace, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
     F3DG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (h_num_rendered) *h_num_rendered = (long long)h.num_rendered;
-    if (h.small_overflow && !small_disabled(h.small_shape[0], h.small_shape[1], h.small_shape[2], h.small_shape[3]))
-        g_small_disabled.push_back({{h.small_shape[0], h.small_shape[1], h.small_shape[2], h.small_shape[3]}});     // the retry takes the general path
+    if (h.small_overflow) small_disable(h.small_shape[0], h.small_shape[1], h.small_shape[2], h.small_shape[3]);     // the retry takes the general path
     return h.overflow ? F3DG_ERR_OVERFLOW : F3DG_OK;
 }
 
@@ -581,7 +593,8 @@ extern "C" int f3dg_backward_pairs(void* stream, const void* workspace, long lon
     F3DG_HIP_CHECK(hipMemcpyAsync(&h, workspace, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
     F3DG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     *h_pairs = (long long)h.bwd_pairs;
-    return F3DG_OK;
+    // the backward found a workspace whose last forward kept no auxiliary planes / took the small-call path: it walked nothing
+    return h.bwd_stale ? F3DG_ERR_STATE : F3DG_OK;
 }
 
 extern "C" long long f3dg_forward(void* stream, void* workspace, size_t workspace_bytes, long long max_rendered,

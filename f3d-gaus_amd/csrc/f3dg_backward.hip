@@ -156,7 +156,12 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
     const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
 
     uint2 range = ranges[(size_t)view * T + tile];
-    if (hdr->overflow) range = make_uint2(0, 0);
+    // no lists to walk after an overflow -- and none that belong to this call when the workspace's last forward kept no auxiliary
+    // planes (an inference call) or took the small-call path (its lists are elsewhere): all gradients stay zero, the header says why
+    if (hdr->overflow || hdr->save_aux == 0u || hdr->small_path != 0u) {
+        range = make_uint2(0, 0);
+        if (!hdr->overflow && blockIdx.x == 0 && threadIdx.x == 0) const_cast<F3dgHeader*>(hdr)->bwd_stale = 1u;
+    }
     const int rounds = (int)((range.y - range.x + F3DG_BLOCK - 1) / F3DG_BLOCK);
     int toDo = (int)(range.y - range.x);
 
@@ -237,19 +242,9 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
             float t = 0, G = 0, alpha = 0;
             if (active) {
                 if (alpha_fast) {
-                    // blend_entry_fast of f3dg_render.hip, operation for operation (the forward of this workspace used it)
-                    const float r = __builtin_amdgcn_rcpf(aaf);
-                    const float t0 = -bhalf * r;
-                    t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+                    // the forward of this workspace took the fast arithmetic: the same function, to the bit
+                    f3dg_fast_t_G(aaf, bhalf, CC, t, G);
                     if (t < 0.2f) active = false;
-                    const float p = bhalf * bhalf;
-                    const float e = fmaf(bhalf, bhalf, -p);
-                    const float q1 = p * r;
-                    const float q2_ = (fmaf(-q1, aaf, p) + e) * r;
-                    const float min_value = (CC - q1) - q2_;
-                    float power = -0.5f * min_value;
-                    if (power > 0.0f) power = 0.0f;
-                    G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
                 } else {
                     const double q = BB / AA;                          // one division: -BB / (2 * AA) == -0.5 * (BB / AA) exactly
                     t = (float)(-0.5 * q);
@@ -422,7 +417,12 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
 
     uint2 range = ranges[(size_t)view * T + tile];
-    if (hdr->overflow) range = make_uint2(0, 0);
+    // no lists to walk after an overflow -- and none that belong to this call when the workspace's last forward kept no auxiliary
+    // planes (an inference call) or took the small-call path (its lists are elsewhere): all gradients stay zero, the header says why
+    if (hdr->overflow || hdr->save_aux == 0u || hdr->small_path != 0u) {
+        range = make_uint2(0, 0);
+        if (!hdr->overflow && blockIdx.x == 0 && threadIdx.x == 0) const_cast<F3dgHeader*>(hdr)->bwd_stale = 1u;
+    }
 
     __shared__ float4 sq0[F3DG_BLOCK], sq1[F3DG_BLOCK], sq2[F3DG_BLOCK], sq3[F3DG_BLOCK];
     __shared__ float4 staged_conic[F3DG_BLOCK];
@@ -540,19 +540,9 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
             float t = 0, G = 0, alpha = 0;
             if (active) {
                 if (alpha_fast) {
-                    // blend_entry_fast of f3dg_render.hip, operation for operation (the forward of this workspace used it)
-                    const float r = __builtin_amdgcn_rcpf(aaf);
-                    const float t0 = -bhalf * r;
-                    t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+                    // the forward of this workspace took the fast arithmetic: the same function, to the bit
+                    f3dg_fast_t_G(aaf, bhalf, CC, t, G);
                     if (t < 0.2f) active = false;
-                    const float p = bhalf * bhalf;
-                    const float e = fmaf(bhalf, bhalf, -p);
-                    const float q1 = p * r;
-                    const float q2_ = (fmaf(-q1, aaf, p) + e) * r;
-                    const float min_value = (CC - q1) - q2_;
-                    float power = -0.5f * min_value;
-                    if (power > 0.0f) power = 0.0f;
-                    G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
                     alpha = fminf(0.99f, q2.z * G);
                 } else {
                     const double AA = aaf;
@@ -745,7 +735,12 @@ render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
 
     uint2 range = ranges[(size_t)view * T + tile];
-    if (hdr->overflow) range = make_uint2(0, 0);
+    // no lists to walk after an overflow -- and none that belong to this call when the workspace's last forward kept no auxiliary
+    // planes (an inference call) or took the small-call path (its lists are elsewhere): all gradients stay zero, the header says why
+    if (hdr->overflow || hdr->save_aux == 0u || hdr->small_path != 0u) {
+        range = make_uint2(0, 0);
+        if (!hdr->overflow && blockIdx.x == 0 && threadIdx.x == 0) const_cast<F3dgHeader*>(hdr)->bwd_stale = 1u;
+    }
 
     __shared__ float4 sR[4][64];          // records of the window, [16-byte chunk][entry] (global_load_lds image)
     __shared__ float4 sC[64];             // 2D conic + opacity * coef
@@ -881,19 +876,9 @@ render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             float t = 0, G = 0, alpha = 0;
             if (active) {
                 if (alpha_fast) {
-                    // blend_entry_fast of f3dg_render.hip, operation for operation (the forward of this workspace used it)
-                    const float r = __builtin_amdgcn_rcpf(aaf);
-                    const float t0 = -bhalf * r;
-                    t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+                    // the forward of this workspace took the fast arithmetic: the same function, to the bit
+                    f3dg_fast_t_G(aaf, bhalf, CC, t, G);
                     if (t < 0.2f) active = false;
-                    const float p = bhalf * bhalf;
-                    const float e = fmaf(bhalf, bhalf, -p);
-                    const float q1_ = p * r;
-                    const float q2_ = (fmaf(-q1_, aaf, p) + e) * r;
-                    const float min_value = (CC - q1_) - q2_;
-                    float power = -0.5f * min_value;
-                    if (power > 0.0f) power = 0.0f;
-                    G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
                     alpha = fminf(0.99f, q2.z * G);
                 } else {
                     const double AA = aaf;

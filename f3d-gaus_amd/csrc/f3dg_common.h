@@ -51,7 +51,8 @@ struct F3dgHeader {
     unsigned int num_rendered;   // total (Gaussian, tile) instances of the call (all views)
     unsigned int overflow;       // 1 if num_rendered > capacity
     unsigned int capacity;       // instance capacity the workspace was carved for
-    unsigned int reserved1[3];
+    unsigned int bwd_stale;      // 1: f3dg_backward ran on a workspace whose last forward was not a SAVE_AUX call of the general path
+    unsigned int reserved1[2];
     unsigned int alpha_fast;      // arithmetic the compositing forward of this call used for alpha (1: error-free float32 pairs): the
                                   // backward must repeat it to the bit
     unsigned int save_aux;        // 1 when the forward of this workspace ran with F3DG_FLAG_SAVE_AUX (the auxiliary planes are valid)
@@ -70,6 +71,43 @@ struct F3dgHeader {
 //   f[15]     c of the conservative ellipse (f3dg_preprocess.hip); the view-space depth (forward.cu:388) is in `depths`
 // The first three float4 are everything the conservative pre-test needs; the 4th is only read by contributors.
 struct __attribute__((aligned(16))) F3dgRec { float f[F3DG_REC_FLOATS]; };
+
+// The "fast" arithmetic of a (pixel, Gaussian) pair up to G = exp(power) (option render_fast; f3dg_render.hip: blend_entry_fast). ONE
+// definition, because the compositing backward must repeat the forward's alpha to the bit when the forward took this mode
+// (F3dgHeader::alpha_fast). aaf, bhalf are the reference's own float32 a and b / 2 (forward.cu:499-509, in its operation order: their
+// rounding errors are amplified 1e5..1e6 x by the cancellation below and must be reproduced, not improved on), CC is the quadric's
+// constant. The reference's float64 island (forward.cu:511-522) becomes error-free float32 pairs:
+//   b^2 = p + e exactly (FMA), q1 = p r, q2 = ((p - q1 a) + e) r with r ~ 1/a: b^2/a = q1 + q2 to ~2^-45; C - q1 is exact (Sterbenz)
+//   wherever the exponent matters, so min_value = (C - q1) - q2 carries one rounding of a number of magnitude <~ 20;
+//   t = -b/a = -b r (<= 1.5 ulp: v_rcp_f32 is good to 1 ulp; round 3 spent two more FMAs on a Newton step for it);
+//   G = exp(min(-min_value / 2, 0)) as v_exp_f32(min(min_value * (-log2(e) / 2), 0)): one multiply and one v_min instead of the
+//   reference's multiply, compare + select, and the log2(e) multiply (a NaN exponent gives G = 1 where the reference's gives NaN:
+//   both are garbage, and no finite record produces one).
+#ifndef F3DG_FAST_R03
+#define F3DG_FAST_R03 0
+#endif
+__device__ __forceinline__ void f3dg_fast_t_G(float aaf, float bhalf, float CC, float& t, float& G)
+{
+    const float r = __builtin_amdgcn_rcpf(aaf);
+#if F3DG_FAST_R03      // A/B switch: round 3's sequence (Newton step for t, compare + select clamp, separate log2(e) multiply): +5 VALU per pair
+    const float t0 = -bhalf * r;
+    t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+#else
+    t = -bhalf * r;
+#endif
+    const float p = bhalf * bhalf;
+    const float e = fmaf(bhalf, bhalf, -p);
+    const float q1 = p * r;
+    const float q2 = (fmaf(-q1, aaf, p) + e) * r;
+    const float min_value = (CC - q1) - q2;
+#if F3DG_FAST_R03
+    float power = -0.5f * min_value;
+    if (power > 0.0f) power = 0.0f;
+    G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+#else
+    G = __builtin_amdgcn_exp2f(fminf(min_value * -0.7213475204444817f, 0.0f));
+#endif
+}
 
 // Host-side description of where each array lives inside the workspace (byte offsets).
 struct F3dgLayout {
@@ -126,12 +164,13 @@ struct F3dgIntegLayout {
 F3dgIntegLayout f3dg_integ_layout(int P, int PN, int W, int H, long long cap, int V = 1);   // V cameras prepared together
 
 // every kernel launch of the library goes through this macro: f3dg_debug_launch_count reports how many a call sequence issued
-extern unsigned long long g_f3dg_kernel_launches;
+#include <atomic>
+extern std::atomic<unsigned long long> g_f3dg_kernel_launches;
 // (host-side cost of every launch site: option "time_launches" + f3dg_debug_launch_times, a diagnostic of the small-call path)
 extern int g_f3dg_time_launches;
 void f3dg_note_launch_time(const char* file, int line, long long ns);
 long long f3dg_now_ns();
-#define F3DG_KLAUNCH(...) do { ++g_f3dg_kernel_launches;                                                                   \
+#define F3DG_KLAUNCH(...) do { g_f3dg_kernel_launches.fetch_add(1ull, std::memory_order_relaxed);                                                                   \
         if (g_f3dg_time_launches) { const long long t0_ = f3dg_now_ns(); hipLaunchKernelGGL(__VA_ARGS__);                  \
                                     f3dg_note_launch_time(__FILE__, __LINE__, f3dg_now_ns() - t0_); }                      \
         else hipLaunchKernelGGL(__VA_ARGS__); } while (0)
@@ -193,6 +232,7 @@ extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is c
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
 extern int g_f3dg_render_lowocc;       // 1 (default): launches of at most 2048 quadrant waves take render3l_fwd_kernel (next window's gathers in flight)
 extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding half-window (render3s_fwd_kernel); 0: fixed 64-entry windows
+extern int g_f3dg_render_wpb;          // quadrant waves per render3s workgroup: 1 (default) or 4 (a tile's four waves start together on one CU)
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);
 void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);

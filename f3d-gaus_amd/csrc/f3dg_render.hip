@@ -123,23 +123,12 @@ __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor
 __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contributor, float n0, float n1, float n2, float aaf,
                                                  float bhalf, float CC, float opac, float cr, float cg, float cb)
 {
-    const float r = __builtin_amdgcn_rcpf(aaf);
-    const float t0 = -bhalf * r;
-    const float t = fmaf(fmaf(-aaf, t0, -bhalf), r, t0);
+    float t, G;
+    f3dg_fast_t_G(aaf, bhalf, CC, t, G);
     // (double)t <= 0.2  <=>  t < 0.2f: 0.2f is the float just above 0.2 (false for NaN, as the reference's test). Tested together
     // with alpha below: a wave nearly always holds a lane that passes, so an early branch here only costs scalar instructions
     const bool behind = t < 0.2f;
-
-    const float p = bhalf * bhalf;
-    const float e = fmaf(bhalf, bhalf, -p);
-    const float q1 = p * r;
-    const float q2 = (fmaf(-q1, aaf, p) + e) * r;
-    const float min_value = (CC - q1) - q2;
-    float power = -0.5f * min_value;
-    if (power > 0.0f)
-        power = 0.0f;
-
-    const float alpha = fminf(0.99f, opac * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+    const float alpha = fminf(0.99f, opac * G);
     if (behind || alpha < 1.0f / 255.0f)
         return false;
     const float Tr = st.Tr;
@@ -696,6 +685,24 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 // The conservative filters only drop pairs that are a bare `continue` in the reference, so the images are bit-identical to the
 // plain transcription within an arithmetic mode (tests/test_raster_forward_gpu.py). LDS: 4 KB of records + 1 KB of queue per wave.
 
+// phase 2 reads the four 16-byte chunks of a record; of chunks 2 and 3 it uses three words (K and the ellipse's c are phase 1's), and
+// hipcc narrows those loads to ds_read_b96 -- which takes 8 LDS cycles per wave where ds_read_b128 takes 4 (MI355X_MICROARCH.md, LDS
+// table). An empty asm that "uses" the fourth word keeps the loads 16 bytes wide.
+#ifndef F3DG_R3_B128
+#define F3DG_R3_B128 1
+#endif
+#if F3DG_R3_B128
+#define F3DG_FULL16(a, b) asm volatile("" :: "v"((a).w), "v"((b).w))
+#else
+#define F3DG_FULL16(a, b) do { } while (0)
+#endif
+#ifndef F3DG_R3S_PRIO
+#define F3DG_R3S_PRIO 0
+#endif
+#ifndef F3DG_R3S_BREAK
+#define F3DG_R3S_BREAK 0
+#endif
+
 #define F3DG_R3_WIN 64              // list entries per window = lanes
 #define F3DG_R3_RING 128            // queue ring of (list position, id) pairs
 #define F3DG_R3_FLAG 0x80000000u    // contributor values of the current window are slots (flag | slot) until the window ends
@@ -815,6 +822,7 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             const int j = __builtin_ctzll(pass);
             pass &= pass - 1;
             const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
+            F3DG_FULL16(q2, q3);
             const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
             const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
@@ -875,19 +883,23 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 // e + 32 share entry e and split the quadrant's rows: half_ballots), and phase 2 runs until the now-older half is finished by
 // everybody, pixels that are through with it already working on the newer half. Same LDS (4 KB of records), same phase-1 cost per
 // entry; the model gives 0.64 (15 % fewer phase-2 trips). Per pixel the sequence of blended entries is unchanged.
-template <bool SAVE_AUX, bool FAST, int OCC>
-__global__ void __launch_bounds__(64, OCC)
+template <bool SAVE_AUX, bool FAST, int OCC, int WPB>
+__global__ void __launch_bounds__(64 * WPB, OCC)
 render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                     const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                     const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
                     const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
                     float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
 {
+    // WPB = 1: a workgroup is one quadrant's wave. WPB = 4 (option render_wpb): the four quadrant waves of a tile are one workgroup --
+    // still no barrier and nothing shared, but they start together on one CU, so the records the second to fourth wave gather are
+    // in that CU's L1 / the XCD's L2 already
     unsigned view, unit;
-    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
-    const unsigned tile = unit >> 2, quad = unit & 3u;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, (4u / (unsigned)WPB) * (unsigned)T, view, unit);
+    const unsigned wv = WPB == 1 ? 0u : (threadIdx.x >> 6);
+    const unsigned tile = WPB == 4 ? unit : unit >> 2, quad = WPB == 4 ? wv : unit & 3u;
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
-    const unsigned lane = threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
     const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
     const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
     const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
@@ -901,9 +913,12 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     if (hdr->overflow) range = make_uint2(0, 0);
     const unsigned n = range.y - range.x;
 
-    __shared__ float4 sR[4][F3DG_R3_WIN];     // records, [16-byte chunk][slot]; slots 0..31 and 32..63 are the two halves of the window
-    __shared__ uint2 sQ[F3DG_R3_RING];        // kept (list position, Gaussian id) pairs not staged yet, ring
-    __shared__ unsigned sP[SAVE_AUX ? F3DG_R3_WIN : 1];   // list position of every staged slot (the reference's `contributor`)
+    __shared__ float4 sR_[WPB][4][F3DG_R3_WIN];     // records, [16-byte chunk][slot]; slots 0..31 and 32..63 are the two halves of the window
+    __shared__ uint2 sQ_[WPB][F3DG_R3_RING];        // kept (list position, Gaussian id) pairs not staged yet, ring
+    __shared__ unsigned sP_[WPB][SAVE_AUX ? F3DG_R3_WIN : 1];   // list position of every staged slot (the reference's `contributor`)
+    float4 (*sR)[F3DG_R3_WIN] = sR_[wv];
+    uint2* sQ = sQ_[wv];
+    unsigned* sP = sP_[wv];
 
     const F3dgRec* vrec = rec + (size_t)view * P;
     const float4* vcull = cull + (size_t)view * P;
@@ -933,6 +948,9 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     unsigned idn = lane < n ? point_list[range.x + lane] : 0u;
     if (__ballot(!done) != 0ull)
     for (;;) {
+#if F3DG_R3S_PRIO
+        __builtin_amdgcn_s_setprio(F3DG_R3S_PRIO);     // scan + staging are chains of memory latencies: their loads should leave first
+#endif
         // ---- scan: keep the entries whose box reaches this quadrant until 32 are pending
         while (qpend < 32u && cursor < n) {
             const unsigned idm = idn, pos = cursor + lane;
@@ -975,6 +993,9 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         if (hl < m) ec = sR[3][base + hl].w;
         qhead += m;
         qpend -= m;
+#if F3DG_R3S_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 
         // ---- phase 1: the 32 new entries against the quadrant's 64 pixels
         int fresh = 0;
@@ -1006,14 +1027,22 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
             const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
             pass &= pass - 1;
             const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
+            F3DG_FULL16(q2, q3);
             const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
             const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
             const float aaf = ray_x * n0 + ray_y * n1 + n2;
             const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
             done = (FAST ? blend_entry_fast : blend_entry)(st, F3DG_R3_FLAG | j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+#if F3DG_R3S_BREAK
+            if (done) break;              // a saturated pixel leaves the loop (its mask is cleared once, below, not on every trip)
+#else
             if (done) pass = 0ull;
+#endif
         }
+#if F3DG_R3S_BREAK
+        if (done) pass = 0ull;
+#endif
         if (__ballot(!done) == 0ull)
             break;
     }
@@ -1165,6 +1194,7 @@ render3l_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
                 const int j = __builtin_ctzll(pass);
                 pass &= pass - 1;
                 const float4 q0 = sR[buf][0][j], q1 = sR[buf][1][j], q2 = sR[buf][2][j], q3 = sR[buf][3][j];
+                F3DG_FULL16(q2, q3);
                 const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
                 const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
                 const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
@@ -1253,9 +1283,11 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
             return F3DG_OK;
         }
         if (g_f3dg_render_slide) {
-#define F3DG_LAUNCH3S(AUX, FST, OCC) F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
-                                                  focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \
-                                                  out_color, final_T, n_contrib)
+#define F3DG_LAUNCH3S(AUX, FST, OCC) do { if (g_f3dg_render_wpb == 4)                                                                                        \
+            F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 4>), grid, dim3(256), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,              \
+                         focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib);                  \
+        else F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 1>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,            \
+                          focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib); } while (0)
             if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3S(true, true, 8); else F3DG_LAUNCH3S(true, false, 8); }
             else { if (g_f3dg_render_fast) F3DG_LAUNCH3S(false, true, 8); else F3DG_LAUNCH3S(false, false, 8); }
 #undef F3DG_LAUNCH3S

@@ -4,16 +4,18 @@
 // 589,824 Gaussians each). For such a call the general binning stage (f3dg_binning.hip: per-view depth sort, instance generation, tile
 // pass; 26 dependent launches built for hundreds of views per call) is all launch latency: ~4.5 us per kernel whatever it does,
 // ~150 us per call at 65,536 Gaussians. Here ONE kernel does the binning, one workgroup per (view, tile):
-//   1. its sixteen waves each scan a sixteenth of the view's Gaussians (tile rectangle + depth key, 12 B each, from L2) and compact those
-//      whose rectangle holds the tile, in id order -- no atomics, no lists in global memory;
+//   1. its sixteen waves each scan a sixteenth of the view's Gaussians (tile rectangle, 8 B each, from L2) and note as one ballot per
+//      64 Gaussians which rectangles hold the tile; the ballots are expanded into the hits' ids in id order (a prefix over the waves'
+//      counts gives every wave its place), their depth keys gathered densely -- no atomics, no lists in global memory;
 //   2. a stable LSD radix sort of the (depth bits, id) pairs in LDS (wave-ballot ranking, four 8-bit passes, passes whose digit is the
 //      same for every entry are skipped) -- exactly the order of the reference's stable sort of (tile | depth) keys
 //      (rasterizer_impl.cu:70-111, 358-363);
 //   3. the list goes to the tile's slot together with its range.
 // Four launches per call (header, projection, this, compositing) instead of 29.
 //
-// A slot holds F3DG_SMALL_CAP entries, a wave's share a sixteenth of that; a longer list sets the overflow flags and the caller
-// re-runs the call on the general path (f3dg_read_status remembers the shape). Inference calls only (no auxiliary planes).
+// A slot holds F3DG_SMALL_CAP entries -- the limit is the tile's total, however its hits are spread over the waves (round 3 gave each
+// wave a sixteenth of the slot, which pixel-ordered predicted Gaussians overflow: all hits of a tile come from the one or two waves
+// that scan its image rows); a longer list sets the overflow flags and the caller re-runs the call on the general path (f3dg_read_status remembers the shape). Inference calls only (no auxiliary planes).
 #include "f3dg_common.h"
 
 namespace {
@@ -23,17 +25,20 @@ typedef unsigned int u32;
 
 #define SMALL_THREADS 1024
 #define SMALL_WAVES (SMALL_THREADS / 64)
-#define SMALL_QCAP (F3DG_SMALL_CAP / SMALL_WAVES)        // entries one wave may collect from its share of the Gaussians
+#define SMALL_MAXP (1u << 18)                                  // f3dg_small_shape: at most 2^18 Gaussians
+#define SMALL_STEPS (SMALL_MAXP / 64u / SMALL_WAVES)          // 64-Gaussian steps of one wave's share: 256
 
 struct SmallShared {
-    u32 k[2][F3DG_SMALL_CAP];                  // depth bits, ping-pong
-    u32 v[2][F3DG_SMALL_CAP];                  // Gaussian id | quadrant mask << F3DG_ID_BITS
+    // four arrays of F3DG_SMALL_CAP words: [2 c] depth bits and [2 c + 1] Gaussian id | quadrant mask << F3DG_ID_BITS of ping-pong
+    // buffer c. While the Gaussians are scanned, buffer 0 (32 KB) holds every wave's hit masks instead: one 64-bit ballot per step.
+    u32 buf[4][F3DG_SMALL_CAP];
     u32 hist[SMALL_WAVES][256];                // per-wave digit counts, then the waves' write offsets
     u32 wave_n[SMALL_WAVES];
     u32 wave_min[SMALL_WAVES], wave_max[SMALL_WAVES];
     u32 wsum[4];
     u32 skip;
 };
+static_assert(sizeof(u64) * SMALL_STEPS * SMALL_WAVES <= 2 * sizeof(u32) * F3DG_SMALL_CAP, "the hit masks must fit buffer 0");
 
 // One workgroup of 16 waves per (view, tile): a single 256^2 view is 256 workgroups, one per CU, and the scan of the view's
 // Gaussians is a latency chain per wave -- the sixteen waves of a CU each take a sixteenth of it.
@@ -51,22 +56,25 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
     const u32* vkey = sort_keys + (size_t)view * P;
 
     // ---- 1. collect: wave w scans Gaussians [w Pq, (w + 1) Pq), 32 steps of 64 in flight. A step only tests the packed tile
-    // rectangle (rmin <= t < rmax in both halves of a word with one packed 16-bit subtraction) and notes the ids of the hits; the
-    // hits' depth keys and quadrant masks are gathered afterwards, densely.
+    // rectangle (rmin <= t < rmax in both halves of a word with one packed 16-bit subtraction); its ballot -- which of the step's 64
+    // Gaussians hit the tile -- is parked in lane `step % 32` and leaves for LDS 32 steps at a time. The limit of a tile is its TOTAL
+    // (F3DG_SMALL_CAP entries), however the hits are spread over the waves: predicted Gaussians are pixel-ordered (id = y * 256 + x), a
+    // wave's share is sixteen image rows = one tile row, and ALL hits of a tile come from one or two waves.
     const u32 Pq = ((P + 64u * SMALL_WAVES - 1u) / (64u * SMALL_WAVES)) * 64u;
     const u32 g0 = min(P, wave * Pq), g1 = min(P, g0 + Pq);
-    u32 nw = 0;                                 // wave-uniform
-    u32* wk = &sh.k[1][wave * SMALL_QCAP];
-    u32* wv = &sh.v[1][wave * SMALL_QCAP];
+    u32 nw = 0;                                 // hits of this wave (wave-uniform)
+    u64* wbal = reinterpret_cast<u64*>(&sh.buf[0][0]) + wave * SMALL_STEPS;
     typedef short pk16 __attribute__((ext_vector_type(2)));
     const u32 cxw = (tx + 1u) | ((tx + 1u) << 16), cyw = (ty + 1u) | ((ty + 1u) << 16);
     const pk16 cx = __builtin_bit_cast(pk16, cxw), cy = __builtin_bit_cast(pk16, cyw);
     constexpr int UN = 32;                       // steps of 64 rectangles in flight per lane (the scan is a chain of memory round trips)
-    for (u32 base = g0; base < g1; base += 64u * UN) {
+    u32 nsteps = 0;
+    for (u32 base = g0; base < g1; base += 64u * UN, nsteps += UN) {
         uint2 r[UN];
 #pragma unroll
         for (int u = 0; u < UN; u++)        // (unconditional loads from a clamped index: a guarded load is a branch + a full wait each)
             r[u] = vrect[min(base + 64u * u + lane, P - 1u)];
+        u32 keep_lo = 0, keep_hi = 0;
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             // low half: rmin - (t + 1) < 0  <=>  rmin <= t;  high half: rmax - (t + 1) >= 0  <=>  t < rmax  (an empty rectangle fails the second)
@@ -74,54 +82,21 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
             const u32 dy = __builtin_bit_cast(u32, __builtin_bit_cast(pk16, r[u].y & 0x7FFF7FFFu) - cy);
             const bool in = (((dx ^ 0x8000u) | (dy ^ 0x8000u)) & 0x80008000u) == 0u && base + 64u * u + lane < g1;
             const u64 bal = __ballot(in);
-            if (in) {
-                const u32 slot = nw + (u32)__popcll(bal & lt);
-                if (slot < (u32)SMALL_QCAP) wv[slot] = base + 64u * u + lane;
-            }
+            if (lane == (u32)u) { keep_lo = (u32)bal; keep_hi = (u32)(bal >> 32); }
             nw += (u32)__popcll(bal);
         }
+        if (lane < (u32)UN) wbal[nsteps + lane] = ((u64)keep_hi << 32) | keep_lo;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    u32 kmin = 0xFFFFFFFFu, kmax = 0u;          // of the entries this lane collects
-    for (u32 i = lane; i < min(nw, (u32)SMALL_QCAP); i += 64u) {
-        const u32 g = wv[i];
-        const uint2 r = vrect[g];
-        const u32 key = vkey[g];
-        const u32 rminx = r.x & F3DG_RECT_COORD, rmaxx = (r.x >> 16) & F3DG_RECT_COORD;
-        const u32 rminy = r.y & F3DG_RECT_COORD, rmaxy = (r.y >> 16) & F3DG_RECT_COORD;
-        // quadrant mask of the instance, as duplicate_sorted_kernel (f3dg_binning.hip) derives it
-        u32 mx = 3u, my = 3u;
-        if (tx == rminx && (r.x & F3DG_RECT_SKIP_LO)) mx &= ~1u;
-        if (tx + 1u == rmaxx && (r.x & F3DG_RECT_SKIP_HI)) mx &= ~2u;
-        if (ty == rminy && (r.y & F3DG_RECT_SKIP_LO)) my &= ~1u;
-        if (ty + 1u == rmaxy && (r.y & F3DG_RECT_SKIP_HI)) my &= ~2u;
-        const u32 qm = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u);
-        wk[i] = key;
-        wv[i] = g | (qm << F3DG_ID_BITS);
-        kmin = min(kmin, key);
-        kmax = max(kmax, key);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        kmin = min(kmin, (u32)__shfl_xor((int)kmin, o, 64));
-        kmax = max(kmax, (u32)__shfl_xor((int)kmax, o, 64));
-    }
-    if (lane == 0) { sh.wave_n[wave] = nw; sh.wave_min[wave] = kmin; sh.wave_max[wave] = kmax; }
+    if (lane == 0) sh.wave_n[wave] = nw;
     __syncthreads();
     u32 n = 0, off = 0;
-    bool over = false;
-    kmin = 0xFFFFFFFFu; kmax = 0u;
 #pragma unroll
     for (u32 w = 0; w < SMALL_WAVES; w++) {
         const u32 c = sh.wave_n[w];
         if (w < wave) off += c;
         n += c;
-        over = over || c > (u32)SMALL_QCAP;
-        kmin = min(kmin, sh.wave_min[w]);
-        kmax = max(kmax, sh.wave_max[w]);
     }
+    const bool over = n > (u32)F3DG_SMALL_CAP;
     const u32 slot_base = seg * (u32)F3DG_SMALL_CAP;
     if (threadIdx.x == 0) {
         const u32 before = atomicAdd(&hdr->num_rendered, n);            // the call's instance count, as on the general path
@@ -132,9 +107,75 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
     }
     if (over || n == 0u || debug_stop == 2)
         return;
-    // concatenate the waves' shares (id order) into buffer 0
+
+    // the hits' ids, in id order, into buffer 1 at the wave's offset: lane l expands the ballots of steps l, l + 64, ...
+    u32* k1 = sh.buf[2];
+    u32* v1 = sh.buf[3];
+    {
+        u32 run = off;
+        for (u32 s0 = 0; s0 < nsteps; s0 += 64u) {
+            u64 m = s0 + lane < nsteps ? wbal[s0 + lane] : 0ull;
+            u32 x = (u32)__popcll(m);
+            const u32 mine = x;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 y = (u32)__shfl_up((int)x, o, 64);
+                if (lane >= (u32)o) x += y;
+            }
+            u32 at = run + x - mine;
+            const u32 gbase = g0 + 64u * (s0 + lane);
+            while (m != 0ull) {
+                v1[at++] = gbase + (u32)__builtin_ctzll(m);
+                m &= m - 1ull;
+            }
+            run += (u32)__shfl((int)x, 63, 64);
+        }
+    }
+    __syncthreads();
+    // depth key and quadrant mask of every hit (dense: at most four per thread), the key range of the list
+    u32 kmin = 0xFFFFFFFFu, kmax = 0u;
+    u32 mykey[F3DG_SMALL_CAP / SMALL_THREADS];
+#pragma unroll
+    for (u32 j = 0; j < F3DG_SMALL_CAP / SMALL_THREADS; j++) {
+        const u32 i = threadIdx.x + j * SMALL_THREADS;
+        mykey[j] = 0u;
+        if (i < n) {
+            const u32 g = v1[i];
+            const uint2 r = vrect[g];
+            const u32 key = vkey[g];
+            const u32 rminx = r.x & F3DG_RECT_COORD, rmaxx = (r.x >> 16) & F3DG_RECT_COORD;
+            const u32 rminy = r.y & F3DG_RECT_COORD, rmaxy = (r.y >> 16) & F3DG_RECT_COORD;
+            // quadrant mask of the instance, as duplicate_sorted_kernel (f3dg_binning.hip) derives it
+            u32 mx = 3u, my = 3u;
+            if (tx == rminx && (r.x & F3DG_RECT_SKIP_LO)) mx &= ~1u;
+            if (tx + 1u == rmaxx && (r.x & F3DG_RECT_SKIP_HI)) mx &= ~2u;
+            if (ty == rminy && (r.y & F3DG_RECT_SKIP_LO)) my &= ~1u;
+            if (ty + 1u == rmaxy && (r.y & F3DG_RECT_SKIP_HI)) my &= ~2u;
+            const u32 qm = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 2 : 0u);
+            v1[i] = g | (qm << F3DG_ID_BITS);
+            mykey[j] = key;
+            kmin = min(kmin, key);
+            kmax = max(kmax, key);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (u32)__shfl_xor((int)kmin, o, 64));
+        kmax = max(kmax, (u32)__shfl_xor((int)kmax, o, 64));
+    }
+    if (lane == 0) { sh.wave_min[wave] = kmin; sh.wave_max[wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (u32 w = 0; w < SMALL_WAVES; w++) {
+        kmin = min(kmin, sh.wave_min[w]);
+        kmax = max(kmax, sh.wave_max[w]);
+    }
     // (keys relative to the list's smallest: the depths of a tile's list differ in ~22 bits, three 8-bit passes instead of four)
-    for (u32 i = lane; i < nw; i += 64u) { sh.k[0][off + i] = wk[i] - kmin; sh.v[0][off + i] = wv[i]; }
+#pragma unroll
+    for (u32 j = 0; j < F3DG_SMALL_CAP / SMALL_THREADS; j++) {
+        const u32 i = threadIdx.x + j * SMALL_THREADS;
+        if (i < n) k1[i] = mykey[j] - kmin;
+    }
     __syncthreads();
     const u32 span = kmax - kmin;
     const int key_bits = debug_stop == 3 ? 0 : span == 0u ? 0 : 32 - __builtin_clz(span);
@@ -142,13 +183,13 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
     // ---- 2. stable LSD radix sort by the depth bits; wave w owns entries [w q, (w + 1) q) of the current buffer
     const u32 q = ((n + 64u * SMALL_WAVES - 1u) / (64u * SMALL_WAVES)) * 64u;
     const u32 e0 = min(n, wave * q), e1 = min(n, e0 + q);
-    u32 cur = 0;
+    u32 cur = 1;
     for (int shift = 0; shift < key_bits; shift += 8) {
         sh.hist[wave][lane] = 0; sh.hist[wave][lane + 64] = 0; sh.hist[wave][lane + 128] = 0; sh.hist[wave][lane + 192] = 0;
         if (threadIdx.x == 0) sh.skip = 0;
         __syncthreads();
         for (u32 i = e0 + lane; i < e1; i += 64u)
-            atomicAdd(&sh.hist[wave][(sh.k[cur][i] >> shift) & 255u], 1u);
+            atomicAdd(&sh.hist[wave][(sh.buf[2u * cur][i] >> shift) & 255u], 1u);
         __syncthreads();
         // thread d < 256: total of digit d, exclusive scan over the digits, per-wave offsets
         u32 tot = 0, x = 0;
@@ -183,7 +224,7 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
         for (u32 i0 = e0; i0 < e1; i0 += 64u) {
             const u32 i = i0 + lane;
             const bool valid = i < e1;
-            const u32 key = valid ? sh.k[cur][i] : 0u, val = valid ? sh.v[cur][i] : 0u;
+            const u32 key = valid ? sh.buf[2u * cur][i] : 0u, val = valid ? sh.buf[2u * cur + 1u][i] : 0u;
             const u32 d = (key >> shift) & 255u;
             u64 m = __ballot(valid);                        // lanes of this step with my digit
 #pragma unroll
@@ -193,8 +234,8 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
             }
             if (valid) {
                 const u32 pos = sh.hist[wave][d] + (u32)__popcll(m & lt);
-                sh.k[cur ^ 1u][pos] = key;
-                sh.v[cur ^ 1u][pos] = val;
+                sh.buf[2u * (cur ^ 1u)][pos] = key;
+                sh.buf[2u * (cur ^ 1u) + 1u][pos] = val;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -211,7 +252,7 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
 
     // ---- 3. the tile's list
     for (u32 i = threadIdx.x; i < n; i += SMALL_THREADS)
-        list[(size_t)slot_base + i] = sh.v[cur][i];
+        list[(size_t)slot_base + i] = sh.buf[2u * cur + 1u][i];
 }
 
 // debug export: the lists in (view, tile) order without gaps, as the general path lays them out, and the matching ranges

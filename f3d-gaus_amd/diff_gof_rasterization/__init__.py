@@ -66,6 +66,7 @@ class Workspace:
             raise _lib.F3dgError(_lib.ERR_BAD_ARG, "f3dg_workspace_bytes")
         self.buffer = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         self.num_rendered = None
+        self.save_aux = False         # whether the last forward on this workspace kept the planes f3dg_backward reads
 
     @property
     def nbytes(self):
@@ -207,6 +208,7 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
             _lib.ptr(cov3Ds_precomp), _lib.ptr(view2gaussian_precomp), _lib.ptr(vm), _lib.ptr(pm), _lib.ptr(cp),
             float(tanfovx), float(tanfovy), float(kernel_size), _lib.ptr(out), _lib.ptr(radii), flags)
         _lib.check(rc, "f3dg_forward_sets")
+        workspace.save_aux = bool(save_aux)
         if not check:
             workspace.num_rendered = None
             return out, radii, workspace

@@ -13,6 +13,10 @@ def rasterize_backward_raw(ws, means3D, sh, colors_precomp, scales, rotations, r
     """n_views-batched backward on a workspace produced with save_aux=True. Returns a dict of gradient tensors:
     per-view [V,P,..] for means2D / colors / view2gaussian, summed over the views for the Gaussian parameters."""
     from . import _dev_f32, _stream
+    if not getattr(ws, "save_aux", False):
+        # (the library checks the same on the device -- the gradients would all be zero and f3dg_backward_pairs reports ERR_STATE)
+        raise RuntimeError("backward on a workspace whose last forward was an inference call (save_aux=False): the auxiliary "
+                           "planes it reads were not written")
     device = means3D.device
     P = means3D.size(0)
     V = ws.n_views

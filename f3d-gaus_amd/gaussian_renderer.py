@@ -104,22 +104,11 @@ def depth_to_normal(world_view_transform, image_width, image_height, FoVx, FoVy,
     return dn[0].permute(1, 2, 0)
 
 
-_SH_CACHE = {}
-
-
 def _cat_sh(dc, rest):
-    """cat(features_dc, features_rest) along the coefficient axis. The reference concatenates on every call (gr.py:1008); its loops
-    render the same Gaussians from many cameras (visualize.py:387-416), so in inference the result is kept for as long as both inputs
-    are the same, unmodified tensors (storage address, shape and in-place version counter)."""
-    if torch.is_grad_enabled() and (dc.requires_grad or rest.requires_grad):
-        return torch.cat([dc, rest], dim=1).contiguous()
-    key = (dc.data_ptr(), rest.data_ptr(), tuple(dc.shape), tuple(rest.shape), dc._version, rest._version, dc.device)
-    hit = _SH_CACHE.get("k")
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    shs = torch.cat([dc, rest], dim=1).contiguous()
-    _SH_CACHE["k"] = (key, shs, dc, rest)       # (keeps the inputs alive so that their addresses cannot be reused)
-    return shs
+    """cat(features_dc, features_rest) along the coefficient axis, on every call as the reference does (gr.py:1008). (Round 3 kept
+    the result while both inputs looked unmodified; the package's own in-place writers -- ``splat_head(out=...)`` fills the buffers
+    through raw pointers -- never touch the version counter that test relied on, so a refilled buffer rendered stale colours.)"""
+    return torch.cat([dc, rest], dim=1).contiguous()
 
 
 def _render_one(get, bs, world_view_transform, full_proj_transform, camera_center, bg_color, cfg, kernel_size,

@@ -31,6 +31,23 @@ def make_gaussians(P, s0=0.01, seed=0, sh_rest=3, device="cpu", behind_fraction=
     return {k: v.float().contiguous().to(device) for k, v in out.items()}
 
 
+def make_pixel_gaussians(res=256, s0=0.01, seed=0, sh_rest=3, device="cpu", fov_deg=13.164):
+    """res * res PIXEL-ORDERED Gaussians, id = y * res + x, as the splat head predicts them (reference src/gaussian_predictor.py:
+    one Gaussian per input pixel, back-projected along the pixel's ray of the canonical camera to a smooth depth map + noise).
+    Everything but the positions follows ``make_gaussians``. The id order is the point: a contiguous id range is a band of image
+    rows, which is what the one-view-per-call loops of the reference feed the rasterizer (visualize.py:293-314, 387-416)."""
+    P = res * res
+    g = make_gaussians(P, s0=s0, seed=seed, sh_rest=sh_rest, device="cpu")
+    gen = torch.Generator(device="cpu").manual_seed(seed + 101)
+    ys, xs = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing="ij")
+    u = (xs.reshape(-1) + 0.5) / res * 2 - 1
+    v = (ys.reshape(-1) + 0.5) / res * 2 - 1
+    t = math.tan(fov_deg * math.pi / 360)
+    z = 7.667 + 0.6 * torch.sin(2.5 * u) * torch.cos(2.0 * v) + 0.02 * torch.randn(P, generator=gen)
+    g["xyz"] = torch.stack([u * t * z, v * t * z, z], 1).float().contiguous()
+    return {k: w.to(device) for k, w in g.items()}
+
+
 def orbit_cameras(n_views, resolution=256, device="cpu", include_canonical=False):
     """world_view [V,4,4], full_proj [V,4,4], centers [V,3] of the n-view F3D-Gaus orbit (+ canonical first)."""
     cfg = cameras.default_cfg(resolution)

@@ -55,6 +55,8 @@ extern "C" {
 #define F3DG_ERR_OVERFLOW   -3   /* more (Gaussian, tile) instances than max_rendered; see f3dg_read_status */
 #define F3DG_ERR_HIP        -4   /* a HIP runtime call failed; f3dg_last_error() has the text */
 #define F3DG_ERR_UNSUPPORTED -5  /* NUM_CHANNELS != 3 etc. (rasterizer_impl.cu:294-297) */
+#define F3DG_ERR_STATE      -6   /* f3dg_backward on a workspace whose last forward was not a F3DG_FLAG_SAVE_AUX call: nothing was
+                                    walked, every gradient is zero (reported by f3dg_backward_pairs / f3dg_read_status) */
 
 /* flags for f3dg_forward_batched */
 #define F3DG_FLAG_SAVE_AUX   1u  /* keep final_T / n_contrib / conic / clamped for f3dg_backward (training mode).

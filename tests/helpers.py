@@ -14,9 +14,13 @@ RENDER_MODE = None      # "fast" / "exact" when a module's fixture forces the co
 
 
 def make_scene(P, res=(64, 64), s0=0.05, seed=0, view="canonical", n_views=1, sh_degree=1, colors_precomp=False,
-               kernel_size=0.0, scale_modifier=1.0, behind_fraction=0.0, bg=(0.0, 0.0, 0.0), aniso=False, depth_range=None):
+               kernel_size=0.0, scale_modifier=1.0, behind_fraction=0.0, bg=(0.0, 0.0, 0.0), aniso=False, depth_range=None, pixel_ordered=False):
     W, H = res
-    g = synthetic.make_gaussians(P, s0=s0, seed=seed, behind_fraction=behind_fraction, sh_rest=max(3, (sh_degree + 1) ** 2 - 1))
+    if pixel_ordered:       # one Gaussian per pixel of a res x res input image, id = y * res + x (what the predictor hands the rasterizer)
+        assert P == W * H and W == H
+        g = synthetic.make_pixel_gaussians(W, s0=s0, seed=seed, sh_rest=max(3, (sh_degree + 1) ** 2 - 1))
+    else:
+        g = synthetic.make_gaussians(P, s0=s0, seed=seed, behind_fraction=behind_fraction, sh_rest=max(3, (sh_degree + 1) ** 2 - 1))
     if depth_range is not None:   # spread the Gaussians over view-space depths z0..z1 (log-uniform), keeping their image positions:
         gen = torch.Generator().manual_seed(seed + 29)      # the NDC depth map then spans ~0.2, so the distortion channel reaches 1e-3..1e-2
         z0, z1 = depth_range

@@ -301,3 +301,26 @@ def test_renderer_derived_maps_carry_gradients(gpu_device):
     (out["rendered_normal"].square().sum() + out["depth_normal"][:, 8:-8, 8:-8].sum()).backward()
     assert pc["xyz"].grad is not None and float(pc["xyz"].grad.abs().max()) > 0 and bool(torch.isfinite(pc["xyz"].grad).all())
     assert float(pc["scaling"].grad.abs().max()) > 0
+
+
+def test_refilled_buffers_render_their_new_contents(gpu_device):
+    """The wrapper concatenates features_dc / features_rest on every call, as the reference does (gr.py:1008). Round 3 cached the
+    concatenation while both inputs "looked" unmodified; the package's own in-place writers (`splat_head(out=...)`, raw pointers)
+    and `.data` writes do not touch the version counter that test used, so a refilled buffer rendered the previous colours."""
+    cfg = cameras.default_cfg(64)
+    g = synthetic.make_gaussians(2000, s0=0.05, seed=3, device=gpu_device)
+    pc = {k: v.unsqueeze(0).clone() for k, v in g.items()}
+    cams = synthetic.orbit_cameras(4, resolution=64, device=gpu_device)
+    args = (cams["viewmatrix"][1:2], cams["projmatrix"][1:2], cams["campos"][1:2], torch.zeros(1, 3, device=gpu_device), cfg)
+    with torch.no_grad():
+        a = f3d.render_predicted_more_v2_gof(pc, 0, *args)["render"].clone()
+        pc["features_dc"].data.mul_(-1.0)            # an in-place refill that leaves `_version` alone
+        b = f3d.render_predicted_more_v2_gof(pc, 0, *args)["render"].clone()
+        pc2 = {k: v.clone() for k, v in pc.items()}
+        c = f3d.render_predicted_more_v2_gof(pc2, 0, *args)["render"]
+    assert not torch.equal(a, b)
+    assert torch.equal(b, c)
+    with torch.inference_mode():                      # (reading `_version` of an inference tensor raised in round 3's cache)
+        pci = {k: v.clone() for k, v in pc.items()}
+        d = f3d.render_predicted_more_v2_gof(pci, 0, *args)["render"]
+    assert torch.equal(d, c)

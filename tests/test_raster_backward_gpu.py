@@ -167,3 +167,34 @@ def test_backward_random_configurations(seed, gpu_device):
     assert _rel(gh["dL_dopacity"], go["dL_dopacity"]) <= 1e-5, kw
     assert _rel(gh["dL_dcolors"][0], go["dL_dcolor"]) <= 1e-5, kw
     assert _rel(gh["dL_dmeans2D"][0], go["dL_dmean2D"]) <= 2e-5, kw
+
+
+def test_backward_refuses_a_stale_workspace(gpu_device):
+    """f3dg_backward on a workspace whose last forward was an inference call (no auxiliary planes, possibly the small-call path):
+    the Python wrapper raises; through the raw C ABI every gradient is zero and f3dg_backward_pairs reports F3DG_ERR_STATE."""
+    import ctypes as C
+    import f3dgaus_amd as f3d
+    from f3dgaus_amd import _lib
+    from f3dgaus_amd.diff_gof_rasterization.backward import rasterize_backward_raw
+    sc = make_scene(P=3000, res=(64, 64), s0=0.05, view="oblique")
+    dev = lambda t: None if t is None else t.to(gpu_device)
+    L = _lib.lib()
+    for small in (1, 0):
+        L.f3dg_set_option(b"small_path", 2 if small else 0)
+        try:
+            out, radii, ws = f3d.rasterize_views(
+                dev(sc["means3D"]), dev(sc["opacities"]), dev(sc["viewmatrix"]), dev(sc["projmatrix"]), dev(sc["campos"]), dev(sc["bg"]),
+                image_height=64, image_width=64, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], sh=dev(sc["shs"]), scales=dev(sc["scales"]),
+                rotations=dev(sc["rotations"]), sh_degree=1, save_aux=False)
+        finally:
+            L.f3dg_set_option(b"small_path", 2)
+        args = (dev(sc["means3D"]), dev(sc["shs"]), None, dev(sc["scales"]), dev(sc["rotations"]), radii, torch.ones_like(out), 1,
+                dev(sc["viewmatrix"]), dev(sc["projmatrix"]), dev(sc["campos"]), dev(sc["bg"]), sc["tanfovx"], sc["tanfovy"], 0.0, 1.0)
+        with pytest.raises(RuntimeError, match="inference call"):
+            rasterize_backward_raw(ws, *args)
+        ws.save_aux = True                      # bypass the host check: the device-side guard
+        g = rasterize_backward_raw(ws, *args)
+        assert all(float(v.abs().max()) == 0.0 for v in g.values())
+        n = C.c_longlong(0)
+        assert L.f3dg_backward_pairs(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), C.byref(n)) == _lib.ERR_STATE
+        ws.save_aux = False

@@ -41,6 +41,10 @@ CASES = {
     "aniso_behind": dict(P=6000, res=(96, 96), s0=0.02, view="oblique", aniso=True, behind_fraction=0.1),
     "single_tile": dict(P=300, res=(16, 12), s0=0.05, view="canonical"),
     "c1_size": dict(P=65536, res=(256, 256), s0=0.01, view="oblique"),
+    # the workload the path exists for: the predictor's pixel-ordered Gaussians (a wave's contiguous share of the ids is a band of
+    # image rows, so ALL hits of a tile come from one or two of the sixteen waves; round 3's per-wave limit overflowed on it)
+    "pixel_ordered": dict(P=65536, res=(256, 256), s0=0.01, view="oblique", pixel_ordered=True),
+    "pixel_ordered_canonical": dict(P=65536, res=(256, 256), s0=0.012, view="canonical", pixel_ordered=True),
 }
 
 
@@ -62,7 +66,7 @@ def test_small_path_equals_general_path(name, tile_cull, gpu_device):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
     assert np.array_equal(a[3], b[3]), "lists differ"
     assert np.array_equal(a[4], b[4]), "ranges differ"
-    if name == "one_view" and tile_cull == 0:
+    if name in ("one_view", "pixel_ordered") and tile_cull == 0:
         o = run_oracle(scene)
         assert a[2] == o["num_rendered"] and np.array_equal(a[3].view(np.uint32), o["point_list"])
         assert_render_parity(a[0][0].cpu().numpy(), o["out_color"], "small path")

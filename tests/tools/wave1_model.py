@@ -131,8 +131,8 @@ for tile in tiles:
                 t["lost_block"] += mx * 64 - bm
 
         # sliding window: 64 entries resident, slides by STEP when every lane has consumed the oldest STEP entries
-        for STEP in (32, 16):
-            key = ("slide", STEP)
+        for STEP, RES in ((32, 64), (16, 64), (32, 96), (32, 128), (64, 128), (32, 1 << 20)):
+            key = ("slide", STEP, RES)
             t = tot.setdefault(key, dict(trips=0, staged=0, slides=0))
             if len(lst) == 0:
                 continue
@@ -142,8 +142,8 @@ for tile in tiles:
             ptr = np.zeros(64, dtype=np.int64)
             s = 0
             while s < nq and lst[s] <= dq:
-                hi = min(s + 64, nq)
-                t["staged"] += min(STEP, nq - s) if s > 0 else min(64, nq)
+                hi = min(s + RES, nq)
+                t["staged"] += min(STEP, nq - s) if s > 0 else min(RES, nq)
                 t["slides"] += 1
                 # trips until every lane has no unprocessed entry < s + STEP
                 while True:
@@ -161,10 +161,10 @@ print("tiles %d  tile entries/view %.3g  quadrant entries/view %.3g (x%.2f)  pha
 ideal = pairs_total / 64.0
 t = tot["r2"]
 print("render2 shape: staged %.3g/view, trips %.3g, lane utilisation %.3f" % (t["staged"] * scale, t["trips"] * scale, ideal / t["trips"]))
-for STEP in (32, 16):
-    t = tot[("slide", STEP)]
-    print("one wave, 64 resident entries sliding by %d: staged %.3g/view, trips %.3g, lane utilisation %.3f, slides %.3g" %
-          (STEP, t["staged"] * scale, t["trips"] * scale, ideal / t["trips"], t["slides"] * scale))
+for STEP, RES in ((32, 64), (16, 64), (32, 96), (32, 128), (64, 128), (32, 1 << 20)):
+    t = tot[("slide", STEP, RES)]
+    print("one wave, %d resident entries sliding by %d: staged %.3g/view, trips %.3g, lane utilisation %.3f, slides %.3g" %
+          (RES, STEP, t["staged"] * scale, t["trips"] * scale, ideal / t["trips"], t["slides"] * scale))
 for wn in WINS:
     t = tot[("w1", wn)]
     print("one wave, %3d-entry windows: staged %.3g/view (gather x%.2f of render2), trips %.3g, lane utilisation %.3f, "
