@@ -499,7 +499,11 @@ def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
     P = args.gaussians if args.gaussians != 196608 else 65536
     V, RES = args.views, args.res
     cfg = cameras.default_cfg(RES)
-    g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)
+    # the predictor's Gaussians are PIXEL-ORDERED (id = y * res + x on the input image's depth map): that is what these loops feed
+    # the rasterizer, and the id order matters to the small-call path (a wave's share of the ids is a band of image rows)
+    pixel = P == RES * RES and not os.environ.get("F3DG_DROPIN_RANDOM_IDS")
+    g = synthetic.make_pixel_gaussians(RES, s0=args.sigma0, seed=rank, device=device) if pixel else \
+        synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)
     pc = {"xyz": g["xyz"][None], "opacity": g["opacity"][None], "scaling": g["scaling"][None], "rotation": g["rotation"][None],
           "features_dc": g["features_dc"][None], "features_rest": g["features_rest"][None]}
     cams = synthetic.orbit_cameras(V, resolution=RES, device=device)
@@ -536,6 +540,14 @@ def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
                                 scales=g["scaling"], rotations=g["rotation"], sh_degree=1, workspace=ws, out=out1, radii=rad1, check=False)
 
     e_ras = timed(step_raster, sync, args.warmup, args.steps)
+    # opt-in: the status of a call is checked when the next call arrives on the stream instead of blocking (set_deferred_status)
+    f3d.set_deferred_status(True)
+
+    def sync_flush():
+        f3d.flush()
+        torch.cuda.synchronize()
+    e_def = timed(step_device, sync_flush, args.warmup, args.steps)
+    f3d.set_deferred_status(False)
     timed(step_device, sync, args.warmup, 0)
     L.f3dg_profile_enable(1)
     L.f3dg_debug_launch_count(1)
@@ -554,10 +566,13 @@ def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
         "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)", "value": n / e_dev, "unit": "views/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * e_dev / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_deferred_status": n / e_def,
+        "gaussian_order": "pixel-ordered (id = y * res + x, as the predictor emits them)" if pixel else "random ids",
         "config": {"workload": "drop-in: render_predicted_more_v2_gof one view per call (the reference's loop, visualize.py:387-416), %d Gaussians "
                                "(sigma0=%g), %d calls per step @%dx%d, frames left on the device" % (P, args.sigma0, V, RES, RES),
                    "gaussians": P, "views": V, "resolution": RES, "kernel_launches_per_call": launches / float(calls)},
         "us_per_call": {"wrapper, frames on the device (= value)": 1e6 * e_dev / n,
+                        "wrapper with set_deferred_status(True): the status of call k is checked when call k + 1 arrives": 1e6 * e_def / n,
                         "wrapper + .cpu() of every frame before the next call (the reference's loop)": 1e6 * e_ref / n,
                         "rasterizer alone (f3dg_forward_batched, one view, no host sync)": 1e6 * e_ras / n,
                         "rasterizer stages per call (HIP events)": {"preprocess": 1e3 * st[0] / calls, "binning": 1e3 * st[1] / calls,

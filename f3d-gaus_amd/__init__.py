@@ -14,7 +14,7 @@ from . import diff_gof_rasterization  # noqa: F401
 _sys.modules.setdefault("diff_gof_rasterization", diff_gof_rasterization)
 
 from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF,  # noqa: E402,F401
-                                     rasterize_views)
+                                     rasterize_views, set_deferred_status, deferred_status, flush)
 
 from . import gaussian_renderer, gaussian_predictor, unet_gs, cycle, dist, ply  # noqa: E402,F401
 from .gaussian_renderer import (render_predicted_more_v2_gof, render_predicted_more_v3_gof,  # noqa: E402,F401

@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libf3dg_hip.so")
 
 OK, ERR_BAD_ARG, ERR_WORKSPACE, ERR_OVERFLOW, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
-FLAG_SAVE_AUX, FLAG_BG_PER_VIEW = 1, 2
+FLAG_SAVE_AUX, FLAG_BG_PER_VIEW, FLAG_SKIP_NORMAL, FLAG_SKIP_DISTORTION = 1, 2, 4, 8
+PENDING = 1
 
 _ERR_TEXT = {
     ERR_BAD_ARG: "bad argument",
@@ -31,6 +32,8 @@ SIGNATURES = {
     "f3dg_forward_sets": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p,
                                _p, _p, _p, _f, _f, _f, _p, _p, _u]),
     "f3dg_read_status": (_i, [_p, _p, C.POINTER(_ll)]),
+    "f3dg_status_post": (_i, [_p, _p]),
+    "f3dg_status_poll": (_i, [_i, _i, C.POINTER(_ll)]),
     "f3dg_forward": (_ll, [_p, _p, _sz, _ll, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,
                            _f, _f, _f, _i, _p, _p, _u, C.POINTER(_ll)]),
     "f3dg_backward": (_i, [_p, _p, _sz, _ll, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p,

@@ -421,7 +421,8 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
                               reinterpret_cast<const float4*>(ws + L.cull), background,
                               (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color,
                               reinterpret_cast<float*>(ws + L.final_T),
-                              reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux);
+                              reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux,
+                              flags & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION));
     prof_mark(prof, ST_RENDER, s);
     return rc;
 }
@@ -584,6 +585,62 @@ extern "C" int f3dg_read_status(void* stream, const void* workspace, long long* 
     if (h_num_rendered) *h_num_rendered = (long long)h.num_rendered;
     if (h.small_overflow) small_disable(h.small_shape[0], h.small_shape[1], h.small_shape[2], h.small_shape[3]);     // the retry takes the general path
     return h.overflow ? F3DG_ERR_OVERFLOW : F3DG_OK;
+}
+
+// ---- non-blocking status (f3dg.h: f3dg_status_post / f3dg_status_poll)
+namespace {
+struct StatusSlot { F3dgHeader* host; hipEvent_t ev; bool busy; };
+std::vector<StatusSlot> g_status;       // grows on demand; slots are recycled
+std::mutex g_status_mutex;
+int finish_status(const F3dgHeader& h, long long* h_num_rendered)
+{
+    if (h_num_rendered) *h_num_rendered = (long long)h.num_rendered;
+    if (h.small_overflow) small_disable(h.small_shape[0], h.small_shape[1], h.small_shape[2], h.small_shape[3]);     // the retry takes the general path
+    return h.overflow ? F3DG_ERR_OVERFLOW : F3DG_OK;
+}
+} // namespace
+
+extern "C" int f3dg_status_post(void* stream, const void* workspace)
+{
+    if (!workspace) return F3DG_ERR_BAD_ARG;
+    int ticket = -1;
+    {
+        std::lock_guard<std::mutex> lock(g_status_mutex);
+        for (size_t i = 0; i < g_status.size(); i++)
+            if (!g_status[i].busy) { ticket = (int)i; break; }
+        if (ticket < 0) {
+            StatusSlot sl = { nullptr, nullptr, false };
+            F3DG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.host), sizeof(F3dgHeader), hipHostMallocDefault));
+            F3DG_HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+            g_status.push_back(sl);
+            ticket = (int)g_status.size() - 1;
+        }
+        g_status[ticket].busy = true;
+    }
+    const StatusSlot sl = g_status[ticket];
+    F3DG_HIP_CHECK(hipMemcpyAsync(sl.host, workspace, sizeof(F3dgHeader), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    F3DG_HIP_CHECK(hipEventRecord(sl.ev, (hipStream_t)stream));
+    return ticket;
+}
+
+extern "C" int f3dg_status_poll(int ticket, int wait, long long* h_num_rendered)
+{
+    StatusSlot sl;
+    {
+        std::lock_guard<std::mutex> lock(g_status_mutex);
+        if (ticket < 0 || ticket >= (int)g_status.size() || !g_status[ticket].busy) return F3DG_ERR_BAD_ARG;
+        sl = g_status[ticket];
+    }
+    if (wait) F3DG_HIP_CHECK(hipEventSynchronize(sl.ev));
+    else {
+        const hipError_t q = hipEventQuery(sl.ev);
+        if (q == hipErrorNotReady) return F3DG_PENDING;
+        F3DG_HIP_CHECK(q);
+    }
+    const int rc = finish_status(*sl.host, h_num_rendered);
+    std::lock_guard<std::mutex> lock(g_status_mutex);
+    g_status[ticket].busy = false;
+    return rc;
 }
 
 extern "C" int f3dg_backward_pairs(void* stream, const void* workspace, long long* h_pairs)

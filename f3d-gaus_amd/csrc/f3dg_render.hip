@@ -52,6 +52,9 @@ struct PixelState {
 
 // The reference's per-(pixel, Gaussian) arithmetic after the geometric terms (forward.cu:511-579), in its operation
 // order. Returns true when the pixel saturates (`done = true`); `contributor` is the 1-based position in the tile list.
+// NORMAL / DIST = false (f3dg_forward_sets with F3DG_FLAG_SKIP_NORMAL / F3DG_FLAG_SKIP_DISTORTION; the one-wave kernel only): the normal
+// channels 3..5 / the distortion channel 8 are neither accumulated nor written; every other channel is bit-identical.
+template <bool NORMAL = true, bool DIST = true>
 __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor, float n0, float n1, float n2, float aaf,
                                             float bhalf, float CC, float opac, float cr, float cg, float cb)
 {
@@ -79,23 +82,25 @@ __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor
     if (test_T < 0.0001f)
         return true;
 
-    const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
-
-    const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
-    const float nn0 = -n0 / length, nn1 = -n1 / length, nn2 = -n2 / length;
-
-    const float A = 1 - Tr;
-    const float error = mapped_max_t * mapped_max_t * A + st.dist2 - 2 * mapped_max_t * st.dist1;
-    st.distortion += error * alpha * Tr;
-    st.dist1 += mapped_max_t * alpha * Tr;
-    st.dist2 += mapped_max_t * mapped_max_t * alpha * Tr;
+    if (DIST) {
+        const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
+        const float A = 1 - Tr;
+        const float error = mapped_max_t * mapped_max_t * A + st.dist2 - 2 * mapped_max_t * st.dist1;
+        st.distortion += error * alpha * Tr;
+        st.dist1 += mapped_max_t * alpha * Tr;
+        st.dist2 += mapped_max_t * mapped_max_t * alpha * Tr;
+    }
 
     st.C0 += cr * alpha * Tr;
     st.C1 += cg * alpha * Tr;
     st.C2 += cb * alpha * Tr;
-    st.C3 += nn0 * alpha * Tr;
-    st.C4 += nn1 * alpha * Tr;
-    st.C5 += nn2 * alpha * Tr;
+    if (NORMAL) {
+        const float length = (float)sqrt(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7);
+        const float nn0 = -n0 / length, nn1 = -n1 / length, nn2 = -n2 / length;
+        st.C3 += nn0 * alpha * Tr;
+        st.C4 += nn1 * alpha * Tr;
+        st.C5 += nn2 * alpha * Tr;
+    }
     if (Tr > 0.5) {
         st.C6 = t;
         st.max_contributor = contributor;
@@ -120,6 +125,7 @@ __device__ __forceinline__ bool blend_entry(PixelState& st, unsigned contributor
 //     the NDC depth as c0 - c1/t with a hardware reciprocal, the normal with v_rsq_f32.
 // Every output stays within ~1e-6 relative of blend_entry's; the parity tests gate this mode at the same 1e-4 / 99.9 % /
 // 80 dB bar as the exact one (tests/test_raster_forward_gpu.py) and report both against the oracle.
+template <bool NORMAL = true, bool DIST = true>
 __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contributor, float n0, float n1, float n2, float aaf,
                                                  float bhalf, float CC, float opac, float cr, float cg, float cb)
 {
@@ -136,51 +142,29 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
     if (test_T < 0.0001f)
         return true;
 
-#ifdef F3DG_FAST_EXACT_DIST
-    // experiment (tools/ab_exact_dist.sh): the NDC depth and the three distortion accumulators in the reference's own operations
-    // (forward.cu:545-560) inside the fast path -- what it costs to take the distortion channel off the fast arithmetic
-    const float mapped_max_t = (float)((F3DG_FAR_PLANE * t - F3DG_FAR_PLANE * F3DG_NEAR_PLANE) / ((F3DG_FAR_PLANE - F3DG_NEAR_PLANE) * t));
-    {
-        const float Tr_ = st.Tr;
-        const float A_ = 1 - Tr_;
-        const float error_ = mapped_max_t * mapped_max_t * A_ + st.dist2 - 2 * mapped_max_t * st.dist1;
-        st.distortion += error_ * alpha * Tr_;
-        st.dist1 += mapped_max_t * alpha * Tr_;
-        st.dist2 += mapped_max_t * mapped_max_t * alpha * Tr_;
-    }
-    const float inv_len_ = __builtin_amdgcn_rsqf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)) + 1e-7f);
-    const float w_ = alpha * Tr;
-    const float wn_ = -w_ * inv_len_;
-    st.C0 = fmaf(cr, w_, st.C0); st.C1 = fmaf(cg, w_, st.C1); st.C2 = fmaf(cb, w_, st.C2);
-    st.C3 = fmaf(n0, wn_, st.C3); st.C4 = fmaf(n1, wn_, st.C4); st.C5 = fmaf(n2, wn_, st.C5);
-    if (Tr > 0.5f) { st.C6 = t; st.max_contributor = contributor; }
-    st.C7 += w_;
-    st.Tr = test_T;
-    st.last_contributor = contributor;
-    return false;
-#else
-    // (FAR*t - FAR*NEAR) / ((FAR - NEAR)*t) = FAR/(FAR-NEAR) - (FAR*NEAR/(FAR-NEAR)) / t
-    const float mapped_max_t = fmaf(-0.20040080160320642f, __builtin_amdgcn_rcpf(t), 1.0020040080160322f);
-
     // (the accumulations below are contracted into FMAs: fewer roundings than the reference's separate products and sums, ~1e-8
     // absolute on the distortion channel, whose values are 1e-7..1e-2)
-    const float inv_len = __builtin_amdgcn_rsqf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)) + 1e-7f);
     const float w = alpha * Tr;
-
-    const float A = 1 - Tr;
-    const float m2 = mapped_max_t * mapped_max_t;
-    const float error = fmaf(-2.0f * mapped_max_t, st.dist1, fmaf(m2, A, st.dist2));
-    st.distortion = fmaf(error, w, st.distortion);
-    st.dist1 = fmaf(mapped_max_t, w, st.dist1);
-    st.dist2 = fmaf(m2, w, st.dist2);
-
-    const float wn = -w * inv_len;
+    if (DIST) {
+        // (FAR*t - FAR*NEAR) / ((FAR - NEAR)*t) = FAR/(FAR-NEAR) - (FAR*NEAR/(FAR-NEAR)) / t
+        const float mapped_max_t = fmaf(-0.20040080160320642f, __builtin_amdgcn_rcpf(t), 1.0020040080160322f);
+        const float A = 1 - Tr;
+        const float m2 = mapped_max_t * mapped_max_t;
+        const float error = fmaf(-2.0f * mapped_max_t, st.dist1, fmaf(m2, A, st.dist2));
+        st.distortion = fmaf(error, w, st.distortion);
+        st.dist1 = fmaf(mapped_max_t, w, st.dist1);
+        st.dist2 = fmaf(m2, w, st.dist2);
+    }
     st.C0 = fmaf(cr, w, st.C0);
     st.C1 = fmaf(cg, w, st.C1);
     st.C2 = fmaf(cb, w, st.C2);
-    st.C3 = fmaf(n0, wn, st.C3);
-    st.C4 = fmaf(n1, wn, st.C4);
-    st.C5 = fmaf(n2, wn, st.C5);
+    if (NORMAL) {
+        const float inv_len = __builtin_amdgcn_rsqf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)) + 1e-7f);
+        const float wn = -w * inv_len;
+        st.C3 = fmaf(n0, wn, st.C3);
+        st.C4 = fmaf(n1, wn, st.C4);
+        st.C5 = fmaf(n2, wn, st.C5);
+    }
     if (Tr > 0.5f) {
         st.C6 = t;
         st.max_contributor = contributor;
@@ -190,7 +174,6 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
     st.Tr = test_T;
     st.last_contributor = contributor;
     return false;
-#endif
 }
 
 #define F3DG_ROUND (F3DG_BLOCK - 1)     // list entries staged per round; LDS slot F3DG_ROUND is the sentinel
@@ -349,7 +332,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                         continue;
                 }
                 const float4 q3 = sq3[j];
-                done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+                done = (FAST ? blend_entry_fast<> : blend_entry<>)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
             }
         } else {
             // ---- two-phase loop over windows of 64 entries
@@ -396,7 +379,7 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
                     const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
                     const float aaf = ray_x * n0 + ray_y * n1 + n2;
                     const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-                    done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+                    done = (FAST ? blend_entry_fast<> : blend_entry<>)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
                 }
             }
         }
@@ -627,7 +610,7 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                 const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
                 const float aaf = ray_x * n0 + ray_y * n1 + n2;
                 const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-                done = (FAST ? blend_entry_fast : blend_entry)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q2.w, q3.x, q3.y);
+                done = (FAST ? blend_entry_fast<> : blend_entry<>)(st, round_base + (unsigned)j + 1u, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q2.w, q3.x, q3.y);
             }
             F3DG_T_MARK(4);
         }
@@ -828,7 +811,7 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
             const float aaf = ray_x * n0 + ray_y * n1 + n2;
             const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-            done = (FAST ? blend_entry_fast : blend_entry)(st, F3DG_R3_FLAG | (unsigned)j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+            done = (FAST ? blend_entry_fast<> : blend_entry<>)(st, F3DG_R3_FLAG | (unsigned)j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
         }
         if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
             if (st.last_contributor - F3DG_R3_FLAG < (unsigned)F3DG_R3_WIN)
@@ -883,7 +866,7 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 // e + 32 share entry e and split the quadrant's rows: half_ballots), and phase 2 runs until the now-older half is finished by
 // everybody, pixels that are through with it already working on the newer half. Same LDS (4 KB of records), same phase-1 cost per
 // entry; the model gives 0.64 (15 % fewer phase-2 trips). Per pixel the sequence of blended entries is unchanged.
-template <bool SAVE_AUX, bool FAST, int OCC, int WPB>
+template <bool SAVE_AUX, bool FAST, int OCC, int WPB, bool NORMAL = true, bool DIST = true>
 __global__ void __launch_bounds__(64 * WPB, OCC)
 render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                     const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
@@ -1033,7 +1016,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
             const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
             const float aaf = ray_x * n0 + ray_y * n1 + n2;
             const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-            done = (FAST ? blend_entry_fast : blend_entry)(st, F3DG_R3_FLAG | j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+            done = (FAST ? blend_entry_fast<NORMAL, DIST> : blend_entry<NORMAL, DIST>)(st, F3DG_R3_FLAG | j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
 #if F3DG_R3S_BREAK
             if (done) break;              // a saturated pixel leaves the loop (its mask is cleared once, below, not on every trip)
 #else
@@ -1068,12 +1051,14 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
         out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
         out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
-        out[3 * HW + pix_id] = st.C3;
-        out[4 * HW + pix_id] = st.C4;
-        out[5 * HW + pix_id] = st.C5;
+        if (NORMAL) {
+            out[3 * HW + pix_id] = st.C3;
+            out[4 * HW + pix_id] = st.C4;
+            out[5 * HW + pix_id] = st.C5;
+        }
         out[6 * HW + pix_id] = st.C6;
         out[7 * HW + pix_id] = st.C7;
-        out[8 * HW + pix_id] = distortion;
+        if (DIST) out[8 * HW + pix_id] = distortion;
     }
 }
 
@@ -1200,7 +1185,7 @@ render3l_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
                 const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
                 const float aaf = ray_x * n0 + ray_y * n1 + n2;
                 const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
-                done = (FAST ? blend_entry_fast : blend_entry)(st, F3DG_R3_FLAG | (unsigned)j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+                done = (FAST ? blend_entry_fast<> : blend_entry<>)(st, F3DG_R3_FLAG | (unsigned)j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
             }
             if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
                 if (st.last_contributor - F3DG_R3_FLAG < (unsigned)F3DG_R3_WIN)
@@ -1255,7 +1240,7 @@ int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
-                       float* final_T, unsigned* n_contrib, int save_aux)
+                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
@@ -1288,8 +1273,16 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
                          focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib);                  \
         else F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 1>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,            \
                           focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib); } while (0)
-            if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3S(true, true, 8); else F3DG_LAUNCH3S(true, false, 8); }
+            // the batched loops of the build that consume RGB, depth and alpha only (cycle aggregation, orbit frames) skip the normal
+            // and distortion accumulators: the channels they do write are bit-identical
+            const bool lean = !save_aux && (skip_channels & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION)) == (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION) &&
+                              g_f3dg_render_wpb == 1;
+#define F3DG_LAUNCH3S_LEAN(FST) F3DG_KLAUNCH((render3s_fwd_kernel<false, FST, 8, 1, false, false>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
+                          focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib)
+            if (lean) { if (g_f3dg_render_fast) F3DG_LAUNCH3S_LEAN(true); else F3DG_LAUNCH3S_LEAN(false); }
+            else if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3S(true, true, 8); else F3DG_LAUNCH3S(true, false, 8); }
             else { if (g_f3dg_render_fast) F3DG_LAUNCH3S(false, true, 8); else F3DG_LAUNCH3S(false, false, 8); }
+#undef F3DG_LAUNCH3S_LEAN
 #undef F3DG_LAUNCH3S
             F3DG_HIP_CHECK(hipGetLastError());
             return F3DG_OK;

@@ -50,7 +50,9 @@ def cycle_aggregate(model, images, depth, cfg, rig=None, num_views=8, yaw_diff=0
     # 8 novel views of every image: one launch sequence for the whole batch (visualize.py:293-314), then the hand-off kernel
     wv, fp, cc = (orbit.world_view_transforms.to(device), orbit.full_proj_transforms.to(device),
                   orbit.camera_centers.to(device))
-    r = render_views(first, None, wv, fp, cc, background, cfg, epilogue=False)
+    # (the hand-off consumes RGB, alpha and the median depth only -- visualize.py:304-306 -- so the compositing kernel is asked for
+    # just those: no normal / distortion accumulators, 16 B per pixel less written)
+    r = render_views(first, None, wv, fp, cc, background, cfg, epilogue=False, channels="rgb_depth_alpha")
     xin, zmed = cycle_inputs(r["raster"], B, num_views)        # [V,B,4,H,W] = clamp(rgb) || alpha (visualize.py:311,332), [V,B,1,H,W]
 
     # re-predict from every novel view with its own camera and merge in place (visualize.py:326-340)
@@ -97,7 +99,7 @@ def render_orbit(gaussians, cfg, rig=None, num_views=128, yaw_diff=0.25, pitch_d
             e = min(a + views_per_call, num_views)
             one = b1 - b0 == 1
             r = render_views(gaussians if one else sub, b0 if one else None, wv[a:e], fp[a:e], cc[a:e], bg, cfg,
-                             workspace=workspaces.get((b1 - b0, e - a)), epilogue=epilogue)
+                             workspace=workspaces.get((b1 - b0, e - a)), epilogue=epilogue, channels="rgb_depth_alpha")
             workspaces[(b1 - b0, e - a)] = r["workspace"]
             for k in keys:
                 out[k][b0:b1, a:e] = r[k].reshape((b1 - b0, e - a) + tuple(r[k].shape[1:]))

@@ -20,6 +20,7 @@ import torch.nn as nn
 from .. import _lib
 
 __all__ = ["GaussianRasterizationSettings_GOF", "GaussianRasterizer_GOF", "rasterize_gaussians", "rasterize_views",
+           "set_deferred_status", "deferred_status", "flush",
            "integrate_gaussians_to_points", "integrate_prepare", "integrate_points", "PreparedIntegration", "Workspace"]
 
 
@@ -145,7 +146,7 @@ def _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov
 def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg, *, image_height, image_width,
                     tanfovx, tanfovy, sh=None, colors_precomp=None, scales=None, rotations=None, cov3Ds_precomp=None,
                     view2gaussian_precomp=None, sh_degree=0, scale_modifier=1.0, kernel_size=0.0, workspace=None,
-                    max_rendered=None, save_aux=False, out=None, radii=None, check=True, n_sets=1):
+                    max_rendered=None, save_aux=False, out=None, radii=None, check=True, n_sets=1, channels="all"):
     """Render ``n_views`` cameras of the same Gaussians in ONE launch sequence (f3dg_forward_batched).
 
     viewmatrices / projmatrices: [V,4,4] (any leading singleton dims), camposs [V,3], bg [3] or [V,3].
@@ -156,6 +157,10 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
     ``n_sets`` > 1 (f3dg_forward_sets): the Gaussian tensors hold n_sets sets of equal size one after the other
     ([n_sets * P, ...]) and the V cameras are n_sets groups of V / n_sets (set-major): camera i renders set i // (V / n_sets).
     This is how the cycle aggregation renders the 8 novel views of every image of a batch in one launch sequence.
+
+    ``channels="rgb_depth_alpha"`` (inference only; the build's own batched loops): the compositing kernel neither accumulates nor
+    writes the normal (3..5) and distortion (8) planes of ``color`` -- they hold whatever the buffer held -- and the channels it
+    does write (0..2, 6, 7) are bit-identical to the 9-channel call (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION).
     """
     L = _lib.lib()
     device = means3D.device
@@ -177,6 +182,12 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
     if pm.size(0) != V or cp.size(0) != V or bgt.size(0) not in (1, V):
         raise RuntimeError("viewmatrices, projmatrices, camposs (and bg if per view) must agree on the number of views")
     flags = (_lib.FLAG_SAVE_AUX if save_aux else 0) | (_lib.FLAG_BG_PER_VIEW if (bgt.size(0) == V and V > 1) else 0)
+    if channels == "rgb_depth_alpha":
+        if save_aux:
+            raise RuntimeError('channels="rgb_depth_alpha" is an inference option (the backward reads all nine channels\' state)')
+        flags |= _lib.FLAG_SKIP_NORMAL | _lib.FLAG_SKIP_DISTORTION
+    elif channels != "all":
+        raise RuntimeError('channels must be "all" or "rgb_depth_alpha"')
 
     means3D = _dev_f32(means3D, device)
     sh = _dev_f32(sh, device)
@@ -224,6 +235,65 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
         return out, radii, workspace
 
 
+# ---- deferred status (opt-in): the reference's loops render ONE view per call and never look at num_rendered; its contract of a
+# status per call (rasterizer_impl.cu:336) costs a host synchronisation per view. With `set_deferred_status(True)` the no-grad calls of
+# `GaussianRasterizer_GOF` / `render_predicted_more_v2_gof` post the header read-back behind the call (f3dg_status_post) and check it
+# when the NEXT call arrives on the same stream (by then it has long landed) or at `flush()`. An overflow found that way re-issues the
+# call it belongs to with a grown workspace INTO THE SAME output tensors (and re-runs whatever the wrapper derived from them), and
+# warns: anything the caller enqueued on those outputs in between read an incomplete frame. The first call of a shape -- no capacity
+# is known for it yet -- is always checked at once. Default: off (the reference's blocking contract).
+_DEFERRED = {"on": False}
+_PENDING = {}       # (device index, stream) -> {"ticket": int, "ws": Workspace, "redo": [callables], "shape": key of _CAP_HINT}
+
+
+def set_deferred_status(on=True):
+    """Opt in / out of the deferred status check of no-grad single-view calls (see the comment above). Turning it off flushes."""
+    if not on:
+        flush()
+    _DEFERRED["on"] = bool(on)
+
+
+def deferred_status():
+    return _DEFERRED["on"]
+
+
+def _resolve(key):
+    p = _PENDING.pop(key, None)
+    if p is None:
+        return
+    n = C.c_longlong(0)
+    rc = _lib.lib().f3dg_status_poll(p["ticket"], 1, C.byref(n))
+    if rc == _lib.ERR_OVERFLOW:
+        import warnings
+        warnings.warn("f3dgaus_amd: a rasterizer call whose status check was deferred needed %d instances, more than its workspace "
+                      "held; it has been re-issued into the same output tensors -- work enqueued on them in between saw an "
+                      "incomplete frame" % n.value)
+        _CAP_HINT[p["shape"]] = max(int(n.value * 1.5) + 1024, 1 << 14)
+        for fn in p["redo"]:
+            fn()
+        return
+    _lib.check(rc, "f3dg_status_poll")
+    p["ws"].num_rendered = int(n.value)
+    _CAP_HINT[p["shape"]] = max(_CAP_HINT.get(p["shape"], 0), int(n.value * 1.5) + 1024, 1 << 14)
+
+
+def flush(device=None):
+    """Checks every deferred status (waits for the calls they belong to). Call it before relying on the frames of a loop that ran
+    with `set_deferred_status(True)`; `torch.cuda.synchronize()` alone does not look at the overflow flags."""
+    for key in list(_PENDING):
+        if device is None or key[0] == torch.device(device).index:
+            _resolve(key)
+
+
+def add_redo(fn):
+    """(wrapper-internal) work derived from the outputs of the call just issued on the current stream, to be repeated if that call
+    turns out to have overflowed."""
+    dev = torch.cuda.current_device()
+    p = _PENDING.get((dev, torch.cuda.current_stream().cuda_stream))
+    if p is not None:
+        p["redo"].append(fn)
+
+
 def read_status(workspace):
     """BLOCKING: number of (Gaussian, tile) instances of the last call on this workspace; raises on overflow."""
     n = C.c_longlong(0)
@@ -244,6 +314,66 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, view2gaussian_precomp, raster_settings)
 
 
+def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp):
+    """One reference-shaped rasterizer call (one view): (color [1,9,H,W], radii [1,P], workspace). Shared by the autograd Function
+    and by the wrapper's inference path (`rasterize_nograd`)."""
+    device = means3D.device
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = None if needs_grad else _WS_CACHE.get(key)
+
+    shape_key = (means3D.size(0), int(rs.image_width), int(rs.image_height), 1)
+    deferred = _DEFERRED["on"] and not needs_grad and not rs.debug and device.type == "cuda"
+    if deferred:
+        _resolve(key)                                  # the previous call on this stream: its status has landed long ago
+        deferred = shape_key in _CAP_HINT             # no capacity known yet: check this one at once
+
+    def call(check=True, out=None, radii=None, workspace=ws, max_rendered=None):
+        return rasterize_views(
+            means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg.reshape(-1)[:3],
+            image_height=rs.image_height, image_width=rs.image_width, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, sh=sh,
+            colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp,
+            view2gaussian_precomp=view2gaussian_precomp, sh_degree=rs.sh_degree, scale_modifier=rs.scale_modifier,
+            kernel_size=rs.kernel_size, workspace=workspace, save_aux=needs_grad, check=check, out=out, radii=radii,
+            max_rendered=max_rendered)
+
+    if rs.debug:
+        # rast_py:88-98: keep a host copy of the arguments (in the order of the reference's tuple, rast_py:61-84) and dump
+        # it if the rasterizer fails
+        cpu_args = cpu_deep_copy_tuple((rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
+                                        cov3Ds_precomp, view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                        rs.tanfovy, rs.kernel_size, rs.subpixel_offset, rs.image_height, rs.image_width, sh,
+                                        rs.sh_degree, rs.campos, rs.prefiltered, rs.debug))
+        try:
+            color, radii, ws = call()
+            torch.cuda.synchronize(device)       # debug mode: surface asynchronous HIP errors here (auxiliary.h:204-211)
+        except Exception as ex:
+            torch.save(cpu_args, "snapshot_fw.dump")
+            print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise ex
+    elif deferred:
+        if ws is not None and ws.max_rendered < _CAP_HINT[shape_key]:
+            ws = None                                  # (the hint grew after an overflow: a workspace of that capacity)
+        color, radii, ws = call(check=False, workspace=ws, max_rendered=None if ws is not None else _CAP_HINT[shape_key])
+        ticket = _lib.check(_lib.lib().f3dg_status_post(_stream(), C.c_void_p(ws.buffer.data_ptr())), "f3dg_status_post")
+
+        def redo(color=color, radii=radii):
+            _, _, ws2 = call(check=True, out=color, radii=radii, workspace=None)
+            _WS_CACHE[key] = ws2
+        _PENDING[key] = {"ticket": ticket, "ws": ws, "redo": [redo], "shape": shape_key}
+    else:
+        color, radii, ws = call()
+    if not needs_grad:
+        _WS_CACHE[key] = ws
+    return color, radii, ws
+
+
+def rasterize_nograd(means3D, sh, colors_precomp, opacities, scales, rotations, raster_settings):
+    """The inference call of `GaussianRasterizer_GOF.forward` without the nn.Module and autograd.Function around it (the wrapper's
+    own no-grad path: ~30 us of host time per call less). Returns (color [9,H,W], radii [P])."""
+    color, radii, _ = _forward_impl(raster_settings, False, means3D, sh, colors_precomp, opacities, scales, rotations, None, None)
+    return color[0], radii[0]
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """Autograd wrapper; argument order and the (color, radii) result follow rast_py:46-104, the gradient order
     rast_py:152-165."""
@@ -253,36 +383,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 view2gaussian_precomp, raster_settings):
         rs = raster_settings
         needs_grad = any(ctx.needs_input_grad)      # (grad mode is always off inside Function.forward)
-        device = means3D.device
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
-        ws = None if needs_grad else _WS_CACHE.get(key)
-
-        def call():
-            return rasterize_views(
-                means3D, opacities, rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg.reshape(-1)[:3],
-                image_height=rs.image_height, image_width=rs.image_width, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, sh=sh,
-                colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp,
-                view2gaussian_precomp=view2gaussian_precomp, sh_degree=rs.sh_degree, scale_modifier=rs.scale_modifier,
-                kernel_size=rs.kernel_size, workspace=ws, save_aux=needs_grad, check=True)
-
-        if rs.debug:
-            # rast_py:88-98: keep a host copy of the arguments (in the order of the reference's tuple, rast_py:61-84) and dump
-            # it if the rasterizer fails
-            cpu_args = cpu_deep_copy_tuple((rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
-                                            cov3Ds_precomp, view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
-                                            rs.tanfovy, rs.kernel_size, rs.subpixel_offset, rs.image_height, rs.image_width, sh,
-                                            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug))
-            try:
-                color, radii, ws = call()
-                torch.cuda.synchronize(device)       # debug mode: surface asynchronous HIP errors here (auxiliary.h:204-211)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_fw.dump")
-                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
-                raise ex
-        else:
-            color, radii, ws = call()
-        if not needs_grad:
-            _WS_CACHE[key] = ws
+        color, radii, ws = _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                         view2gaussian_precomp)
         ctx.raster_settings = rs
         ctx.num_rendered = ws.num_rendered
         ctx.workspace = ws if needs_grad else None

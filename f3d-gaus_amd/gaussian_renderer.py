@@ -16,8 +16,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF, _stream,
-                                     integrate_points, integrate_prepare, integrate_prepare_batched, rasterize_views)
+from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, GaussianRasterizer_GOF, _stream, add_redo, deferred_status,
+                                     integrate_points, integrate_prepare, integrate_prepare_batched, rasterize_nograd,
+                                     rasterize_views)
 
 
 def focal2fov(focal, pixels):
@@ -28,8 +29,9 @@ def focal2fov_torch(focal, pixels):
     return 2 * torch.atan(pixels / (2 * focal))
 
 
-def _epilogue(raster, world_view, W, H, FoVx, FoVy, want_normal=True, want_depth_normal=True):
-    """raster [V,9,H,W], world_view [V,4,4] (row-vector convention). Returns (normal_world, depth_normal) [V,3,H,W]."""
+def _epilogue(raster, world_view, W, H, FoVx, FoVy, want_normal=True, want_depth_normal=True, out=None):
+    """raster [V,9,H,W], world_view [V,4,4] (row-vector convention). Returns (normal_world, depth_normal) [V,3,H,W]; `out`: a pair of
+    such tensors to fill instead of new ones."""
     V = raster.shape[0]
     device = raster.device
     wv = world_view.reshape(V, 16)
@@ -37,8 +39,11 @@ def _epilogue(raster, world_view, W, H, FoVx, FoVy, want_normal=True, want_depth
         wv = wv.float().contiguous()
     fx = W / (2 * math.tan(FoVx / 2.))
     fy = H / (2 * math.tan(FoVy / 2.))
-    nw = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_normal else None
-    dn = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_depth_normal else None
+    if out is not None:
+        nw, dn = out
+    else:
+        nw = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_normal else None
+        dn = torch.empty((V, 3, H, W), dtype=torch.float32, device=device) if want_depth_normal else None
     raster = raster.contiguous()
     # (c2w = inverse(world_view^T) is formed inside the kernel: no torch.linalg.inv per call)
     rc = _lib.lib().f3dg_render_epilogue_view(_stream(), V, H, W, _lib.ptr(raster), _lib.ptr(wv), float(fx), float(fy),
@@ -140,7 +145,7 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
         kernel_size=kernel_size, subpixel_offset=subpixel_offset, bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=world_view_transform, projmatrix=full_proj_transform, sh_degree=cfg['model']['max_sh_degree'],
         campos=camera_center, prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer_GOF(raster_settings=raster_settings)
+    rasterizer = GaussianRasterizer_GOF(raster_settings=raster_settings) if (torch.is_grad_enabled() or points3D is not None) else None
 
     means3D = xyz
     means2D = screenspace_points
@@ -156,6 +161,11 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
             points3D=points3D, means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
             opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None, view2gaussian_precomp=None)
         extra = {"alpha_integrated": alpha_integrated, "color_integrated": color_integrated}
+    elif not torch.is_grad_enabled():
+        # inference: the same call without the nn.Module / autograd.Function wrapping (host time; the kernels are the same)
+        shs = _cat_sh(get("features_dc"), get("features_rest")) if override_color is None else None
+        rendered_image, radii = rasterize_nograd(means3D, shs, None if override_color is None else get("rgbs"), opacity, scales,
+                                                 rotations, raster_settings)
     elif override_color is None:
         shs = _cat_sh(get("features_dc"), get("features_rest"))
         rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None,
@@ -173,7 +183,10 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
         # normal-consistency or depth-normal loss must reach the rasterizer's backward -- same ops here instead of the fused kernel
         nw0, dn0 = _epilogue_autograd(rendered_image, wv[0], image_width, image_height, FovX, FovY)
     else:
-        nw, dn = _epilogue(rendered_image.detach().unsqueeze(0), wv, image_width, image_height, FovX, FovY)
+        raster1 = rendered_image.detach().unsqueeze(0)
+        nw, dn = _epilogue(raster1, wv, image_width, image_height, FovX, FovY)
+        if deferred_status():         # (derived from the raster: repeated if the deferred status check finds that the call overflowed)
+            add_redo(lambda: _epilogue(raster1, wv, image_width, image_height, FovX, FovY, out=(nw, dn)))
         nw0, dn0 = nw[0], dn[0]
     res = {"render": rendered_image[:3, :, :],
            "rendered_normal": nw0,
@@ -265,14 +278,17 @@ def render_predicted_more_v3_gof(pc, bs, world_view_transform, full_proj_transfo
 
 def render_views(pc: dict, bs, world_view_transforms, full_proj_transforms, camera_centers, bg_color, cfg,
                  kernel_size=0.0, scaling_modifier=1.0, override_color=None, workspace=None, epilogue=True,
-                 check=True):
+                 check=True, channels="all"):
     """All V cameras of image ``bs`` in one launch sequence (no per-view Python loop, no per-view host sync).
     Returns a dict with the same keys as ``render_predicted_more_v2_gof`` but a leading view axis:
     render [V,3,H,W], rendered_normal [V,3,H,W], rendered_depth [V,1,H,W], depth_normal [V,3,H,W],
     rendered_alpha [V,1,H,W], distortion_map [V,1,H,W], radii [V,P], visibility_filter [V,P], plus 'workspace'.
 
     ``bs=None``: ALL B images of the batch through the same V cameras in one launch sequence (f3dg_forward_sets); the leading
-    axis is then B * V, image-major (frame b * V + v)."""
+    axis is then B * V, image-major (frame b * V + v).
+
+    ``channels="rgb_depth_alpha"``: what visualize.py:304-306, 400-402 consume. The compositing kernel skips the normal and distortion
+    accumulators; ``rendered_normal`` and ``distortion_map`` are None, the other maps bit-identical to the 9-channel call."""
     fov = cfg['model']['fov']
     tanfov = math.tan(fov * np.pi / 360)
     res = int(cfg['model']['training_resolution'])
@@ -294,13 +310,15 @@ def render_views(pc: dict, bs, world_view_transforms, full_proj_transforms, came
             take(pc["xyz"]), take(pc["opacity"]), wv, fp, cc, bg_color,
             image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, sh=shs, colors_precomp=colors,
             scales=take(pc["scaling"]), rotations=take(pc["rotation"]), sh_degree=cfg['model']['max_sh_degree'],
-            scale_modifier=scaling_modifier, kernel_size=kernel_size, workspace=workspace, check=check, n_sets=n_sets)
+            scale_modifier=scaling_modifier, kernel_size=kernel_size, workspace=workspace, check=check, n_sets=n_sets,
+            channels=channels)
+        lean = channels != "all"
         nw = dn = None
         if epilogue:
             nw, dn = _epilogue(raster, wv.reshape(V * n_sets, 4, 4).to(raster.device), res, res,
-                               fov * np.pi / 180, fov * np.pi / 180)
+                               fov * np.pi / 180, fov * np.pi / 180, want_normal=not lean)
     return {"render": raster[:, :3], "rendered_normal": nw, "rendered_depth": raster[:, 6:7], "depth_normal": dn,
-            "rendered_alpha": raster[:, 7:8], "distortion_map": raster[:, 8:9], "visibility_filter": radii > 0,
+            "rendered_alpha": raster[:, 7:8], "distortion_map": None if lean else raster[:, 8:9], "visibility_filter": radii > 0,
             "radii": radii, "raster": raster, "workspace": ws}
 
 

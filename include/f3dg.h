@@ -62,6 +62,13 @@ extern "C" {
 #define F3DG_FLAG_SAVE_AUX   1u  /* keep final_T / n_contrib / conic / clamped for f3dg_backward (training mode).
                                     Without it the compositing kernel writes only the 9 output channels. */
 #define F3DG_FLAG_BG_PER_VIEW 2u /* background is [n_views,3] instead of [3] */
+/* Output-channel mask of inference calls (not part of the reference's API: visualize.py:304-306, 400-402 consume only `render`,
+ * `rendered_depth` and `rendered_alpha`, and the build's own batched loops -- cycle aggregation, orbit frames -- ask for just those).
+ * With BOTH flags the compositing kernel neither accumulates nor writes the view-space normal (channels 3..5) and the distortion
+ * (channel 8): those planes of out_color are left untouched, every other channel is bit-identical to the 9-channel call. Ignored
+ * with F3DG_FLAG_SAVE_AUX and by the kernels of one- or two-view launches (which then write all nine). */
+#define F3DG_FLAG_SKIP_NORMAL 4u
+#define F3DG_FLAG_SKIP_DISTORTION 8u
 
 #define F3DG_TILE 16             /* BLOCK_X = BLOCK_Y = 16, RAST/cuda_rasterizer/config.h:16-17 */
 #define F3DG_OUT_CHANNELS 9      /* RGB, normal xyz, median depth, alpha, distortion: auxiliary.h:21-24 */
@@ -120,6 +127,18 @@ int f3dg_forward_sets(void* stream, void* workspace, size_t workspace_bytes, lon
  * h_num_rendered: total instances the call needed; returns F3DG_OK, or F3DG_ERR_OVERFLOW if that exceeded
  * the capacity the workspace was sized for (outputs of that call are then undefined). */
 int f3dg_read_status(void* stream, const void* workspace, long long* h_num_rendered);
+
+/* The same status WITHOUT blocking the caller -- what is left of the reference's blocking copy (rasterizer_impl.cu:336) once a loop
+ * renders one view per call and never looks at num_rendered (visualize.py:293-314, 387-416).
+ * f3dg_status_post: enqueues on `stream`, behind the forward just issued on it, a copy of the workspace header into pinned host
+ *   memory owned by the library, and an event. Returns a ticket >= 0 (or a negative error). The workspace may be reused by the next
+ *   call on the same stream at once: the copy is ordered before it.
+ * f3dg_status_poll: F3DG_PENDING while the copy has not landed (wait == 0); otherwise -- after waiting for it if wait != 0 --
+ *   F3DG_OK / F3DG_ERR_OVERFLOW as f3dg_read_status, *h_num_rendered as there, and the ticket is released. A caller that defers the
+ *   check this way must be able to re-issue the call it belongs to (outputs of an overflowed call are undefined). */
+#define F3DG_PENDING 1
+int f3dg_status_post(void* stream, const void* workspace);
+int f3dg_status_poll(int ticket, int wait, long long* h_num_rendered);
 
 /* Reference-shaped single-view forward (Rasterizer::forward): f3dg_forward_batched(n_views = 1) followed by
  * f3dg_read_status(). BLOCKING, like the reference (rasterizer_impl.cu:336). Returns num_rendered >= 0 or a

@@ -324,3 +324,31 @@ def test_refilled_buffers_render_their_new_contents(gpu_device):
         pci = {k: v.clone() for k, v in pc.items()}
         d = f3d.render_predicted_more_v2_gof(pci, 0, *args)["render"]
     assert torch.equal(d, c)
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_channel_mask_leaves_the_written_channels_bit_identical(mode, gpu_device):
+    """`channels="rgb_depth_alpha"` (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION; used by cycle_aggregate / render_orbit, which
+    consume what visualize.py:304-306, 400-402 consume): RGB, median depth and alpha equal the 9-channel render to the bit, the
+    normal and distortion planes of the output buffer are not touched."""
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    g = synthetic.make_gaussians(20000, s0=0.02, seed=5, device=gpu_device)
+    cams = synthetic.orbit_cameras(24, resolution=128, device=gpu_device)
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
+    kw = dict(image_height=128, image_width=128, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"],
+              rotations=g["rotation"], sh_degree=1)
+    args = (g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], torch.zeros(3, device=gpu_device))
+    assert L.f3dg_set_option(b"render_fast", 1 if mode == "fast" else 0) == 0
+    try:
+        full, _, _ = f3d.rasterize_views(*args, **kw)
+        buf = torch.full_like(full, 123.0)
+        lean, _, _ = f3d.rasterize_views(*args, out=buf, channels="rgb_depth_alpha", **kw)
+    finally:
+        L.f3dg_set_option(b"render_fast", 1)
+    for c in (0, 1, 2, 6, 7):
+        assert torch.equal(lean[:, c], full[:, c]), c
+    assert bool((lean[:, 3:6] == 123.0).all()) and bool((lean[:, 8] == 123.0).all())
+    assert float(full[:, 3:6].abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        f3d.rasterize_views(*args, channels="rgb_depth_alpha", save_aux=True, **kw)

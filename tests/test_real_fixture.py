@@ -78,7 +78,8 @@ def test_dropin_wrapper_on_real_fixture(v, gpu_device):
     dev = gpu_device
     pc = {k[2:]: torch.from_numpy(g[k]).unsqueeze(0).to(dev) for k in g.files if k.startswith("g_") and g[k].ndim >= 2}
     wv, fp, cc = (torch.from_numpy(g[f"v{v}_{n}"]).to(dev) for n in ("wv", "fp", "cc"))
-    r = f3d.render_predicted_more_v2_gof(pc, 0, wv, fp, cc, torch.zeros(1, 3, device=dev), cfg)
+    with torch.no_grad():
+        r = f3d.render_predicted_more_v2_gof(pc, 0, wv, fp, cc, torch.zeros(1, 3, device=dev), cfg)
     ref = g[f"v{v}_raster"]
     got = torch.cat([r["render"], r["rendered_normal"], r["rendered_depth"], r["rendered_alpha"], r["distortion_map"]], 0).cpu().numpy()
     for name, a, b in (("render", got[:3], ref[:3]), ("alpha", got[7], ref[7])):

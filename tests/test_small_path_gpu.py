@@ -88,3 +88,57 @@ def test_small_path_overflow_falls_back(gpu_device):
     assert a[5] > b[5] and again[5] == b[5]                    # first: small attempt + general retry; then general at once
     for r in (a, again):
         assert torch.equal(r[0], b[0]) and torch.equal(r[1], b[1]) and r[2] == b[2] and np.array_equal(r[3], b[3])
+
+
+def _pc(scene, device):
+    shs = scene["shs"].to(device)
+    return {"xyz": scene["means3D"][None].to(device), "opacity": scene["opacities"][None].to(device),
+            "scaling": scene["scales"][None].to(device), "rotation": scene["rotations"][None].to(device),
+            "features_dc": shs[None, :, :1].contiguous(), "features_rest": shs[None, :, 1:].contiguous()}
+
+
+def test_deferred_status_same_frames_and_late_overflow_is_repaired(gpu_device):
+    """`set_deferred_status(True)`: the status of a drop-in call is checked when the next call arrives on the stream (or at `flush()`)
+    instead of blocking. Same frames as the blocking contract; an overflow found late -- here a call that needs 6x the instances of
+    the one that sized the workspace, on the small-call path AND beyond a tile's slot -- re-issues the call into the same output
+    tensors (and the derived normal maps), with a warning."""
+    import warnings
+    from f3dgaus_amd import cameras
+    from f3dgaus_amd import diff_gof_rasterization as dgr
+    cfg = cameras.default_cfg(128)
+    small = make_scene(P=30000, res=(128, 128), s0=0.008, view="oblique")
+    big = make_scene(P=30000, res=(128, 128), s0=0.05, view="oblique")          # tile lists of 4 k .. 16 k entries
+    dev = gpu_device
+    cam = lambda sc: (sc["viewmatrix"][:1].to(dev), sc["projmatrix"][:1].to(dev), sc["campos"][:1].to(dev), torch.zeros(1, 3, device=dev), cfg)
+    L = _lib.lib()
+    L.f3dg_set_option(b"small_path", 2)
+    keys = ("render", "rendered_normal", "rendered_depth", "depth_normal", "rendered_alpha", "distortion_map", "radii")
+    with torch.no_grad():
+        want_small = {k: v.clone() for k, v in f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small)).items() if k in keys}
+        want_big = {k: v.clone() for k, v in f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big)).items() if k in keys}
+        dgr._CAP_HINT.clear()
+        dgr._WS_CACHE.clear()
+        L.f3dg_set_option(b"small_path", 2)
+        f3d.set_deferred_status(True)
+        try:
+            a0 = f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small))      # first call of the shape: checked at once
+            a1 = f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small))      # deferred
+            assert len(dgr._PENDING) == 1
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                b = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))       # resolves a1 (fine), overflows itself -- unnoticed so far
+                assert not w
+                f3d.flush()                                                             # ... until here: re-issued in place
+                assert len(w) == 1 and "re-issued" in str(w[0].message)
+            assert not dgr._PENDING
+            c = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))           # the grown hint: no overflow any more
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                f3d.flush()
+                assert not w
+        finally:
+            f3d.set_deferred_status(False)
+            L.f3dg_set_option(b"small_path", 2)
+    for got, want in ((a0, want_small), (a1, want_small), (b, want_big), (c, want_big)):
+        for k in keys:
+            assert torch.equal(got[k], want[k]), k
