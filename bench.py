@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--tile-cull", type=int, choices=[0, 1], default=1,
                     help="1 (library default): a Gaussian is instantiated only in the tiles its alpha >= 1/255 ellipse reaches; "
                          "0: the reference's tile lists (every tile of the 3-sigma square)")
+    ap.add_argument("--data", choices=["synthetic", "real"], default="synthetic",
+                    help="c2: synthetic = the recipe of SURVEY 8d; real = the image of fixture F6 (tests/golden/real_image_256.npz: "
+                         "images/1/n01644373_4548.jpg + its LeReS depth) through the build's own predictor and cycle aggregation "
+                         "(formula weights, no checkpoint travels): the 589,824 merged Gaussians along the 128-view orbit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the timed loops with frame packing + device-to-host copy: `value` is then the in-HBM rate")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra timed loop in the reference's arithmetic (value_exact / roofline_exact)")
@@ -167,7 +171,17 @@ def main():
 def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     from f3dgaus_amd import _lib, synthetic
     P, V, RES = args.gaussians, args.views, args.res
-    g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)     # every rank = a different image
+    if args.data == "real":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from real_data import real_merged_set
+        assert RES == 256, "--data real is the 256 x 256 image"
+        g = real_merged_set(device)                # predict -> 8 novel views -> 8 re-predictions -> merge (untimed set-up)
+        P = g["xyz"].shape[0]
+        if V == 120:
+            V = args.views = 128                   # the reference's final orbit (visualize.py:343-416)
+        torch.cuda.synchronize()
+    else:
+        g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)     # every rank = a different image
     cams = synthetic.orbit_cameras(V, resolution=RES, device=device)
     shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
     bg = torch.zeros(3, device=device)
@@ -201,6 +215,17 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         cap = int(max(c[1] for c in counts if c[0] == n) * 1.25) + 4096
         workspaces[n] = f3d.diff_gof_rasterization.Workspace(P, RES, RES, n, cap, device)
     R_proc = sum(c[1] for c in counts)
+    # length of the (view, tile) lists the compositing kernel is handed (last chunk's call: the ranges are still in its workspace)
+    a_, b_ = chunks[-1]
+    T_ = ((RES + 15) // 16) ** 2
+    rng_ = torch.zeros((b_ - a_) * T_ * 2, dtype=torch.int32, device=device)
+    _lib.check(L.f3dg_debug_export(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), P, RES, RES, b_ - a_,
+                                   ws.max_rendered, None, None, None, None, None, None, None, None, C.c_void_p(rng_.data_ptr()), None, None, None),
+               "f3dg_debug_export")
+    rr_ = rng_.reshape(-1, 2).cpu()
+    lens_ = (rr_[:, 1] - rr_[:, 0]).float()
+    list_stats = {"tile_list_mean": float(lens_.mean()), "tile_list_max": int(lens_.max()), "instances_per_view_and_gaussian": R_proc / float(V * P),
+                  "reference_instances_per_view_and_gaussian (R/P per view)": R_total / float(V * P)}
 
     gat = Gatherer(dist, world, rank, (V, RES, RES, 3), comm_device)
 
@@ -210,23 +235,32 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         if world > 1:
             gat.submit(f3d.gaussian_renderer.pack_frames(out))          # uint8 [V,H,W,3], one kernel
 
+    def collect(steps):
+        """per-stage HIP-event milliseconds of the calls recorded since profiling was enabled: (sums, calls, per-call rows [calls][3])"""
+        cap = steps * len(chunks) + 8
+        st = (C.c_double * 5)()
+        nc = C.c_int(0)
+        per = (C.c_double * (3 * cap))()
+        _lib.check(L.f3dg_profile_collect_calls(st, C.byref(nc), per, cap), "f3dg_profile_collect_calls")
+        n = min(int(nc.value), cap)
+        return [st[i] for i in range(5)], max(int(nc.value), 1), [[per[3 * k + i] for i in range(3)] for k in range(n)]
+
     def measure(fn, warmup, steps):
-        """(seconds for `steps` steps, per-stage HIP-event milliseconds summed over them, forward calls, kernel launches)"""
+        """(seconds for `steps` steps, per-stage HIP-event milliseconds summed over them, forward calls, kernel launches, per-call rows)"""
         timed(fn, gat.barrier, warmup, 0)
         L.f3dg_profile_enable(1)
         L.f3dg_debug_launch_count(1)
         t = timed(fn, gat.barrier, 0, steps)
         launches = int(L.f3dg_debug_launch_count(1))
         L.f3dg_profile_enable(0)
-        st = (C.c_double * 5)()
-        nc = C.c_int(0)
-        _lib.check(L.f3dg_profile_collect(st, C.byref(nc)), "f3dg_profile_collect")
+        st, nc, rows = collect(steps)
         for ws in workspaces.values():      # no overflow happened in the timed region
             f3d.diff_gof_rasterization.read_status(ws)
-        return t, [st[i] for i in range(5)], max(int(nc.value), 1), launches
+        return t, st, nc, launches, rows
 
     # (1) frames left in HBM (N > 1: + the RCCL gather of the packed frames)
-    elapsed_hbm, stage_ms, ncalls, nlaunch = measure(step, args.warmup, args.steps)
+    elapsed_hbm, stage_ms, ncalls, nlaunch, rows = measure(step, args.warmup, args.steps)
+    kernel_name = L.f3dg_debug_last_render_kernel().decode()           # what the library launched, with its template arguments
     elapsed_hbm = max_over_ranks(elapsed_hbm, dist, world, comm_device if world > 1 else device)
 
     # (2) N = 1, SURVEY 8d "views/s = views / wall time including the final D2H of RGB only": the frames leave the GPU as 8-bit RGB
@@ -252,18 +286,30 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         # The pack + copy of a finished step is issued by a second host thread: where a device-to-host copy blocks its caller (a box
         # whose pinned allocation or copy engine misbehaves: seen once, 20 k instead of 29 k views/s) it blocks that thread, not the one
         # that issues the next step's kernels.
+        copier_error = []
+
         def copier():
             torch.cuda.set_device(device)
             while True:
                 k = jobs.get()
                 if k is None:
                     return
-                with torch.cuda.stream(side):
-                    side.wait_event(rendered[k])
-                    f3d.gaussian_renderer.pack_frames(outs[k], out=packed[k])
-                    host[k].copy_(packed[k], non_blocking=True)
-                    copied[k].record()
-                issued[k].set()
+                try:
+                    with torch.cuda.stream(side):
+                        side.wait_event(rendered[k])
+                        f3d.gaussian_renderer.pack_frames(outs[k], out=packed[k])
+                        host[k].copy_(packed[k], non_blocking=True)
+                        copied[k].record()
+                except Exception as ex:          # the main thread must not wait for ever on issued[k]
+                    copier_error.append(ex)
+                finally:
+                    issued[k].set()
+
+        def wait_issued(ev):
+            if not ev.wait(timeout=120.0):
+                raise RuntimeError("bench: the frame-copy thread did not answer within 120 s")
+            if copier_error:
+                raise RuntimeError("bench: the frame-copy thread failed") from copier_error[0]
 
         worker = threading.Thread(target=copier, daemon=True)
         worker.start()
@@ -271,7 +317,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         def step_d2h():
             k = state["i"] & 1
             state["i"] += 1
-            issued[k].wait()
+            wait_issued(issued[k])
             issued[k].clear()
             torch.cuda.current_stream().wait_event(copied[k])        # the side stream has read buffer k (two steps ago)
             for a, b in chunks:
@@ -281,7 +327,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
 
         def d2h_barrier():
             for ev in issued:                                        # every copy has been issued ...
-                ev.wait()
+                wait_issued(ev)
             gat.barrier()                                            # ... and (device synchronisation) has arrived
 
         for k in range(2):
@@ -293,10 +339,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         elapsed = timed(step_d2h, d2h_barrier, 0, args.steps)
         nlaunch = int(L.f3dg_debug_launch_count(1)) - args.steps       # (the pack kernel of every step is the copy thread's)
         L.f3dg_profile_enable(0)
-        st_ = (C.c_double * 5)()
-        nc_ = C.c_int(0)
-        _lib.check(L.f3dg_profile_collect(st_, C.byref(nc_)), "f3dg_profile_collect")
-        stage_ms, ncalls = [st_[i] for i in range(5)], max(int(nc_.value), 1)
+        stage_ms, ncalls, rows = collect(args.steps)
         for ws in workspaces.values():      # no overflow happened in the timed region
             f3d.diff_gof_rasterization.read_status(ws)
         jobs.put(None)
@@ -321,10 +364,29 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     exact = None
     if args.render_mode == "fast" and not args.no_exact:
         _lib.check(L.f3dg_set_option(b"render_fast", 0), "f3dg_set_option")
-        e_x, st_x, nc_x, _ = measure(step, 1, args.steps)
+        e_x, st_x, nc_x, _, rows_x = measure(step, 1, args.steps)
+        kernel_name_x = L.f3dg_debug_last_render_kernel().decode()
         _lib.check(L.f3dg_set_option(b"render_fast", 1), "f3dg_set_option")
         e_x = max_over_ranks(e_x, dist, world, comm_device if world > 1 else device)
-        exact = (e_x, st_x, nc_x)
+        exact = (e_x, st_x, nc_x, rows_x, kernel_name_x)
+
+    # (4) what the compositing kernel did, counted by its counting variant in ONE untimed call sequence (option render_count): the
+    # list entries it staged (a quadrant stops reading its tile's list once its 64 pixels are saturated), its phase-2 trips and lanes
+    counts = None
+    if True:        # (every rank: at N > 1 a step ends in the collective gather)
+        _lib.check(L.f3dg_set_option(b"render_count", 1), "f3dg_set_option")
+        cbuf = (C.c_ulonglong * 8)()
+        L.f3dg_debug_render_counts(cbuf, 1)
+        step()
+        gat.barrier()
+        _lib.check(L.f3dg_debug_render_counts(cbuf, 1), "f3dg_debug_render_counts")
+        _lib.check(L.f3dg_set_option(b"render_count", 0), "f3dg_set_option")
+        if cbuf[5]:
+            counts = {"list_entries_staged": int(cbuf[0]), "list_entries_scanned": int(cbuf[1]), "phase2_wave_trips": int(cbuf[2]),
+                      "slides": int(cbuf[3]), "phase2_lane_trips": int(cbuf[4]), "waves": int(cbuf[5]),
+                      "phase2_lane_utilisation": cbuf[4] / (64.0 * cbuf[2]) if cbuf[2] else None,
+                      "note": "one untimed step with option render_count = 1 (the same kernel with work counters); staged entries count "
+                              "a list entry once per quadrant wave that gathers its record"}
 
     if rank != 0:
         return None
@@ -344,26 +406,42 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     b_bin = (108.0 * P * V + 18.0 * R_proc + 8.0 * T * V) / nl
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     prof = profiles_record(P, V, RES, args.views_per_call, args.render_mode, args.tile_cull, args.sigma0)
-    kname = {3: "render3_fwd_kernel", 2: "render2_fwd_kernel", 1: "render_fwd_kernel"}[render_kernel_id()]
+    import statistics
 
-    def roofline(stage, mode_fast, n):
+    def spread(rws, col):
+        v = sorted(r[col] for r in rws) if col is not None else sorted(sum(r) for r in rws)
+        return {"min": v[0], "median": statistics.median(v), "max": v[-1], "n": len(v)} if v else None
+
+    def roofline(stage, kernel, n, rws):
         ms = per(stage[2], n)
-        return {"bound": "hbm", "kernel": "%s<SAVE_AUX=false, FAST=%s>" % (kname, "true" if mode_fast else "false"),
+        return {"bound": "hbm", "kernel": kernel,
                 "achieved": gbs(b_render, ms), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(b_render, ms) / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": b_render, "ms_per_launch": ms,
+                "algorithmic_bytes_per_launch": b_render, "ms_per_launch": ms, "ms_per_launch_spread": spread(rws, 2),
                 "units": "72 B x instances_processed_per_step (the list entries the launch is handed) + 36 B x pixels + 8 B x tiles",
                 "frac_on_reference_instances": gbs(b_render_ref, ms) / HBM_PEAK_GBS,
                 "units_reference": "the same formula on instances_per_step = the reference's num_rendered for this input (tile_cull 0)"}
 
-    rf = roofline(stage_ms, args.render_mode == "fast", ncalls)
-    if rf["frac"] > 1.0:
-        rf["note"] = ("frac > 1: the byte formula counts every list entry, but a quadrant stops reading its tile's list when its 64 pixels are "
-                      "saturated -- with splats this large most of every list is never staged, so the algorithmic bytes are not moved; the "
-                      "kernel is bound by VALU issue, not by HBM (counter traffic: profiles/*/sigma005.md)")
-    # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes, which cannot run inside this process): the figure is
-    # the one of the newest committed profile of THIS configuration (see traffic_from_profiles for kernel, source and how), else null
-    rf.update({"traffic": (prof.get("traffic") or {}).get("bytes_per_launch"),
+    rf = roofline(stage_ms, kernel_name, ncalls, rows)
+    if counts:
+        # the same formula on what the kernel READ: 4 B per scanned list entry + 80 B (record + ellipse) per staged one + the
+        # pixels and ranges. Where saturated quadrants stop long before their list ends (large splats) this, not the algorithmic
+        # figure, is what the launch moved -- and it cannot exceed 1
+        b_staged = (4.0 * counts["list_entries_scanned"] + 80.0 * counts["list_entries_staged"] + (36.0 * RES * RES + 8.0 * T) * V) / nl
+        rf["frac_on_staged_entries"] = gbs(b_staged, rf["ms_per_launch"]) / HBM_PEAK_GBS
+        rf["bytes_read_per_launch_counted"] = b_staged
+        rf["kernel_counters"] = counts
+        if rf["frac"] > 1.0:
+            rf["frac_formula_on_all_list_entries"] = rf["frac"]
+            rf["frac"] = rf["frac_on_staged_entries"]
+            rf["achieved"] = gbs(b_staged, rf["ms_per_launch"])
+            rf["units"] = ("COUNTED by the kernel: 4 B x list entries scanned + 80 B x list entries staged + 36 B x pixels + 8 B x tiles -- the "
+                           "72 B x list-entry formula gives a fraction above 1 here (frac_formula_on_all_list_entries) because saturated "
+                           "quadrants never read most of their tile's list")
+    # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes, which cannot run inside this process): `traffic` stays
+    # null in this line; the figure of the newest committed profile of THIS configuration is under traffic_from_profiles, with its source
+    rf.update({"traffic": None,
                "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
+               "valu_issue_frac_from_profiles": (prof.get("valu") or {}).get("valu_issue_frac"),
                "peak_measured_copy": copy_gbs,     # device-to-device copy on THIS box, read + write bytes
                "stage_ms_per_step": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
                                      "compositing": stage_ms[2] / args.steps}})
@@ -378,19 +456,29 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.render_mode == "fast" else "f32 (+f64 islands, as the reference)", "data": "synthetic",
-        "config": {"workload": "C2: 1 image/GPU, %d Gaussians (sigma0=%g), %d-view orbit @%dx%d, GOF forward raster only; timed region = "
+        "dtype": "f32" if args.render_mode == "fast" else "f32 (+f64 islands, as the reference)",
+        "data": "synthetic" if args.data == "synthetic" else
+                "real image n01644373_4548.jpg + LeReS depth (tests/golden/real_image_256.npz) through this build's predictor + cycle "
+                "aggregation with formula weights (no checkpoint travels); cameras as the reference's orbit",
+        "config": {"workload": "%s: 1 image/GPU, %d Gaussians (%s), %d-view orbit @%dx%d, GOF forward raster only; timed region = "
                                "%s; compositing arithmetic: %s" % (
-                                   P, args.sigma0, V, RES, RES,
+                                   "C2" if args.data == "synthetic" else "C2-shaped on the real merged set",
+                                   P, ("sigma0=%g" % args.sigma0) if args.data == "synthetic" else "9 x 65,536 predicted, sigma ~ 0.01", V, RES, RES,
                                    "render + RCCL gather of the 8-bit frames to rank 0" if world > 1 else
                                    ("render, frames left in HBM" if d2h is None else "render + 8-bit RGB frames copied to pinned host memory"),
                                    caveat),
-                   "gaussians": P, "views": V, "resolution": RES, "sigma0": args.sigma0, "instances_per_step": R_total,
+                   "gaussians": P, "views": V, "resolution": RES, "sigma0": args.sigma0, "instances_per_step": R_total, "lists": list_stats,
                    "instances_processed_per_step": R_proc, "tile_cull": args.tile_cull,
                    "views_per_call": args.views_per_call, "render_mode": args.render_mode,
                    "kernel_launches_per_call": nlaunch / float(ncalls),
                    "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
         "value_in_hbm": world * V * args.steps / elapsed_hbm, "ms_per_step_in_hbm": 1e3 * elapsed_hbm / args.steps,
+        "call_ms_spread": {"note": "device time of one call (projection + binning + compositing, HIP events) over the calls of the timed "
+                                   "loop `value` comes from: a box-to-box or run-to-run effect shows here, not only in the mean",
+                           "all_stages": spread(rows, None), "preprocess": spread(rows, 0), "binning": spread(rows, 1),
+                           "compositing": spread(rows, 2)},
+        "dist_backend": (os.environ.get("F3DG_DIST_BACKEND", "nccl") if world > 1 else None),
+        "ranks_seen": (dist.get_world_size() if world > 1 else 1),
         "roofline": rf,
         "rooflines_other": {
             "preprocess_kernel": {"bound": "hbm", "algorithmic_bytes_per_launch": b_pre, "ms_per_launch": per(stage_ms[0]),
@@ -406,18 +494,14 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     if d2h:
         result["with_d2h"] = d2h
     if exact:
-        e_x, st_x, nc_x = exact
+        e_x, st_x, nc_x, rows_x, kernel_name_x = exact
         result["value_exact"] = world * V * args.steps / e_x
         result["ms_per_step_exact"] = 1e3 * e_x / args.steps
-        result["roofline_exact"] = roofline(st_x, False, nc_x)
+        result["roofline_exact"] = roofline(st_x, kernel_name_x, nc_x, rows_x)
         result["roofline_exact"]["note"] = "same run, option render_fast = 0: the reference's float32/float64 operation order; frames left in HBM"
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(g, cams, shs, P, RES, args.cpu_sample_views)
+        result["cpu_baseline"] = cpu_baseline(g, cams, shs, P, RES, args.cpu_sample_views if args.data == "synthetic" else max(2, args.cpu_sample_views // 3))
     return result
-
-
-def render_kernel_id():
-    return int(os.environ.get("F3DG_RENDER_KERNEL", "3"))
 
 
 # ---------------------------------------------------------------------------------------------------------------- C4

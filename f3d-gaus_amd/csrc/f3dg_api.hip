@@ -119,6 +119,7 @@ int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
 int g_f3dg_render_wpb = 1;
+int g_f3dg_render_count = 0;
 int g_f3dg_render_slide = 1;
 int g_f3dg_render_lowocc = 1;
 int g_f3dg_render_lds_pad = 0;
@@ -140,6 +141,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_count") == 0) { g_f3dg_render_count = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_wpb") == 0) { g_f3dg_render_wpb = value == 4 ? 4 : 1; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
@@ -193,16 +195,23 @@ extern "C" int f3dg_profile_enable(int on)
 // BLOCKING: waits for the recorded events, adds up per-stage milliseconds of every forward call recorded since
 // the previous collect: h_stage_ms[0] preprocess, [1] binning (scan + keys + sort + ranges), [2] compositing, and of every
 // f3dg_backward call: [3] compositing backward, [4] per-Gaussian backward. h_stage_ms holds FIVE doubles.
-extern "C" int f3dg_profile_collect(double* h_stage_ms, int* h_calls)
+extern "C" int f3dg_profile_collect(double* h_stage_ms, int* h_calls) { return f3dg_profile_collect_calls(h_stage_ms, h_calls, nullptr, 0); }
+
+// The same, and the three forward stage times of every recorded call, in call order, in h_per_call[max_calls][3] (calls beyond
+// max_calls only enter the sums): what bench.py's per-launch min / median / max come from.
+extern "C" int f3dg_profile_collect_calls(double* h_stage_ms, int* h_calls, double* h_per_call, int max_calls)
 {
     double sum[ST_COUNT] = { 0, 0, 0 };
+    int k = 0;
     for (ProfCall& c : g_prof.calls) {
         F3DG_HIP_CHECK(hipEventSynchronize(c.ev[ST_COUNT]));
         for (int i = 0; i < ST_COUNT; i++) {
             float ms = 0;
             F3DG_HIP_CHECK(hipEventElapsedTime(&ms, c.ev[i], c.ev[i + 1]));
             sum[i] += ms;
+            if (h_per_call && k < max_calls) h_per_call[3 * k + i] = ms;
         }
+        k++;
         g_prof.pool.push_back(c);
     }
     double bsum[BW_COUNT] = { 0, 0 };

@@ -232,6 +232,7 @@ extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is c
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
 extern int g_f3dg_render_lowocc;       // 1 (default): launches of at most 2048 quadrant waves take render3l_fwd_kernel (next window's gathers in flight)
 extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding half-window (render3s_fwd_kernel); 0: fixed 64-entry windows
+extern int g_f3dg_render_count;        // 1: the one-wave kernel's counting variant (diagnostic; f3dg_debug_render_counts)
 extern int g_f3dg_render_wpb;          // quadrant waves per render3s workgroup: 1 (default) or 4 (a tile's four waves start together on one CU)
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);

@@ -159,13 +159,17 @@ __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float t
     const double m00 = q.m00, m01 = q.m01, m02 = q.m02, m11 = q.m11, m12 = q.m12, m22 = q.m22;
     const double D22 = m00 * m11 - m01 * m01;
     if (!(m00 > 0.0) || !(m11 > 0.0) || !(D22 > 1e-9 * fabs(m00 * m11))) return;
-    const double inv_D22 = 1.0 / D22;
+    // (hardware reciprocals instead of IEEE float64 divisions, ~25 instructions each and three per (view, Gaussian): these are this
+    // build's own bounds, inflated by 0.1 % below. v_rcp_f64 is good to ~1e-8; the centre feeds Qc, where terms of ~1e10 cancel to
+    // ~1e5, so ITS reciprocal takes one Newton step (-> ~1e-16); the other two only scale the form as a whole)
+    double inv_D22 = __builtin_amdgcn_rcp(D22);
+    inv_D22 = fma(fma(-D22, inv_D22, 1.0), inv_D22, inv_D22);
     const double cx = (m01 * m12 - m02 * m11) * inv_D22, cy = (m01 * m02 - m00 * m12) * inv_D22;
     const double Qc = m22 + m02 * cx + m12 * cy;            // value of the conic at its centre; the quadratic part is positive definite
     if (!(Qc == Qc) || !(cx == cx) || !(cy == cy)) return;
     if (Qc > 0.0 && Qc < 1.0e300) { e = never; ec = 1.0e30f; return; }      // empty level set: never visible
     if (!(Qc < 0.0)) return;
-    const double k = -1.0 / Qc;
+    const double k = -__builtin_amdgcn_rcp(Qc);
     double a = m00 * k * (ifx * ifx), b = 2.0 * m01 * k * (ifx * ify), c = m11 * k * (ify * ify);
     const double det = a * c - 0.25 * b * b, tr = a + c;
     if (!(det > 0.0) || !(tr < 1.0e300)) return;
@@ -189,13 +193,16 @@ __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float t
     const double s = 1.001 + 0.05 * (double)(sqrtf((float)lmax) * 1.000001f);   // 0.05 px / semi-minor axis (= 1/sqrt(lmax))
     const double px = cx * focal_x + W / 2. - 0.5, py = cy * focal_y + H / 2. - 0.5;      // pixel-index coordinates
     if (!(fabs(px) < 8192.0) || !(fabs(py) < 8192.0)) return;
-    const double is2 = 1.0 / (s * s);
+    const double is2 = __builtin_amdgcn_rcp(s * s) * (1.0 - 1e-7);      // rounded down: the form only shrinks, the ellipse only grows
     const float fa = (float)(a * is2), fb = (float)(b * is2), fc = (float)(c * is2);
     if (!(fa > 1.0e-30f) || !(fc > 1.0e-30f) || !(fa < 1.0e30f) || !(fc < 1.0e30f)) return;
     e = make_float4((float)px, (float)py, fa, fb);
     ec = fc;
 }
 
+// SAVE_AUX = false (inference calls): the planes only the backward and the debug export read -- and the arithmetic only they need
+// (the 2D conic: one IEEE division) -- are not produced.
+template <bool SAVE_AUX>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 preprocess_kernel(int P, int D, int M, int views_per_set,
                   const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
@@ -210,7 +217,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                   float4* __restrict__ bbox_out, float4* __restrict__ cull_out,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
-                  unsigned char* __restrict__ clamped, int save_aux, int debug_skip_all, int tile_cull,
+                  unsigned char* __restrict__ clamped, int debug_skip_all, int tile_cull,
                   double inv_focal_x, double inv_focal_y, F3dgHeaderInit init)
 {
     if (init.hdr != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
@@ -317,8 +324,11 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
         // ---- invert, extent, tile rectangle (forward.cu:350-374)
         const float det = (cx * cz - cy * cy);
         if (det != 0.0f) {
-            const float det_inv = 1.f / det;
-            const float conic_x = cz * det_inv, conic_y = -cy * det_inv, conic_z = cx * det_inv;
+            float conic_x = 0.0f, conic_y = 0.0f, conic_z = 0.0f;
+            if (SAVE_AUX) {
+                const float det_inv = 1.f / det;
+                conic_x = cz * det_inv; conic_y = -cy * det_inv; conic_z = cx * det_inv;
+            }
             const float mid = 0.5f * (cx + cz);
             const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
             const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -446,7 +456,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                 // Pre-test constant of the compositing kernel (see pretest_constant). alpha = min(.99, opac*exp(power))
                 // < 1/255 whenever power < thr = log(1/(255*opac)); 1e-4 of slack covers logf/expf ulps and the final float
                 // rounding of power. opac <= 0 -> alpha <= 0 always (K = +inf); NaN opacity disables the test.
-                const float thr = debug_skip_all ? __builtin_inff() : opac > 0.0f ? logf(1.0f / (255.0f * opac)) - 1e-4f : (opac <= 0.0f ? __builtin_inff() : opac);
+                const float thr = debug_skip_all ? __builtin_inff() : opac > 0.0f ? -0.6931471805599453f * __builtin_amdgcn_logf(255.0f * opac) - 1e-4f : (opac <= 0.0f ? __builtin_inff() : opac);
                 const float Kpre = pretest_constant(vg, thr);
                 {
                     const bool have_scale = scales != nullptr && v2g_precomp == nullptr;
@@ -464,7 +474,9 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                     // hold a pixel with alpha >= 1/255, the others would be a bare `continue` for each of their pixels.
                     const float edet = fmaf(ce.z, cec, -0.25f * ce.w * ce.w);
                     if (edet > 0.0f) {
-                        const float hx = sqrtf(cec / edet) * 1.0005f + 2e-3f, hy = sqrtf(ce.z / edet) * 1.0005f + 2e-3f;
+                        // (v_rcp_f32 / v_sqrt_f32, 1 ulp each: far inside the 0.05 % + 2e-3 px margin of this box)
+                        const float iedet = __builtin_amdgcn_rcpf(edet);
+                        const float hx = __builtin_amdgcn_sqrtf(cec * iedet) * 1.0005f + 2e-3f, hy = __builtin_amdgcn_sqrtf(ce.z * iedet) * 1.0005f + 2e-3f;
                         int fminx = rminx, fmaxx = rmaxx, fminy = rminy, fmaxy = rmaxy;
                         if (tile_cull) {
                             // tile t holds the pixel centres 16 t .. 16 t + 15
@@ -505,11 +517,16 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
     rects[idx] = rect;
     sort_keys[idx] = my_tiles ? __float_as_uint(depth) : 0xFFFFFFFFu;      // key of the per-view depth sort (f3dg_binning.hip)
     if (bbox_out) bbox_out[idx] = box;
-    cull_out[idx] = ce;
-    r3.w = cec;                             // record slot 15: the ellipse's c (the depth lives in depths_out)
-    float4* dst = reinterpret_cast<float4*>(rec + idx);
-    dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-    if (save_aux) {                         // planes only the backward and the debug export read
+    // The 64-byte record and the 16-byte ellipse are read through the tile lists only: a (view, Gaussian) pair that is in no list
+    // (behind the camera, off screen, or -- with tile culling -- nowhere above alpha 1/255) does not write its 80 bytes. (SAVE_AUX
+    // calls write them all: the debug export hands the arrays out whole.)
+    if (SAVE_AUX || my_tiles != 0u) {
+        cull_out[idx] = ce;
+        r3.w = cec;                         // record slot 15: the ellipse's c (the depth lives in depths_out)
+        float4* dst = reinterpret_cast<float4*>(rec + idx);
+        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+    }
+    if (SAVE_AUX) {                         // planes only the backward and the debug export read
         tiles_touched[idx] = my_tiles;
         means2D[idx] = xy;
         depths_out[idx] = depth;
@@ -540,11 +557,13 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
-    F3DG_KLAUNCH(preprocess_kernel, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales, scale_modifier,
-                       rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,
-                       cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,
-                       depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, save_aux, g_f3dg_debug_skip_all, tile_cull,
-                       1.0 / (double)focal_x, 1.0 / (double)focal_y, init);
+#define F3DG_LAUNCH_PRE(AUX) F3DG_KLAUNCH(preprocess_kernel<AUX>, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales,     \
+                       scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,                          \
+                       cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,                                          \
+                       depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, g_f3dg_debug_skip_all, tile_cull,                                    \
+                       1.0 / (double)focal_x, 1.0 / (double)focal_y, init)
+    if (save_aux) F3DG_LAUNCH_PRE(true); else F3DG_LAUNCH_PRE(false);
+#undef F3DG_LAUNCH_PRE
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

@@ -41,6 +41,11 @@
 #include "f3dg_common.h"
 #include "f3dg_ellipse.h"
 
+#include <stdio.h>
+#include <string.h>
+
+extern const char* g_f3dg_last_render_kernel;
+
 namespace {
 
 struct PixelState {
@@ -434,6 +439,11 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 // through and re-derives every decision from the reference's arithmetic: outputs are bit-identical to the kernel above in either
 // arithmetic mode (tests/test_raster_forward_gpu.py::test_render2_bit_identical).
 
+
+// Work counters of the one-wave kernel (option render_count = 1; f3dg_debug_render_counts): [0] list entries staged (record gathers),
+// [1] list entries scanned, [2] phase-2 trips (wave iterations), [3] slides, [4] lane-trips = (pixel, entry) pairs that entered phase 2
+// ([4] / (64 [2]) = lane utilisation of phase 2), [5] waves. 64 rows against atomic contention; summed on the host.
+__device__ unsigned long long g_f3dg_counts[64][8];
 
 // ---- optional phase timing (build with -DF3DG_TIMING: tools/render_timing.py). Shader-clock cycles per wave, summed over all
 // waves of all launches since the last reset: [0] barrier waits, [1] staging, [2] list build, [3] phase 1, [4] phase 2,
@@ -866,7 +876,7 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 // e + 32 share entry e and split the quadrant's rows: half_ballots), and phase 2 runs until the now-older half is finished by
 // everybody, pixels that are through with it already working on the newer half. Same LDS (4 KB of records), same phase-1 cost per
 // entry; the model gives 0.64 (15 % fewer phase-2 trips). Per pixel the sequence of blended entries is unchanged.
-template <bool SAVE_AUX, bool FAST, int OCC, int WPB, bool NORMAL = true, bool DIST = true>
+template <bool SAVE_AUX, bool FAST, int OCC, int WPB, bool NORMAL = true, bool DIST = true, bool COUNT = false>
 __global__ void __launch_bounds__(64 * WPB, OCC)
 render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                     const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
@@ -925,6 +935,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         }
     };
 
+    unsigned n_staged = 0, n_trips = 0, n_wave_trips = 0, n_slides = 0;    // COUNT (option render_count): what this wave did, summed into g_f3dg_counts at its end
     unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
     unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
     unsigned long long pass = 0ull;               // per pixel: bits 0..31 older half, 32..63 newer half, in list order
@@ -976,6 +987,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         if (hl < m) ec = sR[3][base + hl].w;
         qhead += m;
         qpend -= m;
+        if (COUNT) { n_staged += m; n_slides++; }
 #if F3DG_R3S_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1006,9 +1018,11 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         // ---- phase 2: until every live pixel has finished the older half; pixels that have go on with the newer one
         // (a divergent loop: a pixel leaves it when its mask is empty -- it has nothing left in either half -- and the ballot, taken
         // over the pixels still inside, ends it for everybody once no older-half bit is left)
+        const unsigned trips_before = n_trips;
         while (pass != 0ull && __ballot((unsigned)pass != 0u) != 0ull) {
             const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
             pass &= pass - 1;
+            if (COUNT) n_trips++;
             const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
             F3DG_FULL16(q2, q3);
             const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
@@ -1026,10 +1040,30 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
 #if F3DG_R3S_BREAK
         if (done) pass = 0ull;
 #endif
+        if (COUNT) {                // the loop ran as often as its busiest lane needed (lanes leave it, none re-enters)
+            unsigned t = n_trips - trips_before;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o, 64));
+            n_wave_trips += t;
+        }
         if (__ballot(!done) == 0ull)
             break;
     }
     translate(2u);
+    if (COUNT && lane == 0) {
+        unsigned long long* c = g_f3dg_counts[blockIdx.x & 63u];
+        atomicAdd(&c[0], (unsigned long long)n_staged);
+        atomicAdd(&c[1], (unsigned long long)(cursor < n ? cursor : n));
+        atomicAdd(&c[2], (unsigned long long)n_wave_trips);
+        atomicAdd(&c[3], (unsigned long long)n_slides);
+        atomicAdd(&c[5], 1ull);
+    }
+    if (COUNT) {
+        unsigned t = n_trips;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += (unsigned)__shfl_xor((int)t, o, 64);
+        if (lane == 0) atomicAdd(&g_f3dg_counts[blockIdx.x & 63u][4], (unsigned long long)t);
+    }
 
     if (inside) {
         const float* bg = background + (bg_per_view ? 3 * view : 0);
@@ -1235,6 +1269,15 @@ render3l_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
 
 } // namespace
 
+namespace {
+char g_kernel_name[160] = "";
+void note_kernel(const char* base, int save_aux, int fast, const char* extra)
+{
+    snprintf(g_kernel_name, sizeof g_kernel_name, "%s<SAVE_AUX=%s, FAST=%s%s>", base, save_aux ? "true" : "false", fast ? "true" : "false", extra);
+    g_f3dg_last_render_kernel = g_kernel_name;
+}
+} // namespace
+
 int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f3dg_render_fast == 1 && !save_aux); }
 
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
@@ -1264,6 +1307,7 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
             if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3L(true, true); else F3DG_LAUNCH3L(true, false); }
             else { if (g_f3dg_render_fast) F3DG_LAUNCH3L(false, true); else F3DG_LAUNCH3L(false, false); }
 #undef F3DG_LAUNCH3L
+            note_kernel("render3l_fwd_kernel", save_aux, g_f3dg_render_fast, "");
             F3DG_HIP_CHECK(hipGetLastError());
             return F3DG_OK;
         }
@@ -1279,11 +1323,21 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
                               g_f3dg_render_wpb == 1;
 #define F3DG_LAUNCH3S_LEAN(FST) F3DG_KLAUNCH((render3s_fwd_kernel<false, FST, 8, 1, false, false>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
                           focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib)
-            if (lean) { if (g_f3dg_render_fast) F3DG_LAUNCH3S_LEAN(true); else F3DG_LAUNCH3S_LEAN(false); }
+            if (g_f3dg_render_count && !save_aux && g_f3dg_render_wpb == 1) {      // (diagnostic: the same kernel with its work counters on)
+                if (g_f3dg_render_fast) F3DG_KLAUNCH((render3s_fwd_kernel<false, true, 8, 1, true, true, true>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y,
+                                                     hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib);
+                else F3DG_KLAUNCH((render3s_fwd_kernel<false, false, 8, 1, true, true, true>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y,
+                                  hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib);
+                note_kernel("render3s_fwd_kernel", 0, g_f3dg_render_fast, ", OCC=8, WPB=1, COUNT=true");
+            } else
+            if (lean) { if (g_f3dg_render_fast) F3DG_LAUNCH3S_LEAN(true); else F3DG_LAUNCH3S_LEAN(false);
+                        note_kernel("render3s_fwd_kernel", 0, g_f3dg_render_fast, ", OCC=8, WPB=1, NORMAL=false, DIST=false"); }
             else if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3S(true, true, 8); else F3DG_LAUNCH3S(true, false, 8); }
             else { if (g_f3dg_render_fast) F3DG_LAUNCH3S(false, true, 8); else F3DG_LAUNCH3S(false, false, 8); }
 #undef F3DG_LAUNCH3S_LEAN
 #undef F3DG_LAUNCH3S
+            if (!lean && !(g_f3dg_render_count && !save_aux && g_f3dg_render_wpb == 1))
+                note_kernel("render3s_fwd_kernel", save_aux, g_f3dg_render_fast, g_f3dg_render_wpb == 4 ? ", OCC=8, WPB=4" : ", OCC=8, WPB=1");
             F3DG_HIP_CHECK(hipGetLastError());
             return F3DG_OK;
         }
@@ -1291,6 +1345,7 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
         else { if (g_f3dg_render_fast) F3DG_LAUNCH3(false, true, 8); else F3DG_LAUNCH3(false, false, 8); }
 #undef F3DG_LAUNCH3
 #undef F3DG_LAUNCH3D
+        note_kernel("render3_fwd_kernel", save_aux, g_f3dg_render_fast, g_f3dg_render_dma ? ", DMA=true, OCC=8" : ", DMA=false, OCC=8");
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
     }
@@ -1305,6 +1360,7 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
         else { if (g_f3dg_render_fast) F3DG_LAUNCH2(false, true); else F3DG_LAUNCH2(false, false); }
 #undef F3DG_LAUNCH2R
 #undef F3DG_LAUNCH2
+        note_kernel("render2_fwd_kernel", save_aux, g_f3dg_render_fast, "");
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
     }
@@ -1326,9 +1382,32 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     }
 #undef F3DG_LAUNCH_Q
 #undef F3DG_LAUNCH
+    note_kernel("render_fwd_kernel", save_aux, g_f3dg_render_fast, "");
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
+
+// debug: the work counters of the counting variant of the one-wave kernel (option render_count = 1), summed over all launches since
+// the last reset: h_out8 = { staged, scanned, wave trips, slides, lane-trips, waves, 0, 0 }
+extern "C" int f3dg_debug_render_counts(unsigned long long* h_out8, int reset)
+{
+    unsigned long long rows[64][8];
+    F3DG_HIP_CHECK(hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_f3dg_counts), sizeof rows));
+    if (h_out8)
+        for (int k = 0; k < 8; k++) {
+            h_out8[k] = 0;
+            for (int r = 0; r < 64; r++) h_out8[k] += rows[r][k];
+        }
+    if (reset) {
+        memset(rows, 0, sizeof rows);
+        F3DG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_f3dg_counts), rows, sizeof rows));
+    }
+    return F3DG_OK;
+}
+
+// the compositing forward kernel the last f3dg_launch_render of this process launched (what `roofline.kernel` of bench.py prints)
+const char* g_f3dg_last_render_kernel = "";
+extern "C" const char* f3dg_debug_last_render_kernel(void) { return g_f3dg_last_render_kernel; }
 
 // debug: read (and optionally reset) the phase-timing counters of a -DF3DG_TIMING build (zeros otherwise)
 extern "C" int f3dg_debug_timing(unsigned long long* h_out8, int reset)

@@ -347,6 +347,13 @@ int f3dg_debug_launch_times(int reset);
  * doubles: [3] and [4] are the compositing backward and the per-Gaussian backward of the f3dg_backward calls in between. */
 int f3dg_profile_enable(int on);
 int f3dg_profile_collect(double* h_stage_ms, int* h_calls);
+/* The same, plus the three forward stage times of every recorded call in call order: h_per_call[max_calls][3] (may be NULL). */
+int f3dg_profile_collect_calls(double* h_stage_ms, int* h_calls, double* h_per_call, int max_calls);
+/* Diagnostics of the compositing forward: the kernel (with its template arguments) the last launch of this process used, and -- with
+ * f3dg_set_option("render_count", 1), which swaps in a counting variant of the one-wave kernel -- its work counters summed over the
+ * launches since the last reset: h_out8 = { list entries staged, list entries scanned, phase-2 trips, slides, lane-trips, waves }. */
+const char* f3dg_debug_last_render_kernel(void);
+int f3dg_debug_render_counts(unsigned long long* h_out8, int reset);
 
 /* BLOCKING: number of contributing (pixel, Gaussian) pairs the last f3dg_backward on this workspace blended back through --
  * "C" of the byte formula 80 R + 60 W H + 68 C of the compositing backward. */

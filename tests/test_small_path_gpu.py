@@ -45,6 +45,9 @@ CASES = {
     # image rows, so ALL hits of a tile come from one or two of the sixteen waves; round 3's per-wave limit overflowed on it)
     "pixel_ordered": dict(P=65536, res=(256, 256), s0=0.01, view="oblique", pixel_ordered=True),
     "pixel_ordered_canonical": dict(P=65536, res=(256, 256), s0=0.012, view="canonical", pixel_ordered=True),
+    # long lists, just below a slot (reference lists: mean ~2,200 / max ~3,300 entries per tile): the per-tile LDS sort and the
+    # compositing kernel of small launches (render3l) at their limit, checked against the ORACLE directly (tile_cull 0)
+    "long_lists": dict(P=65536, res=(256, 256), s0=0.025, view="oblique"),
 }
 
 
@@ -66,7 +69,7 @@ def test_small_path_equals_general_path(name, tile_cull, gpu_device):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
     assert np.array_equal(a[3], b[3]), "lists differ"
     assert np.array_equal(a[4], b[4]), "ranges differ"
-    if name in ("one_view", "pixel_ordered") and tile_cull == 0:
+    if name in ("one_view", "pixel_ordered", "long_lists") and tile_cull == 0:
         o = run_oracle(scene)
         assert a[2] == o["num_rendered"] and np.array_equal(a[3].view(np.uint32), o["point_list"])
         assert_render_parity(a[0][0].cpu().numpy(), o["out_color"], "small path")

@@ -1,0 +1,90 @@
+"""One pass of the SongUNet backbone (reference src/gaussian_predictor.py:137-511; this build's f3d-gaus_amd/gaussian_predictor.py) under
+torch.profiler: device time per (operator, input shapes) with the FLOPs torch derives from the shapes, i.e. achieved TFLOP/s of the
+convolutions and matrix products that make up the pass, plus the GPU kernels behind the five most expensive ones.
+
+  python tools/prof_unet.py B mode       B = images per pass; mode = fp32 | bf16 (the opt-in autocast option) | bf16_resident
+                                         (the same with the convolution weights held in bfloat16: no per-call cast kernels)
+Prints a markdown section (profiles/r04_final/unet.md is assembled from these runs)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import f3dgaus_amd as f3d  # noqa: E402
+from f3dgaus_amd import cameras, gaussian_predictor as gp  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+dev = torch.device("cuda:0")
+cfg = cameras.default_cfg(256)
+torch.manual_seed(0)
+torch.backends.cudnn.benchmark = True
+pred = f3d.GaussianSplatPredictor_gtunet(cfg).to(dev).eval()
+x = torch.rand(B, 4, 256, 256, device=dev)
+
+if mode == "bf16_resident":
+    # experiment: every convolution weight / bias cast ONCE (Conv2d.forward casts `self.weight.to(x.dtype)` per call; under autocast
+    # the cast is cached per autocast region, i.e. repeated every pass)
+    for m in pred.modules():
+        if isinstance(m, gp.Conv2d) and m.weight is not None:
+            m.weight.data = m.weight.data.to(torch.bfloat16)
+            m.bias.data = m.bias.data.to(torch.bfloat16)
+
+
+def run():
+    with torch.no_grad():
+        if mode.startswith("bf16"):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return pred.network_with_offset(x)
+        return pred.network_with_offset(x)
+
+
+for _ in range(3):
+    y = run()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    y = run()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 3 * 1e3
+
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_flops=True) as prof:
+    run()
+    torch.cuda.synchronize()
+ka = prof.key_averages(group_by_input_shape=True)
+dt = lambda e: getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)
+rows = sorted((e for e in ka if dt(e) > 0), key=dt, reverse=True)
+total_us = sum(dt(e) for e in rows)
+print(f"### {B} images, {mode}: {ms:.1f} ms per pass (wall, 3 passes), {total_us / 1e3:.1f} ms of device time in {len(rows)} (operator, shape) groups\n")
+print("| operator | input shapes | calls | device ms | % | GFLOP | TFLOP/s |")
+print("|---|---|---:|---:|---:|---:|---:|")
+for e in rows[:14]:
+    fl = e.flops or 0
+    shapes = str(e.input_shapes)[:90]
+    print(f"| `{e.key}` | {shapes} | {e.count} | {dt(e) / 1e3:.3f} | {100 * dt(e) / total_us:.1f} | {fl / 1e9:.1f} | "
+          f"{(fl / (dt(e) * 1e-6) / 1e12) if fl else 0:.1f} |")
+conv_us = sum(dt(e) for e in rows if "conv" in e.key)
+conv_fl = sum((e.flops or 0) for e in rows if "conv" in e.key)
+mm_us = sum(dt(e) for e in rows if e.key in ("aten::bmm", "aten::mm", "aten::addmm", "aten::matmul", "aten::_scaled_dot_product_flash_attention", "aten::_scaled_dot_product_efficient_attention"))
+cast_us = sum(dt(e) for e in rows if e.key in ("aten::_to_copy", "aten::copy_", "aten::to"))
+gn_us = total_us - conv_us - mm_us - cast_us
+print(f"\nconvolutions: {conv_us / 1e3:.1f} ms, {conv_fl / 1e12:.2f} TFLOP -> {conv_fl / max(conv_us, 1) / 1e6:.1f} TFLOP/s overall; matrix products / attention "
+      f"{mm_us / 1e3:.2f} ms; dtype casts / copies {cast_us / 1e3:.2f} ms; everything else (GroupNorm+SiLU kernel, resampling, adds) {gn_us / 1e3:.2f} ms\n")
+# kernels behind the device time
+kern = {}
+for ev in prof.events():
+    if getattr(ev, "device_type", None) is not None and "cuda" in str(ev.device_type).lower() or str(getattr(ev, "device_type", "")).endswith("CUDA"):
+        kern.setdefault(ev.name, [0, 0.0])
+        kern[ev.name][0] += 1
+        kern[ev.name][1] += getattr(ev, "device_time", 0) or getattr(ev, "cuda_time", 0) or 0
+top = sorted(kern.items(), key=lambda kv: kv[1][1], reverse=True)[:8]
+if top and top[0][1][1] > 0:
+    print("| GPU kernel | launches | ms |")
+    print("|---|---:|---:|")
+    for name, (n, us) in top:
+        print(f"| `{name[:110]}` | {n} | {us / 1e3:.3f} |")
+    print()
