@@ -375,7 +375,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     counts = None
     if True:        # (every rank: at N > 1 a step ends in the collective gather)
         _lib.check(L.f3dg_set_option(b"render_count", 1), "f3dg_set_option")
-        cbuf = (C.c_ulonglong * 8)()
+        cbuf = (C.c_ulonglong * 16)()
         L.f3dg_debug_render_counts(cbuf, 1)
         step()
         gat.barrier()
@@ -385,6 +385,8 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
             counts = {"list_entries_staged": int(cbuf[0]), "list_entries_scanned": int(cbuf[1]), "phase2_wave_trips": int(cbuf[2]),
                       "slides": int(cbuf[3]), "phase2_lane_trips": int(cbuf[4]), "waves": int(cbuf[5]),
                       "phase2_lane_utilisation": cbuf[4] / (64.0 * cbuf[2]) if cbuf[2] else None,
+                      "phase2_trips_of_slides_with_at_most_8_live_pixels": int(cbuf[6]), "..._at_most_24": int(cbuf[7]),
+                      "slides_with_at_most_8_live_pixels": int(cbuf[8]), "slides_with_at_most_24": int(cbuf[9]),
                       "note": "one untimed step with option render_count = 1 (the same kernel with work counters); staged entries count "
                               "a list entry once per quadrant wave that gathers its record"}
 

@@ -442,8 +442,9 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 
 // Work counters of the one-wave kernel (option render_count = 1; f3dg_debug_render_counts): [0] list entries staged (record gathers),
 // [1] list entries scanned, [2] phase-2 trips (wave iterations), [3] slides, [4] lane-trips = (pixel, entry) pairs that entered phase 2
-// ([4] / (64 [2]) = lane utilisation of phase 2), [5] waves. 64 rows against atomic contention; summed on the host.
-__device__ unsigned long long g_f3dg_counts[64][8];
+// ([4] / (64 [2]) = lane utilisation of phase 2), [5] waves, [6] / [7] the trips of slides that began with at most 8 / at most 24 of the
+// quadrant's 64 pixels still unsaturated, [8] / [9] those slides. 64 rows against atomic contention; summed on the host.
+__device__ unsigned long long g_f3dg_counts[64][16];
 
 // ---- optional phase timing (build with -DF3DG_TIMING: tools/render_timing.py). Shader-clock cycles per wave, summed over all
 // waves of all launches since the last reset: [0] barrier waits, [1] staging, [2] list build, [3] phase 1, [4] phase 2,
@@ -935,7 +936,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         }
     };
 
-    unsigned n_staged = 0, n_trips = 0, n_wave_trips = 0, n_slides = 0;    // COUNT (option render_count): what this wave did, summed into g_f3dg_counts at its end
+    unsigned n_staged = 0, n_trips = 0, n_wave_trips = 0, n_slides = 0, n_t8 = 0, n_t24 = 0, n_s8 = 0, n_s24 = 0;    // COUNT (option render_count): what this wave did, summed into g_f3dg_counts at its end
     unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
     unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
     unsigned long long pass = 0ull;               // per pixel: bits 0..31 older half, 32..63 newer half, in list order
@@ -1019,6 +1020,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         // (a divergent loop: a pixel leaves it when its mask is empty -- it has nothing left in either half -- and the ballot, taken
         // over the pixels still inside, ends it for everybody once no older-half bit is left)
         const unsigned trips_before = n_trips;
+        const unsigned live_now = COUNT ? (unsigned)__popcll(__ballot(!done)) : 0u;
         while (pass != 0ull && __ballot((unsigned)pass != 0u) != 0ull) {
             const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
             pass &= pass - 1;
@@ -1045,6 +1047,8 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o, 64));
             n_wave_trips += t;
+            if (live_now <= 8u) { n_t8 += t; n_s8++; }
+            if (live_now <= 24u) { n_t24 += t; n_s24++; }
         }
         if (__ballot(!done) == 0ull)
             break;
@@ -1057,6 +1061,10 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         atomicAdd(&c[2], (unsigned long long)n_wave_trips);
         atomicAdd(&c[3], (unsigned long long)n_slides);
         atomicAdd(&c[5], 1ull);
+        atomicAdd(&c[6], (unsigned long long)n_t8);
+        atomicAdd(&c[7], (unsigned long long)n_t24);
+        atomicAdd(&c[8], (unsigned long long)n_s8);
+        atomicAdd(&c[9], (unsigned long long)n_s24);
     }
     if (COUNT) {
         unsigned t = n_trips;
@@ -1388,13 +1396,13 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
 }
 
 // debug: the work counters of the counting variant of the one-wave kernel (option render_count = 1), summed over all launches since
-// the last reset: h_out8 = { staged, scanned, wave trips, slides, lane-trips, waves, 0, 0 }
+// the last reset: h_out8[16] = { staged, scanned, wave trips, slides, lane-trips, waves, trips with <= 8 / <= 24 live pixels, slides with <= 8 / <= 24, 0... }
 extern "C" int f3dg_debug_render_counts(unsigned long long* h_out8, int reset)
 {
-    unsigned long long rows[64][8];
+    unsigned long long rows[64][16];
     F3DG_HIP_CHECK(hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_f3dg_counts), sizeof rows));
     if (h_out8)
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 16; k++) {
             h_out8[k] = 0;
             for (int r = 0; r < 64; r++) h_out8[k] += rows[r][k];
         }

@@ -351,7 +351,8 @@ int f3dg_profile_collect(double* h_stage_ms, int* h_calls);
 int f3dg_profile_collect_calls(double* h_stage_ms, int* h_calls, double* h_per_call, int max_calls);
 /* Diagnostics of the compositing forward: the kernel (with its template arguments) the last launch of this process used, and -- with
  * f3dg_set_option("render_count", 1), which swaps in a counting variant of the one-wave kernel -- its work counters summed over the
- * launches since the last reset: h_out8 = { list entries staged, list entries scanned, phase-2 trips, slides, lane-trips, waves }. */
+ * launches since the last reset: h_out8[SIXTEEN] = { list entries staged, list entries scanned, phase-2 trips, slides, lane-trips, waves,
+ * trips of slides that began with <= 8 / <= 24 live pixels, those slides, 0 ... }. */
 const char* f3dg_debug_last_render_kernel(void);
 int f3dg_debug_render_counts(unsigned long long* h_out8, int reset);
 

@@ -16,7 +16,21 @@ from helpers import make_scene, run_oracle
 
 NT = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 S0 = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
-sc = make_scene(P=196608, res=(256, 256), s0=S0, view="oblique")
+if os.environ.get("REAL"):
+    # the merged set of the real image (tests/real_data.py: needs a HIP device for the predictor and the cycle aggregation), one
+    # view of its final orbit: how do the schedules fare on pixel-aligned splats on a real depth map?
+    import torch
+    from f3dgaus_amd import synthetic
+    from real_data import real_merged_set
+    g = {k: v.cpu() for k, v in real_merged_set(torch.device("cuda:0")).items()}
+    cams = synthetic.orbit_cameras(128, resolution=256)
+    vi = int(os.environ.get("VIEW", "40"))
+    sc = dict(P=g["xyz"].shape[0], W=256, H=256, sh_degree=1, kernel_size=0.0, scale_modifier=1.0, tanfovx=cams["tanfovx"],
+              tanfovy=cams["tanfovy"], bg=torch.zeros(3), viewmatrix=cams["viewmatrix"][vi:vi + 1], projmatrix=cams["projmatrix"][vi:vi + 1],
+              campos=cams["campos"][vi:vi + 1], means3D=g["xyz"], opacities=g["opacity"], scales=g["scaling"], rotations=g["rotation"],
+              shs=torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous(), colors_precomp=None)
+else:
+    sc = make_scene(P=196608, res=(256, 256), s0=S0, view="oblique")
 o = run_oracle(sc)
 W = H = 256
 f32 = np.float32
@@ -131,7 +145,7 @@ for tile in tiles:
                 t["lost_block"] += mx * 64 - bm
 
         # sliding window: 64 entries resident, slides by STEP when every lane has consumed the oldest STEP entries
-        for STEP, RES in ((32, 64), (16, 64), (32, 96), (32, 128), (64, 128), (32, 1 << 20)):
+        for STEP, RES in ((32, 64), (16, 64), (32, 96), (32, 128), (64, 128), (32, 256), (32, 512), (32, 1 << 20)):
             key = ("slide", STEP, RES)
             t = tot.setdefault(key, dict(trips=0, staged=0, slides=0))
             if len(lst) == 0:
@@ -161,7 +175,7 @@ print("tiles %d  tile entries/view %.3g  quadrant entries/view %.3g (x%.2f)  pha
 ideal = pairs_total / 64.0
 t = tot["r2"]
 print("render2 shape: staged %.3g/view, trips %.3g, lane utilisation %.3f" % (t["staged"] * scale, t["trips"] * scale, ideal / t["trips"]))
-for STEP, RES in ((32, 64), (16, 64), (32, 96), (32, 128), (64, 128), (32, 1 << 20)):
+for STEP, RES in ((32, 64), (16, 64), (32, 96), (32, 128), (64, 128), (32, 256), (32, 512), (32, 1 << 20)):
     t = tot[("slide", STEP, RES)]
     print("one wave, %d resident entries sliding by %d: staged %.3g/view, trips %.3g, lane utilisation %.3f, slides %.3g" %
           (RES, STEP, t["staged"] * scale, t["trips"] * scale, ideal / t["trips"], t["slides"] * scale))

@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--mode", default="fast")
 ap.add_argument("--label", default="")
 ap.add_argument("--pixel-ordered", action="store_true")
+ap.add_argument("--real", action="store_true", help="the merged set of the real image (tests/real_data.py), 589,824 Gaussians")
 a = ap.parse_args()
 L = _lib.lib()
 dev = torch.device("cuda:0")
@@ -34,7 +35,12 @@ for k, v in os.environ.items():
         _lib.check(L.f3dg_set_option(k[9:].lower().encode(), int(v)), "f3dg_set_option " + k)
 L.f3dg_set_option(b"render_fast", 1 if a.mode == "fast" else 0)
 P, V, RES = a.gaussians, a.views, a.res
-g = synthetic.make_pixel_gaussians(RES, s0=a.sigma0, device=dev) if a.pixel_ordered else synthetic.make_gaussians(P, s0=a.sigma0, seed=0, device=dev)
+if a.real:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from real_data import real_merged_set
+    g = real_merged_set(dev)
+else:
+    g = synthetic.make_pixel_gaussians(RES, s0=a.sigma0, device=dev) if a.pixel_ordered else synthetic.make_gaussians(P, s0=a.sigma0, seed=0, device=dev)
 P = g["xyz"].shape[0]
 cams = synthetic.orbit_cameras(V, resolution=RES, device=dev)
 shs = torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous()
