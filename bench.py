@@ -155,7 +155,7 @@ def main():
         _lib.check(L.f3dg_set_option(b"render_round", int(os.environ["F3DG_RENDER_ROUND"])), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
-    for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad"), ("F3DG_BWD_OCC", b"bwd_occ"), ("F3DG_RENDER_SLIDE", b"render_slide"), ("F3DG_RENDER_LOWOCC", b"render_lowocc"), ("F3DG_SMALL_DEBUG", b"small_debug")):     # A/B switches of render3
+    for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad"), ("F3DG_BWD_OCC", b"bwd_occ"), ("F3DG_RENDER_SLIDE", b"render_slide"), ("F3DG_RENDER_LOWOCC", b"render_lowocc"), ("F3DG_RENDER_TAIL", b"render_tail"), ("F3DG_SMALL_DEBUG", b"small_debug")):     # A/B switches of render3
         if os.environ.get(env):
             _lib.check(L.f3dg_set_option(opt, int(os.environ[env])), "f3dg_set_option")
     _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
@@ -387,6 +387,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                       "phase2_lane_utilisation": cbuf[4] / (64.0 * cbuf[2]) if cbuf[2] else None,
                       "phase2_trips_of_slides_with_at_most_8_live_pixels": int(cbuf[6]), "..._at_most_24": int(cbuf[7]),
                       "slides_with_at_most_8_live_pixels": int(cbuf[8]), "slides_with_at_most_24": int(cbuf[9]),
+                      "tail_steps": int(cbuf[10]), "tail_wave_trips": int(cbuf[11]), "tail_entries_tested": int(cbuf[12]),
                       "note": "one untimed step with option render_count = 1 (the same kernel with work counters); staged entries count "
                               "a list entry once per quadrant wave that gathers its record"}
 

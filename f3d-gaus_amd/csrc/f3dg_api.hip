@@ -120,12 +120,15 @@ int g_f3dg_render_kernel = 3;
 int g_f3dg_render_dma = 1;
 int g_f3dg_render_wpb = 1;
 int g_f3dg_render_count = 0;
+#define F3DG_RENDER_TAIL_DEFAULT 0
+int g_f3dg_render_tail = F3DG_RENDER_TAIL_DEFAULT;
 int g_f3dg_render_slide = 1;
 int g_f3dg_render_lowocc = 1;
 int g_f3dg_render_lds_pad = 0;
 int g_f3dg_bwd_occ = 5;
 int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
+int g_f3dg_sort_fused_rects = 0;
 int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
@@ -142,12 +145,14 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_count") == 0) { g_f3dg_render_count = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_tail") == 0) { g_f3dg_render_tail = value < 0 ? F3DG_RENDER_TAIL_DEFAULT : value > 64 ? 64 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_wpb") == 0) { g_f3dg_render_wpb = value == 4 ? 4 : 1; return F3DG_OK; }
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "sort_fused_rects") == 0) { g_f3dg_sort_fused_rects = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
     return F3DG_ERR_BAD_ARG;
@@ -275,7 +280,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.offsets = take(VP * sizeof(unsigned));
     L.clamped = take(VP);
     L.rects = take(VP * sizeof(uint2));
-    L.gsort = take(4 * VP * sizeof(unsigned));
+    L.gsort = take(7 * VP * sizeof(unsigned));
     L.scan_tmp = take((size_t)L.scan_tmp_elems * sizeof(unsigned));
     L.keys[0] = take(C * 8);
     L.keys[1] = take(C * 4);

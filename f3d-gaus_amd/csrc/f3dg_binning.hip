@@ -242,11 +242,24 @@ struct ScatterShared {
     u32 sval[F3DG_SORT_CHUNK];
 };
 
+// What a view's LAST depth pass adds (option sort_fused_rects, the default): the element's payload is a Gaussian id and its final
+// position is known, so the pass also fetches that Gaussian's tile rectangle and writes it -- and its area = tiles touched, the input
+// of the prefix sum that places the instances -- at the sorted position. This is the one random gather of the path (an 8-byte read
+// per 128-byte line, from the view's 8 P bytes in its XCD's L2); inside the pass it flies behind the other chunks' LDS work of the CU
+// instead of being a launch of its own that reads the order back.
+struct RectSink {
+    const uint2* rects;     // the segment's rectangles, id-indexed
+    u32* tiles;             // [V P] sorted order
+    u32* rx;
+    u32* ry;
+};
+
 // IOTA: the payload of the input is its position inside the segment (first pass of the depth sort)
-template <typename K, bool IOTA, typename DIGIT>
+template <typename K, bool IOTA, typename DIGIT, bool RECTS = false>
 __device__ __forceinline__ void scatter_chunk(const K* __restrict__ keys_in, const u32* __restrict__ vals_in, K* __restrict__ keys_out,
                                               u32* __restrict__ vals_out, const SegChunk& ck, const DIGIT digit,
-                                              const u32* __restrict__ offsets /* exclusive scan of hist */, ScatterShared& sh, K* skey)
+                                              const u32* __restrict__ offsets /* exclusive scan of hist */, ScatterShared& sh, K* skey,
+                                              const RectSink sink = RectSink{nullptr, nullptr, nullptr, nullptr})
 {
     // the chunk is digit-sorted inside LDS (stable), then written out in coalesced runs
     const u32 n = ck.n;
@@ -325,6 +338,34 @@ __device__ __forceinline__ void scatter_chunk(const K* __restrict__ keys_in, con
         }
     }
     __syncthreads();
+    if constexpr (RECTS) {
+        constexpr int GI = 4;                         // gathers in flight per thread
+        for (u32 s0 = threadIdx.x; s0 < in_block; s0 += GI * F3DG_BLOCK) {
+            u32 pos[GI], id[GI];
+            uint2 r[GI];
+#pragma unroll
+            for (int g = 0; g < GI; g++) {
+                const u32 slot = s0 + (u32)g * F3DG_BLOCK;
+                const bool ok = slot < in_block;
+                id[g] = ok ? sh.sval[slot] : 0u;
+                pos[g] = ok ? sh.gdelta[digit((u32)skey[ok ? slot : 0u])] + slot : 0u;
+            }
+#pragma unroll
+            for (int g = 0; g < GI; g++)
+                r[g] = s0 + (u32)g * F3DG_BLOCK < in_block ? sink.rects[id[g]] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int g = 0; g < GI; g++) {
+                if (s0 + (u32)g * F3DG_BLOCK < in_block) {
+                    vals_out[pos[g]] = id[g];
+                    sink.tiles[pos[g]] = (((r[g].x >> 16) & F3DG_RECT_COORD) - (r[g].x & F3DG_RECT_COORD)) *
+                                         (((r[g].y >> 16) & F3DG_RECT_COORD) - (r[g].y & F3DG_RECT_COORD));
+                    sink.rx[pos[g]] = r[g].x;
+                    sink.ry[pos[g]] = r[g].y;
+                }
+            }
+        }
+        return;
+    }
     for (u32 slot = threadIdx.x; slot < in_block; slot += F3DG_BLOCK) {
         const K k = skey[slot];
         const u32 d = digit((u32)k);
@@ -434,14 +475,16 @@ gsort_range_kernel(u32 cps, const u32* __restrict__ chunk_minmax, u32* __restric
     if (threadIdx.x == 0) { minmax[2 * blockIdx.x] = kmin; minmax[2 * blockIdx.x + 1] = kmax; }
 }
 
-template <int PASS>
+template <int PASS, bool RECTS = false>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 gsort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, u32* __restrict__ keys_out,
-                     u32* __restrict__ vals_out, u32 seg_len, u32 cps, const u32* __restrict__ offsets, const u32* __restrict__ minmax)
+                     u32* __restrict__ vals_out, u32 seg_len, u32 cps, const u32* __restrict__ offsets, const u32* __restrict__ minmax,
+                     RectSink sink)
 {
     __shared__ ScatterShared sh;
     __shared__ u32 skey[F3DG_SORT_CHUNK];
     const SegChunk ck = fixed_chunk(seg_len, cps);
+    sink.rects += ck.seg_base;
     if constexpr (PASS == 0) {           // the payload of the input is its position inside the segment
         scatter_chunk<u32, true, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{0}, offsets, sh, skey);
     } else if constexpr (PASS == 1) {
@@ -450,10 +493,17 @@ gsort_scatter_kernel(const u32* __restrict__ keys_in, const u32* __restrict__ va
         u32 kbase;
         const bool compact = gsort_compact(minmax, ck.seg, kbase);
         // (the keys are not read again after a view's LAST pass -- pass 2 of a compact view, pass 3 otherwise --: it does not write them)
-        if (!compact)
-            scatter_chunk<u32, false, ShiftDigit>(keys_in, vals_in, PASS == 3 ? (u32*)nullptr : keys_out, vals_out, ck, ShiftDigit{8 * PASS}, offsets, sh, skey);
-        else if constexpr (PASS == 2)
-            scatter_chunk<u32, false, CompactDigit>(keys_in, vals_in, (u32*)nullptr, vals_out, ck, CompactDigit{kbase}, offsets, sh, skey);
+        if (!compact) {
+            if constexpr (PASS == 3 && RECTS)
+                scatter_chunk<u32, false, ShiftDigit, true>(keys_in, vals_in, (u32*)nullptr, vals_out, ck, ShiftDigit{8 * PASS}, offsets, sh, skey, sink);
+            else
+                scatter_chunk<u32, false, ShiftDigit>(keys_in, vals_in, PASS == 3 ? (u32*)nullptr : keys_out, vals_out, ck, ShiftDigit{8 * PASS}, offsets, sh, skey);
+        } else if constexpr (PASS == 2) {
+            if constexpr (RECTS)
+                scatter_chunk<u32, false, CompactDigit, true>(keys_in, vals_in, (u32*)nullptr, vals_out, ck, CompactDigit{kbase}, offsets, sh, skey, sink);
+            else
+                scatter_chunk<u32, false, CompactDigit>(keys_in, vals_in, (u32*)nullptr, vals_out, ck, CompactDigit{kbase}, offsets, sh, skey);
+        }
     }
 }
 
@@ -617,7 +667,8 @@ gsort_gather_rects_kernel(int P, u32* __restrict__ gv0, u32* __restrict__ gv1, c
 template <typename G>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict__ gv0, const u32* __restrict__ gv1,
-                        const u32* __restrict__ minmax, const u32* __restrict__ rx, const u32* __restrict__ offsets_sorted,
+                        const u32* __restrict__ minmax, const u32* __restrict__ rx, const u32* __restrict__ ry_fused /* null: the view's spare order buffer */,
+                        const u32* __restrict__ offsets_sorted,
                         const F3dgHeader* __restrict__ hdr, G* __restrict__ kgrp, u32* __restrict__ vals)
 {
     __shared__ G sk[F3DG_DUP_CAP];
@@ -628,7 +679,7 @@ duplicate_sorted_kernel(int P, int tile_bits, int grid_x, const u32* __restrict_
     u32 kbase;
     const bool pass2 = gsort_compact(minmax, (u32)v, kbase);      // as in gsort_gather_rects_kernel
     const u32* perm = pass2 ? gv1 : gv0;
-    const u32* ry = pass2 ? gv0 : gv1;
+    const u32* ry = ry_fused ? ry_fused : pass2 ? gv0 : gv1;
     // output range of the workgroup
     const size_t first = (size_t)v * P + (size_t)blockIdx.x * F3DG_BLOCK;
     const int in_block = min(F3DG_BLOCK, P - (int)(blockIdx.x * F3DG_BLOCK));
@@ -786,6 +837,10 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
     u32* minmax = reinterpret_cast<u32*>(ws + L.segtab) + L.segtab_minmax;
     u32* chunk_minmax = minmax + 2 * (size_t)V;
     const bool view_scan = cps <= 64;      // one workgroup per view (<= 4 rounds of 4096 entries) or the general three-kernel scan
+    // (sort_fused_rects: the last pass of a view also delivers its rectangles and tile counts in sorted order; see RectSink)
+    const bool fused = g_f3dg_sort_fused_rects != 0;
+    u32* const gx = reinterpret_cast<u32*>(ws + L.gsort) + 4 * VP;           // [3][V P]: tiles / prefix sum, rx, ry of the fused path
+    const RectSink sink{reinterpret_cast<const uint2*>(ws + L.rects), gx, gx + VP, gx + 2 * VP};
 #define F3DG_GSORT_PASS(PASS, IN, OUT)                                                                                                     \
     F3DG_KLAUNCH((gsort_hist_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], (u32)P, cps, hist, minmax, chunk_minmax); \
     if (view_scan)                                                                                                                         \
@@ -794,8 +849,12 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
         rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * gblocks, scan_tmp, L.scan_tmp_elems, 1, nullptr);        \
         if (rc != F3DG_OK) return rc;                                                                                                      \
     }                                                                                                                                      \
-    F3DG_KLAUNCH((gsort_scatter_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], gv[IN], gk[OUT], gv[OUT], (u32)P, cps, \
-                       hist, minmax)
+    if (fused && PASS >= 2)                                                                                                                \
+        F3DG_KLAUNCH((gsort_scatter_kernel<PASS, (PASS >= 2)>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], gv[IN], gk[OUT], gv[OUT], (u32)P, cps, \
+                     hist, minmax, sink);                                                                                                  \
+    else                                                                                                                                   \
+        F3DG_KLAUNCH((gsort_scatter_kernel<PASS>), dim3(gblocks), dim3(F3DG_BLOCK), 0, s, gk[IN], gv[IN], gk[OUT], gv[OUT], (u32)P, cps, \
+                     hist, minmax, sink)
     F3DG_GSORT_PASS(0, 0, 1);
     F3DG_GSORT_PASS(1, 1, 0);
     F3DG_KLAUNCH(gsort_range_kernel, dim3(V), dim3(64), 0, s, cps, chunk_minmax, minmax);
@@ -803,17 +862,18 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
     F3DG_GSORT_PASS(3, 1, 0);
 #undef F3DG_GSORT_PASS
     // a view's order (perm) is gv[1] after pass 2 if its key range is compact, gv[0] after pass 3 otherwise; the other one takes ry
-    u32* offsets_sorted = gk[1];          // tiles_touched in sorted order, then its inclusive prefix sum (in place)
-    u32* rx = gk[0];
+    u32* offsets_sorted = fused ? sink.tiles : gk[1];          // tiles_touched in sorted order, then its inclusive prefix sum (in place)
+    u32* rx = fused ? sink.rx : gk[0];
 
     // 2. instances in (view, depth, id) order
-    F3DG_KLAUNCH(gsort_gather_rects_kernel, dim3((unsigned)V * (unsigned)((P + 4 * F3DG_BLOCK - 1) / (4 * F3DG_BLOCK))), dim3(F3DG_BLOCK), 0, s, P, gv[0], gv[1], minmax,
-                       reinterpret_cast<const uint2*>(ws + L.rects), offsets_sorted, rx);
+    if (!fused)
+        F3DG_KLAUNCH(gsort_gather_rects_kernel, dim3((unsigned)V * (unsigned)((P + 4 * F3DG_BLOCK - 1) / (4 * F3DG_BLOCK))), dim3(F3DG_BLOCK), 0, s, P, gv[0], gv[1], minmax,
+                           reinterpret_cast<const uint2*>(ws + L.rects), offsets_sorted, rx);
     rc = f3dg_launch_scan_inclusive(s, offsets_sorted, offsets_sorted, (unsigned long long)VP, scan_tmp, L.scan_tmp_elems, 0, hdr);
     if (rc != F3DG_OK) return rc;
     const int passes = f3dg_sort_passes(V, T);
     int src = passes & 1;                                                      // so that the tile pass(es) end in half 0
-    F3DG_KLAUNCH((duplicate_sorted_kernel<G>), pgrid, dim3(F3DG_BLOCK), 0, s, P, tile_bits, grid_x, gv[0], gv[1], minmax, rx, offsets_sorted, hdr,
+    F3DG_KLAUNCH((duplicate_sorted_kernel<G>), pgrid, dim3(F3DG_BLOCK), 0, s, P, tile_bits, grid_x, gv[0], gv[1], minmax, rx, fused ? sink.ry : (u32*)nullptr, offsets_sorted, hdr,
                        kgrp[src], vals[src]);
 
     // 3. stable pass(es) over the tile bits inside every view's segment of the instance arrays: (view, tile, depth, id) order

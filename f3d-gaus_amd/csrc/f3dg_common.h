@@ -123,8 +123,8 @@ struct F3dgLayout {
     size_t offsets;        // [V*P] u32   inclusive scan of tiles_touched
     size_t clamped;        // [V*P] u8    bit c set when SH colour channel c was clamped
     size_t rects;          // [V*P] uint2: tile rectangle of every (view, Gaussian) (rminx | rmaxx << 16, rminy | rmaxy << 16)
-    size_t gsort;          // [4][V*P] u32: ping-pong (key, id) buffers of the per-view depth sort of the Gaussians; reused for the
-                           // tiles_touched / prefix sum in sorted order
+    size_t gsort;          // [7][V*P] u32: ping-pong (key, id) buffers of the per-view depth sort of the Gaussians ([0..3]; without
+                           // sort_fused_rects reused for the sorted tile counts and rectangles), [4..6] tile counts -> prefix sum, rx, ry in sorted order
     size_t scan_tmp;       // u32 block sums for the scans
     size_t keys[2];        // group stream (u16 / u32 per instance) of the two ping-pong halves, [cap] 4 B; [0] is [cap] 8 B: it also
                            // holds the rebuilt 64-bit keys of the debug export
@@ -222,6 +222,7 @@ int f3dg_launch_export_keys(hipStream_t s, int V, int P, int W, int H, const F3d
 
 extern int g_f3dg_render_pretest;      // 1 (default): conservative f32 pre-test enabled; 0: plain path (A/B, tests)
 extern int g_f3dg_render_cull;         // 1 (default): per-strip culling of the staged list by the conservative box
+extern int g_f3dg_sort_fused_rects;    // 1: a view's last depth pass also gathers its rectangles into sorted order (no gsort_gather_rects_kernel); 0 (default): measured equal
 extern int g_f3dg_sort_wide_groups;    // 0 (default): u16 group stream when it fits; 1: always u32 (tests)
 extern int g_f3dg_render_queue;        // 1 (default): two-phase loop with per-lane work queues
 extern int g_f3dg_render_kernel;       // 3 (default): render3 (one wave64 per 8x8 quadrant, no barriers); 2: render2 (four waves per tile,
@@ -232,6 +233,7 @@ extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is c
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
 extern int g_f3dg_render_lowocc;       // 1 (default): launches of at most 2048 quadrant waves take render3l_fwd_kernel (next window's gathers in flight)
 extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding half-window (render3s_fwd_kernel); 0: fixed 64-entry windows
+extern int g_f3dg_render_tail;         // N > 0: render3s switches a quadrant to the tail schedule once at most N of its pixels are unsaturated (0: never)
 extern int g_f3dg_render_count;        // 1: the one-wave kernel's counting variant (diagnostic; f3dg_debug_render_counts)
 extern int g_f3dg_render_wpb;          // quadrant waves per render3s workgroup: 1 (default) or 4 (a tile's four waves start together on one CU)
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)

@@ -877,13 +877,22 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 // e + 32 share entry e and split the quadrant's rows: half_ballots), and phase 2 runs until the now-older half is finished by
 // everybody, pixels that are through with it already working on the newer half. Same LDS (4 KB of records), same phase-1 cost per
 // entry; the model gives 0.64 (15 % fewer phase-2 trips). Per pixel the sequence of blended entries is unchanged.
-template <bool SAVE_AUX, bool FAST, int OCC, int WPB, bool NORMAL = true, bool DIST = true, bool COUNT = false>
+//
+// TAIL (option render_tail = N > 0): once at most N of the quadrant's 64 pixels are still unsaturated the wave changes its schedule for
+// the rest of the list. On pixel-aligned splats over a real depth map a quadrant's last few pixels (depth edges, thin coverage) never
+// saturate and walk the whole tile list; the sliding window then pays its fixed cost per 32 entries -- a record gather for every entry
+// and 32 two-pixel ballot steps for 64 pixels of which a handful are alive. The tail schedule takes 64 kept entries per step, one per
+// lane, gathers only their 20 bytes of ellipse, runs the ellipse test for the LIVE pixels only (a scalar loop over the set bits of the
+// live mask: the same two FMAs and comparison, the ballot written to the pixel's lane by v_writelane with the lane in M0), gathers the
+// records of the entries some live pixel passes (the OR of the ballots) and lets the live pixels walk their masks through the same
+// phase 2. Per pixel the sequence of blended entries and every operation on them is unchanged: bit-identical images.
+template <bool SAVE_AUX, bool FAST, int OCC, int WPB, bool NORMAL = true, bool DIST = true, bool COUNT = false, bool TAIL = false>
 __global__ void __launch_bounds__(64 * WPB, OCC)
 render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                     const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                     const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
                     const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
-                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib, int tail_n)
 {
     // WPB = 1: a workgroup is one quadrant's wave. WPB = 4 (option render_wpb): the four quadrant waves of a tile are one workgroup --
     // still no barrier and nothing shared, but they start together on one CU, so the records the second to fourth wave gather are
@@ -936,6 +945,8 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         }
     };
 
+    unsigned n_tail_steps = 0, n_tail_trips = 0, n_tail_tests = 0;
+    bool go_tail = false;
     unsigned n_staged = 0, n_trips = 0, n_wave_trips = 0, n_slides = 0, n_t8 = 0, n_t24 = 0, n_s8 = 0, n_s24 = 0;    // COUNT (option render_count): what this wave did, summed into g_f3dg_counts at its end
     unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
     unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
@@ -1050,12 +1061,119 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
             if (live_now <= 8u) { n_t8 += t; n_s8++; }
             if (live_now <= 24u) { n_t24 += t; n_s24++; }
         }
-        if (__ballot(!done) == 0ull)
+        const unsigned long long live = __ballot(!done);
+        if (live == 0ull)
             break;
+        if (TAIL && __popcll(live) <= tail_n) {
+            go_tail = true;
+            break;
+        }
+    }
+    if (TAIL && go_tail) {
+        // `pass` still holds the pending bits of the newer half (logical slots 32..63, physical slot = logical ^ xr): the first trip
+        // round of the loop below finishes them; from the second round on the 64 slots are one window, slot = bit
+        unsigned xr = flip << 5;
+        for (;;) {
+            const unsigned trips_before = n_trips;
+            while (pass != 0ull) {
+                const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
+                pass &= pass - 1;
+                if (COUNT) n_trips++;
+                const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
+                F3DG_FULL16(q2, q3);
+                const float n0 = q0.x * ray_x + q0.y * ray_y + q0.z;
+                const float n1 = q0.y * ray_x + q0.w * ray_y + q1.x;
+                const float n2 = q0.z * ray_x + q1.x * ray_y + q1.y;
+                const float aaf = ray_x * n0 + ray_y * n1 + n2;
+                const float bhalf = q1.z * ray_x + q1.w * ray_y + q2.x;
+                done = (FAST ? blend_entry_fast<NORMAL, DIST> : blend_entry<NORMAL, DIST>)(st, F3DG_R3_FLAG | j, n0, n1, n2, aaf, bhalf, q2.y, q2.z, q3.x, q3.y, q3.z);
+                if (done) pass = 0ull;
+            }
+            if (COUNT) {
+                unsigned t = n_trips - trips_before;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o, 64));
+                n_wave_trips += t;
+                n_tail_trips += t;
+            }
+            translate(2u);
+            const unsigned long long live = __ballot(!done);
+            if (live == 0ull)
+                break;
+            // ---- scan: as above, until 64 are pending
+            while (qpend < 64u && cursor < n) {
+                const unsigned idm = idn, pos = cursor + lane;
+                cursor += 64u;
+                idn = cursor + lane < n ? point_list[range.x + cursor + lane] : 0u;
+                const bool keep = pos < n && (idm & qbit) != 0u;
+                const unsigned long long kb = __ballot(keep);
+                if (keep) sQ[(qhead + qpend + (unsigned)__popcll(kb & lt)) & (F3DG_R3_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+                qpend += (unsigned)__popcll(kb);
+            }
+            const unsigned m = qpend < 64u ? qpend : 64u;
+            if (m == 0u)
+                break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- lane e <- entry e: its ellipse only (16 bytes + the c of record slot 15)
+            const bool have = lane < m;
+            uint2 q = make_uint2(0u, 0u);
+            float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float ec = 0.0f;
+            if (have) {
+                q = sQ[(qhead + lane) & (F3DG_R3_RING - 1)];
+                e4 = vcull[q.y];
+                ec = reinterpret_cast<const float*>(vrec + q.y)[15];
+            }
+            qhead += m;
+            qpend -= m;
+            // ---- phase 1 for the live pixels only (the arithmetic of quad_ballots: dx = (qx0 - cx) + column, dy = (qy0 - cy) + row)
+            const float u0 = have ? (float)qx0 - e4.x : __builtin_nanf("");
+            const float v0 = (float)qy0 - e4.y;
+            int lo = 0, hi = 0;
+            unsigned long long any = 0ull, lv = live;
+            while (lv != 0ull) {
+                const int p = __builtin_ctzll(lv);
+                lv &= lv - 1;
+                const float dx = u0 + (float)(p & 7), dy = v0 + (float)(p >> 3);
+                const float adx = e4.z * dx, cdy = ec * dy * dy;
+                const float E = fmaf(dx, fmaf(e4.w, dy, adx), cdy);
+                // (the comparison IS the ballot; M0 selects the lane; two wait states between the VALU write of VCC and its VALU read)
+                asm volatile("v_cmp_ge_f32 vcc, 1.0, %[e]\n\t"
+                             "s_mov_b32 m0, %[p]\n\t"
+                             "s_nop 1\n\t"
+                             "v_writelane_b32 %[lo], vcc_lo, m0\n\t"
+                             "v_writelane_b32 %[hi], vcc_hi, m0\n\t"
+                             "s_or_b64 %[any], %[any], vcc"
+                             : [lo] "+v"(lo), [hi] "+v"(hi), [any] "+s"(any)
+                             : [e] "v"(E), [p] "s"(p)
+                             : "vcc", "scc", "m0");
+            }
+            // ---- records of the entries some live pixel passes, slot = lane
+            if ((any >> lane) & 1ull) {
+                const float4* src = reinterpret_cast<const float4*>(vrec + q.y);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                     (__attribute__((address_space(3))) void*)&sR[c][0], 16, 0, 0);
+                if (SAVE_AUX) sP[lane] = q.x;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (COUNT) { n_staged += (unsigned)__popcll(any); n_tail_steps++; n_tail_tests += m; }
+            pass = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+            xr = 0u;
+        }
     }
     translate(2u);
     if (COUNT && lane == 0) {
         unsigned long long* c = g_f3dg_counts[blockIdx.x & 63u];
+        atomicAdd(&c[10], (unsigned long long)n_tail_steps);
+        atomicAdd(&c[11], (unsigned long long)n_tail_trips);
+        atomicAdd(&c[12], (unsigned long long)n_tail_tests);
         atomicAdd(&c[0], (unsigned long long)n_staged);
         atomicAdd(&c[1], (unsigned long long)(cursor < n ? cursor : n));
         atomicAdd(&c[2], (unsigned long long)n_wave_trips);
@@ -1320,32 +1438,42 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
             return F3DG_OK;
         }
         if (g_f3dg_render_slide) {
-#define F3DG_LAUNCH3S(AUX, FST, OCC) do { if (g_f3dg_render_wpb == 4)                                                                                        \
-            F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 4>), grid, dim3(256), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,              \
-                         focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib);                  \
-        else F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 1>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,            \
-                          focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib); } while (0)
+#define F3DG_R3S_ARGS s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib, tail_n
+            // render_tail = N > 0 (one-wave workgroups only): the tail schedule once at most N pixels of a quadrant are unsaturated
+            const int tail_n = g_f3dg_render_wpb == 1 ? g_f3dg_render_tail : 0;
+#define F3DG_LAUNCH3S(AUX, FST, OCC) do { if (g_f3dg_render_wpb == 4)                                                                           \
+            F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 4>), grid, dim3(256), (size_t)g_f3dg_render_lds_pad, F3DG_R3S_ARGS);               \
+        else if (tail_n > 0)                                                                                                                    \
+            F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 1, true, true, false, true>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, F3DG_R3S_ARGS); \
+        else F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FST, OCC, 1>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, F3DG_R3S_ARGS); } while (0)
             // the batched loops of the build that consume RGB, depth and alpha only (cycle aggregation, orbit frames) skip the normal
             // and distortion accumulators: the channels they do write are bit-identical
             const bool lean = !save_aux && (skip_channels & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION)) == (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION) &&
                               g_f3dg_render_wpb == 1;
-#define F3DG_LAUNCH3S_LEAN(FST) F3DG_KLAUNCH((render3s_fwd_kernel<false, FST, 8, 1, false, false>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
-                          focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib)
+#define F3DG_LAUNCH3S_LEAN(FST) do { if (tail_n > 0)                                                                                            \
+            F3DG_KLAUNCH((render3s_fwd_kernel<false, FST, 8, 1, false, false, false, true>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, F3DG_R3S_ARGS); \
+        else F3DG_KLAUNCH((render3s_fwd_kernel<false, FST, 8, 1, false, false>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, F3DG_R3S_ARGS); } while (0)
+#define F3DG_LAUNCH3S_COUNT(FST) do { if (tail_n > 0)                                                                                           \
+            F3DG_KLAUNCH((render3s_fwd_kernel<false, FST, 8, 1, true, true, true, true>), grid3, dim3(64), 0, F3DG_R3S_ARGS);                    \
+        else F3DG_KLAUNCH((render3s_fwd_kernel<false, FST, 8, 1, true, true, true>), grid3, dim3(64), 0, F3DG_R3S_ARGS); } while (0)
+            const char* const tail_tag = tail_n > 0 ? ", TAIL=true" : "";
+            char extra[96];
             if (g_f3dg_render_count && !save_aux && g_f3dg_render_wpb == 1) {      // (diagnostic: the same kernel with its work counters on)
-                if (g_f3dg_render_fast) F3DG_KLAUNCH((render3s_fwd_kernel<false, true, 8, 1, true, true, true>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y,
-                                                     hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib);
-                else F3DG_KLAUNCH((render3s_fwd_kernel<false, false, 8, 1, true, true, true>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y,
-                                  hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib);
-                note_kernel("render3s_fwd_kernel", 0, g_f3dg_render_fast, ", OCC=8, WPB=1, COUNT=true");
-            } else
-            if (lean) { if (g_f3dg_render_fast) F3DG_LAUNCH3S_LEAN(true); else F3DG_LAUNCH3S_LEAN(false);
-                        note_kernel("render3s_fwd_kernel", 0, g_f3dg_render_fast, ", OCC=8, WPB=1, NORMAL=false, DIST=false"); }
-            else if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3S(true, true, 8); else F3DG_LAUNCH3S(true, false, 8); }
-            else { if (g_f3dg_render_fast) F3DG_LAUNCH3S(false, true, 8); else F3DG_LAUNCH3S(false, false, 8); }
+                if (g_f3dg_render_fast) F3DG_LAUNCH3S_COUNT(true); else F3DG_LAUNCH3S_COUNT(false);
+                snprintf(extra, sizeof extra, ", OCC=8, WPB=1, COUNT=true%s", tail_tag);
+            } else if (lean) {
+                if (g_f3dg_render_fast) F3DG_LAUNCH3S_LEAN(true); else F3DG_LAUNCH3S_LEAN(false);
+                snprintf(extra, sizeof extra, ", OCC=8, WPB=1, NORMAL=false, DIST=false%s", tail_tag);
+            } else {
+                if (save_aux) { if (g_f3dg_render_fast) F3DG_LAUNCH3S(true, true, 8); else F3DG_LAUNCH3S(true, false, 8); }
+                else { if (g_f3dg_render_fast) F3DG_LAUNCH3S(false, true, 8); else F3DG_LAUNCH3S(false, false, 8); }
+                snprintf(extra, sizeof extra, ", OCC=8, WPB=%d%s", g_f3dg_render_wpb == 4 ? 4 : 1, tail_tag);
+            }
+#undef F3DG_LAUNCH3S_COUNT
 #undef F3DG_LAUNCH3S_LEAN
 #undef F3DG_LAUNCH3S
-            if (!lean && !(g_f3dg_render_count && !save_aux && g_f3dg_render_wpb == 1))
-                note_kernel("render3s_fwd_kernel", save_aux, g_f3dg_render_fast, g_f3dg_render_wpb == 4 ? ", OCC=8, WPB=4" : ", OCC=8, WPB=1");
+#undef F3DG_R3S_ARGS
+            note_kernel("render3s_fwd_kernel", lean || (g_f3dg_render_count && !save_aux && g_f3dg_render_wpb == 1) ? 0 : save_aux, g_f3dg_render_fast, extra);
             F3DG_HIP_CHECK(hipGetLastError());
             return F3DG_OK;
         }

@@ -116,6 +116,28 @@ def test_forward_batched_views_equal_single_views(gpu_device, kw):
     assert total == h["num_rendered"]
 
 
+@pytest.mark.parametrize("kw", [
+    dict(P=8000, res=(128, 128), s0=0.03, view=[0, 1, 3, 5, 6, 2, 4, 7, 8]),
+    dict(P=4001, res=(96, 80), s0=0.2, view=[0, 3, 5], depth_range=(1.0, 30.0)),       # four-pass views: the last pass is pass 3
+], ids=["compact", "four_pass"])
+def test_fused_rectangle_gather_is_invisible(gpu_device, kw):
+    """Option sort_fused_rects (a view's last depth pass also delivers its tile rectangles in sorted order; measured equal, off by
+    default) against the separate gather launch: lists, ranges and images identical."""
+    from f3dgaus_amd import _lib
+    scene = make_scene(**kw)
+    L = _lib.lib()
+    a = run_hip(scene, gpu_device)
+    try:
+        assert L.f3dg_set_option(b"sort_fused_rects", 1) == 0
+        b = run_hip(scene, gpu_device)
+    finally:
+        L.f3dg_set_option(b"sort_fused_rects", 0)
+    assert a["num_rendered"] == b["num_rendered"]
+    for k in ("point_list", "ranges", "keys_sorted"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["out_color"].view(np.uint32), b["out_color"].view(np.uint32))
+
+
 @pytest.mark.parametrize("which", ["cov3D+view2gaussian", "view2gaussian"])
 def test_precomputed_covariance_and_view2gaussian(which, gpu_device):
     """cov3D_precomp replaces scales / rotations in the 2D footprint (forward.cu:338-348), view2gaussian_precomp replaces the
@@ -254,6 +276,9 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
         variants.append(run_hip(scene, gpu_device))   # the default for launches this small: render3l_fwd_kernel (prefetching windows)
         L.f3dg_set_option(b"render_lowocc", 0)
         variants.append(run_hip(scene, gpu_device))   # the default for everything larger: sliding half-windows (render3s_fwd_kernel)
+        for tail in (64, 24, 5, 0):                   # ... with the tail schedule from at most `tail` unsaturated pixels per quadrant on
+            L.f3dg_set_option(b"render_tail", tail)
+            variants.append(run_hip(scene, gpu_device))
         L.f3dg_set_option(b"render_slide", 0)         # fixed 64-entry windows,
         for dma in (1, 0):                          # records staged by global_load_lds / through registers
             L.f3dg_set_option(b"render_dma", dma)
@@ -264,12 +289,42 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
         L.f3dg_set_option(b"render_lowocc", 1)
         L.f3dg_set_option(b"render_dma", 1)
         L.f3dg_set_option(b"render_round", 192)
+        L.f3dg_set_option(b"render_tail", -1)
         for o in (b"render_pretest", b"render_cull", b"render_queue"):
             L.f3dg_set_option(o, 1)
     for b in variants:
         for k in ("out_color", "final_T", "n_contrib"):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     assert L.f3dg_set_option(b"no_such_option", 1) == _lib.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("tail", [64, 16, 3])
+def test_tail_schedule_thin_coverage(tail, gpu_device):
+    """The tail schedule of the one-wave kernel (option render_tail) on the case it exists for: long tile lists of faint
+    Gaussians, so that pixels never saturate and walk the whole list (several views, odd image size, inference and SAVE_AUX
+    calls). Held against the oracle and bit-identical to the sliding-window schedule."""
+    from f3dgaus_amd import _lib
+    scene = make_scene(P=40000, res=(120, 88), s0=0.03, view="oblique", n_views=3, seed=7)
+    scene["opacities"] = scene["opacities"] * 0.04        # ~40 entries per pixel, alpha <= 0.04 each: T stays far above 1e-4
+    L = _lib.lib()
+    try:
+        L.f3dg_set_option(b"render_lowocc", 0)
+        L.f3dg_set_option(b"render_tail", 0)
+        a = run_hip(scene, gpu_device)
+        a_inf = run_hip(scene, gpu_device, save_aux=False)
+        L.f3dg_set_option(b"render_tail", tail)
+        b = run_hip(scene, gpu_device)
+        b_inf = run_hip(scene, gpu_device, save_aux=False)
+    finally:
+        L.f3dg_set_option(b"render_lowocc", 1)
+        L.f3dg_set_option(b"render_tail", -1)
+    for k in ("out_color", "final_T", "n_contrib"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert np.array_equal(a_inf["out_color"].view(np.uint32), b_inf["out_color"].view(np.uint32))
+    assert float(b["final_T"][:, 0].min()) > 1e-3         # nothing saturated: every quadrant went through its whole list
+    for v in range(3):
+        o = run_oracle(scene, view=v)
+        assert_render_parity(b["out_color"][v], o["out_color"], "tail %d view %d" % (tail, v))
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--mode", default="fast")
 ap.add_argument("--label", default="")
 ap.add_argument("--pixel-ordered", action="store_true")
+ap.add_argument("--counts", action="store_true", help="one more call with the compositing kernel's work counters on (option render_count)")
 ap.add_argument("--real", action="store_true", help="the merged set of the real image (tests/real_data.py), 589,824 Gaussians")
 a = ap.parse_args()
 L = _lib.lib()
@@ -76,3 +77,14 @@ b = 72.0 * R + (36.0 * RES * RES + 8.0 * T) * V
 fmt = lambda c: "%.3f/%.3f/%.3f" % (rows[:, c].min(), np.median(rows[:, c]), rows[:, c].max())
 print("%-28s P=%d V=%d R=%d mode=%s | pre %s | bin %s | comp %s ms (min/med/max) | frac %.3f | sha %s" %
       (a.label, P, V, R, a.mode, fmt(0), fmt(1), fmt(2), b / (np.median(rows[:, 2]) * 1e-3) / 8e12, h), flush=True)
+if a.counts:
+    cb = (C.c_ulonglong * 16)()
+    L.f3dg_set_option(b"render_count", 1)
+    L.f3dg_debug_render_counts(cb, 1)
+    call(False)
+    torch.cuda.synchronize()
+    L.f3dg_debug_render_counts(cb, 1)
+    L.f3dg_set_option(b"render_count", 0)
+    c = [int(x) for x in cb]
+    print("    counters: staged %.3e scanned %.3e wave-trips %.3e slides %.3e lane-util %.3f | slides<=8 live %.3e (trips %.3e) <=24 %.3e (trips %.3e) | "
+          "tail steps %.3e trips %.3e tested %.3e" % (c[0], c[1], c[2], c[3], c[4] / (64.0 * max(c[2], 1)), c[8], c[6], c[9], c[7], c[10], c[11], c[12]), flush=True)

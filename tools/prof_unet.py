@@ -51,6 +51,42 @@ for _ in range(3):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / 3 * 1e3
 
+# ---- every convolution of the pass between two HIP events: milliseconds, FLOPs (2 N Cout Hout Wout Cin k^2) and TFLOP/s per shape.
+# (torch's with_flops knows aten::conv2d but the device time sits on aten::miopen_convolution and the kernels below it, so the
+# profiler table further down has no FLOP column worth reading.)
+import torch.nn.functional as F  # noqa: E402
+_conv2d = F.conv2d
+conv_log = []
+
+
+def timed_conv2d(inp, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = _conv2d(inp, weight, bias, stride, padding, dilation, groups)
+    e1.record()
+    conv_log.append((tuple(inp.shape), tuple(weight.shape), tuple(out.shape), str(inp.dtype).replace("torch.", ""), e0, e1))
+    return out
+
+
+F.conv2d = timed_conv2d
+run()
+torch.cuda.synchronize()
+F.conv2d = _conv2d
+groups = {}
+for ishape, wshape, oshape, dt_, e0, e1 in conv_log:
+    fl = 2.0 * oshape[0] * oshape[1] * oshape[2] * oshape[3] * wshape[1] * wshape[2] * wshape[3]
+    g = groups.setdefault((ishape, wshape, dt_), [0, 0.0, 0.0])
+    g[0] += 1; g[1] += e0.elapsed_time(e1); g[2] += fl
+tot_ms = sum(g[1] for g in groups.values()); tot_fl = sum(g[2] for g in groups.values())
+peak = 157.3 if mode == "fp32" else 2500.0
+print(f"### {B} images, {mode}: convolutions between HIP events: {len(conv_log)} calls, {tot_ms:.1f} ms, {tot_fl / 1e12:.2f} TFLOP -> "
+      f"**{tot_fl / tot_ms / 1e9:.1f} TFLOP/s** ({100 * tot_fl / tot_ms / 1e9 / peak:.1f} % of the {peak:.0f} TFLOP/s dense {'fp32 vector / matrix' if mode == 'fp32' else 'bf16 MFMA'} peak)\n")
+print("| input | weight | dtype | calls | ms | GFLOP | TFLOP/s |")
+print("|---|---|---|---:|---:|---:|---:|")
+for (ishape, wshape, dt_), g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:8]:
+    print(f"| {list(ishape)} | {list(wshape)} | {dt_} | {g[0]} | {g[1]:.3f} | {g[2] / 1e9:.1f} | {g[2] / g[1] / 1e9:.1f} |")
+print()
+
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_flops=True) as prof:
     run()
