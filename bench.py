@@ -63,6 +63,9 @@ def parse():
                          "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
     ap.add_argument("--backbone", choices=["fp32", "bf16"], default="fp32",
                     help="c4: precision of the SongUNet backbone (bf16 = the opt-in autocast option, SURVEY 8f-3)")
+    ap.add_argument("--backbone-layout", choices=["nchw", "nhwc"], default="nchw",
+                    help="c4: memory layout of the SongUNet backbone (nhwc = the opt-in channels-last option: MIOpen's NHWC kernels + the "
+                         "channels-last GroupNorm+SiLU kernel)")
     ap.add_argument("--tile-cull", type=int, choices=[0, 1], default=1,
                     help="1 (library default): a Gaussian is instantiated only in the tiles its alpha >= 1/255 ellipse reaches; "
                          "0: the reference's tile lists (every tile of the 3-sigma square)")
@@ -515,6 +518,7 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
     B, RES, V = args.images, args.res, 8
     cfg = cameras.default_cfg(RES)
     cfg['model']['backbone_dtype'] = args.backbone
+    cfg['model']['backbone_layout'] = args.backbone_layout
     torch.backends.cudnn.benchmark = True               # MIOpen picks its convolution algorithms once per shape
     torch.manual_seed(0)
     model = f3d.Unet_GS_gtunet(cfg, renderer=f3d.render_predicted_more_v2_gof).to(device).eval()
@@ -563,7 +567,7 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
         "config": {"workload": "C4 shape per rank (C3 at 1 GPU): %d images/GPU @%dx%d, predictor (SongUNet, random weights) + cycle "
                                "aggregation (8 views, 8 re-predictions, merged sets of 589,824 Gaussians) + 8 orbit views of every merged set "
                                "+ frame packing + gather" % (B, RES, RES),
-                   "images_per_gpu": B, "views_per_image": V, "resolution": RES, "backbone": args.backbone,
+                   "images_per_gpu": B, "views_per_image": V, "resolution": RES, "backbone": args.backbone, "backbone_layout": args.backbone_layout,
                    "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
         "breakdown_ms_per_step": {"predictor + cycle aggregation": t_cycle[0] / args.steps, "orbit render + frame packing": t_cycle[1] / args.steps,
                                   "rasterizer stages (HIP events)": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,

@@ -130,6 +130,7 @@ int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_sort_fused_rects = 0;
 int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
+int g_f3dg_pre_order = 0;             // projection grid: 0 view-major (a view's chunks follow each other), 1 chunk-major (a chunk's views do)
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
 
 extern "C" int f3dg_set_option(const char* name, int value)
@@ -154,6 +155,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_fused_rects") == 0) { g_f3dg_sort_fused_rects = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "pre_order") == 0) { g_f3dg_pre_order = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
     return F3DG_ERR_BAD_ARG;
 }

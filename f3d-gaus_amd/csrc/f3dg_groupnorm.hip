@@ -146,7 +146,138 @@ int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const 
     return F3DG_OK;
 }
 
+// ---- channels-last (NHWC) variant ---------------------------------------------------------------------------------------------------
+// MIOpen's fastest convolutions on gfx950 are its NHWC kernels; handed NCHW tensors it wraps them in batched_transpose launches
+// (15 % of a bf16 pass of the backbone, profiles/r04_final/unet.md), and torch's GroupNorm converts a channels_last tensor back, so the
+// layout only pays if GroupNorm keeps it. x is [N][HW][C]: a group's Cg channels are 8..64 bytes of every pixel's C-vector, so a
+// workgroup takes a run of pixels with ALL channels (whole lines), and the moments of a (sample, group) are summed across workgroups:
+//   gn_nhwc_moments_kernel: thread (row, col) owns the 16-byte packet `col` of the pixels row, row + rows, ...: float sums per channel
+//       over at most GN_NHWC_PIX / rows pixels, per-channel totals over the rows in LDS, per-group totals added in float64 (atomics) to
+//       moments[n][g] = (sum, sum of squares);
+//   gn_nhwc_apply_kernel: the same mapping; scale / shift of the thread's PN channels once, then one pass: silu(x * sc + sh).
+// Two reads (the second from L2 / MALL) and one write, as the NCHW kernel.
+constexpr int GN_NHWC_PIX = 256;      // pixels per workgroup
+constexpr int GN_NHWC_MAXC = 1024;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gn_nhwc_moments_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, double* __restrict__ moments)
+{
+    constexpr int PN = Packet<T>::N;
+    const int ppp = C / PN;                                   // packets per pixel
+    const int col = threadIdx.x % ppp, row = threadIdx.x / ppp;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * GN_NHWC_PIX;
+    const int p1 = min(p0 + GN_NHWC_PIX, HW);
+    float a[PN], b[PN];
+#pragma unroll
+    for (int k = 0; k < PN; k++) { a[k] = 0.0f; b[k] = 0.0f; }
+    if (row < rows) {
+        const T* xs = x + ((size_t)n * HW) * C + (size_t)col * PN;
+        for (int p = p0 + row; p < p1; p += rows) {
+            Packet<T> q;
+            q.load(xs + (size_t)p * C);
+#pragma unroll
+            for (int k = 0; k < PN; k++) { a[k] += q.v[k]; b[k] += q.v[k] * q.v[k]; }
+        }
+    }
+    __shared__ float sa[GN_NHWC_MAXC], sb[GN_NHWC_MAXC];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { sa[c] = 0.0f; sb[c] = 0.0f; }
+    __syncthreads();
+    if (row < rows) {
+#pragma unroll
+        for (int k = 0; k < PN; k++) { atomicAdd(&sa[col * PN + k], a[k]); atomicAdd(&sb[col * PN + k], b[k]); }
+    }
+    __syncthreads();
+    const int Cg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = g * Cg; c < (g + 1) * Cg; c++) { s1 += (double)sa[c]; s2 += (double)sb[c]; }
+        unsafeAtomicAdd(&moments[2 * ((size_t)n * groups + g)], s1);
+        unsafeAtomicAdd(&moments[2 * ((size_t)n * groups + g) + 1], s2);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, const double* __restrict__ moments,
+                     const float* __restrict__ weight, const float* __restrict__ bias, float eps, int apply_silu, T* __restrict__ y)
+{
+    constexpr int PN = Packet<T>::N;
+    const int ppp = C / PN;
+    const int col = threadIdx.x % ppp, row = threadIdx.x / ppp;
+    if (row >= rows) return;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * GN_NHWC_PIX;
+    const int p1 = min(p0 + GN_NHWC_PIX, HW);
+    const int Cg = C / groups;
+    const double cnt = (double)Cg * (double)HW;
+    float sc[PN], sh[PN];
+    {
+        int g_prev = -1;
+        float mean = 0.0f, rstd = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PN; k++) {
+            const int c = col * PN + k, g = c / Cg;
+            if (g != g_prev) {
+                const double m = moments[2 * ((size_t)n * groups + g)] / cnt;
+                double var = moments[2 * ((size_t)n * groups + g) + 1] / cnt - m * m;
+                if (var < 0.0) var = 0.0;
+                mean = (float)m;
+                rstd = (float)(1.0 / sqrt(var + (double)eps));
+                g_prev = g;
+            }
+            sc[k] = weight[c] * rstd;
+            sh[k] = bias[c] - mean * sc[k];
+        }
+    }
+    const size_t base = ((size_t)n * HW) * C + (size_t)col * PN;
+    for (int p = p0 + row; p < p1; p += rows) {
+        Packet<T> q;
+        q.load(x + base + (size_t)p * C);
+#pragma unroll
+        for (int k = 0; k < PN; k++) {
+            float v = q.v[k] * sc[k] + sh[k];
+            if (apply_silu) v = v / (1.0f + expf(-v));
+            q.v[k] = v;
+        }
+        q.store(y + base + (size_t)p * C);
+    }
+}
+
+template <typename T>
+int launch_gn_nhwc(void* stream, int N, int C, int HW, int groups, const T* x, const float* weight, const float* bias, float eps,
+                   int apply_silu, T* y, double* moments)
+{
+    constexpr int PN = Packet<T>::N;
+    if (N < 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0 || !x || !weight || !bias || !y || !moments) return F3DG_ERR_BAD_ARG;
+    if (C % PN != 0 || C / PN > 256 || C > GN_NHWC_MAXC) return F3DG_ERR_BAD_ARG;   // whole 16-byte packets per pixel, one packet column per thread
+    if (N == 0) return F3DG_OK;
+    if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;
+    const int ppp = C / PN, rows = 256 / ppp;
+    hipStream_t s = (hipStream_t)stream;
+    F3DG_HIP_CHECK(hipMemsetAsync(moments, 0, sizeof(double) * 2 * (size_t)N * groups, s));
+    const dim3 grid((unsigned)((HW + GN_NHWC_PIX - 1) / GN_NHWC_PIX), (unsigned)N);
+    F3DG_KLAUNCH(gn_nhwc_moments_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, moments);
+    F3DG_KLAUNCH(gn_nhwc_apply_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, moments, weight, bias, eps, apply_silu, y);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
 } // namespace
+
+// GroupNorm (+ SiLU) of a channels-last tensor, x and y [N][HW][C]; `moments` is scratch of 2 * N * groups doubles (zeroed here)
+extern "C" int f3dg_group_norm_silu_nhwc(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
+                                         const float* bias, float eps, int apply_silu, float* y, double* moments)
+{
+    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y, moments);
+}
+
+extern "C" int f3dg_group_norm_silu_nhwc_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
+                                              const float* bias, float eps, int apply_silu, uint16_t* y, double* moments)
+{
+    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y, moments);
+}
 
 extern "C" int f3dg_group_norm_silu(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
                                     const float* bias, float eps, int apply_silu, float* y)

@@ -11,6 +11,7 @@
 #include "f3dg_common.h"
 
 extern int g_f3dg_debug_skip_all;
+extern int g_f3dg_pre_order;
 
 namespace {
 
@@ -218,7 +219,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
                   unsigned char* __restrict__ clamped, int debug_skip_all, int tile_cull,
-                  double inv_focal_x, double inv_focal_y, F3dgHeaderInit init)
+                  double inv_focal_x, double inv_focal_y, F3dgHeaderInit init, int chunk_major)
 {
     if (init.hdr != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
         // the workspace header (read by every later kernel of the call, by nothing in this one): zeroed, then its constants
@@ -230,8 +231,10 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
             init.hdr->small_shape[2] = init.shape[2]; init.hdr->small_shape[3] = init.shape[3];
         }
     }
-    const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
-    const int v = blockIdx.y;
+    // chunk_major (option pre_order = 1): blockIdx.x is the VIEW, so the workgroups that follow each other in dispatch order are the
+    // views of ONE chunk of 256 Gaussians and its 23 KB of inputs are fetched once per XCD instead of once per view
+    const int g = (chunk_major ? blockIdx.y : blockIdx.x) * F3DG_BLOCK + threadIdx.x;
+    const int v = chunk_major ? blockIdx.x : blockIdx.y;
     const size_t gs = (size_t)(v / views_per_set) * P + g;       // this view's Gaussian set: inputs are [n_sets, P, ...]
     if (g >= P)
         return;
@@ -556,12 +559,14 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
-    dim3 grid((P + F3DG_BLOCK - 1) / F3DG_BLOCK, V, 1);
+    const int chunks = (P + F3DG_BLOCK - 1) / F3DG_BLOCK;
+    const int chunk_major = g_f3dg_pre_order != 0 && chunks <= 65535;
+    dim3 grid(chunk_major ? V : chunks, chunk_major ? chunks : V, 1);
 #define F3DG_LAUNCH_PRE(AUX) F3DG_KLAUNCH(preprocess_kernel<AUX>, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales,     \
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,                          \
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,                                          \
                        depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, g_f3dg_debug_skip_all, tile_cull,                                    \
-                       1.0 / (double)focal_x, 1.0 / (double)focal_y, init)
+                       1.0 / (double)focal_x, 1.0 / (double)focal_y, init, chunk_major)
     if (save_aux) F3DG_LAUNCH_PRE(true); else F3DG_LAUNCH_PRE(false);
 #undef F3DG_LAUNCH_PRE
     F3DG_HIP_CHECK(hipGetLastError());

@@ -53,6 +53,11 @@ def _xavier_uniform(shape, fan_in, fan_out, gain=1.0):
     return gain * math.sqrt(6.0 / (fan_in + fan_out)) * (torch.rand(*shape) * 2 - 1)
 
 
+def _is_nhwc(t):
+    """A 4-D tensor stored channels-last (and not also NCHW-contiguous, as 1-channel or 1x1 tensors are)."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
 class Conv2d(nn.Module):
     """Convolution with optional x2 up / down resampling BEFORE the convolution (gaussian_predictor.py:137-178 with
     resample_filter [1,1], fused_resample False). kernel = 0 means "resample only"."""
@@ -76,7 +81,10 @@ class Conv2d(nn.Module):
         if self.down:
             x = F.avg_pool2d(x, 2)
         if self.weight is not None:
-            x = F.conv2d(x, self.weight.to(x.dtype), self.bias.to(x.dtype), padding=self.weight.shape[-1] // 2)
+            w = self.weight.to(x.dtype)
+            if _is_nhwc(x) and not _is_nhwc(w) and w.shape[1] > 1:      # layout option "nhwc": the filter in the activations' layout
+                w = w.contiguous(memory_format=torch.channels_last)
+            x = F.conv2d(x, w, self.bias.to(x.dtype), padding=self.weight.shape[-1] // 2)
         return x
 
 
@@ -94,6 +102,16 @@ class GroupNorm(nn.Module):
         or on the host (the CPU fixtures of the backbone) it is the two PyTorch ops."""
         if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 3 and self.weight.dtype == torch.float32 and not (
                 torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+            if _is_nhwc(x) and x.shape[1] % (4 if x.dtype == torch.float32 else 8) == 0 and x.shape[1] <= 1024:
+                # layout option "nhwc": the channels-last kernel, channels-last out
+                y = torch.empty_like(x)           # preserves the strides
+                N, Cc = x.shape[0], x.shape[1]
+                mom = torch.empty(2 * N * self.num_groups, dtype=torch.float64, device=x.device)
+                fn = _lib.lib().f3dg_group_norm_silu_nhwc if x.dtype == torch.float32 else _lib.lib().f3dg_group_norm_silu_nhwc_bf16
+                rc = fn(_stream(), N, Cc, x.shape[2] * x.shape[3], self.num_groups, _lib.ptr(x), _lib.ptr(self.weight), _lib.ptr(self.bias),
+                        float(self.eps), 1 if silu else 0, _lib.ptr(y), _lib.ptr(mom))
+                _lib.check(rc, "f3dg_group_norm_silu_nhwc")
+                return y
             xc = x.contiguous()
             y = torch.empty_like(xc)
             N, Cc = xc.shape[0], xc.shape[1]
@@ -144,6 +162,8 @@ class UNetBlock(nn.Module):
             q, k, v = (t.transpose(1, 2).unsqueeze(1).float() for t in qkv.unbind(2))      # [b,1,L,c]
             a = F.scaled_dot_product_attention(q, k, v)                  # softmax(q k^T / sqrt(c)) v, fp32
             a = a.squeeze(1).transpose(1, 2).to(x.dtype).reshape(*x.shape)
+            if _is_nhwc(x):
+                a = a.contiguous(memory_format=torch.channels_last)
             x = self.proj(a) + x
             x = x * self.skip_scale
             if N_views_xa != 1:
@@ -289,6 +309,11 @@ class GaussianSplatPredictor_gtunet(nn.Module):
         # extension: "bf16" runs the backbone's convolutions under bfloat16 autocast with bf16 activations between
         # the layers (GroupNorm statistics, attention and the splat head stay float32); "fp32" (default) is the reference's precision
         self.backbone_dtype = str(m.get('backbone_dtype', 'fp32'))
+        # extension: "nhwc" keeps the backbone's activations (and filters) channels-last, the layout of MIOpen's fastest kernels on
+        # gfx950 -- GroupNorm+SiLU is the channels-last HIP kernel, nothing converts in between; "nchw" (default) is torch's layout
+        self.backbone_layout = str(m.get('backbone_layout', 'nchw'))
+        if self.backbone_layout not in ("nchw", "nhwc"):
+            raise ValueError("backbone_layout must be 'nchw' or 'nhwc'")
         self.init_ray_dirs()
         self.init_sh_transform_matrices()
 
@@ -336,6 +361,11 @@ class GaussianSplatPredictor_gtunet(nn.Module):
         x = x.reshape(B * Nv, *x.shape[2:])
         v2w = source_cameras_view_to_world.reshape(B * Nv, 4, 4)
         quat = source_cv2wT_quat.reshape(B * Nv, 4)
+        if self.backbone_layout == "nhwc" and x.is_cuda and not torch.is_grad_enabled():
+            if not getattr(self, "_nhwc_filters", False):       # once: the filters in the activations' layout
+                self.network_with_offset.to(memory_format=torch.channels_last)
+                self._nhwc_filters = True
+            x = x.contiguous(memory_format=torch.channels_last)
         if self.backbone_dtype == "bf16" and x.is_cuda and not torch.is_grad_enabled():
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)
@@ -344,6 +374,7 @@ class GaussianSplatPredictor_gtunet(nn.Module):
             raise ValueError("backbone_dtype must be 'fp32' or 'bf16'")
         else:
             net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)
+        net_out = net_out.contiguous()                  # (the splat head reads planar channels)
         H, W = net_out.shape[-2:]
         depth = unet_depth.reshape(B * Nv, 1, H, W)
         if out is not None:

@@ -295,6 +295,13 @@ int f3dg_group_norm_silu(void* stream, int N, int C, int HW, int groups, const f
  * the moments float64. */
 int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
                               const float* bias, float eps, int apply_silu, uint16_t* y);
+/* The same for channels-last activations (the backbone's "nhwc" layout option: MIOpen's NHWC convolution kernels without the layout
+ * transposes around them): x, y [N,HW,C] contiguous, C a multiple of 4 (float32) / 8 (bfloat16) and at most 1024;
+ * `moments` is scratch of 2 * N * groups doubles (cleared by the call). Same statistics, same formula. */
+int f3dg_group_norm_silu_nhwc(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
+                              const float* bias, float eps, int apply_silu, float* y, double* moments);
+int f3dg_group_norm_silu_nhwc_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
+                                   const float* bias, float eps, int apply_silu, uint16_t* y, double* moments);
 
 /* Runtime switches (process-wide). Known names: "render_pretest" (default 1): the compositing kernel first runs a
  * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;

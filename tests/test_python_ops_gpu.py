@@ -281,6 +281,87 @@ def test_backbone_bf16_option(gpu_device):
     assert out["xyz"].dtype == torch.float32 and out["xyz"].shape == (2, 1024, 3) and bool(torch.isfinite(out["scaling"]).all())
 
 
+def test_group_norm_silu_channels_last_kernel(gpu_device):
+    """f3dg_group_norm_silu_nhwc(_bf16): the channels-last GroupNorm (+ SiLU) of the backbone's "nhwc" layout option against float64
+    torch, on the channel counts of the backbone (128 / 256 / 384 / 512: 16..128 packets per pixel, incl. the two that do not divide
+    the workgroup) and on pixel counts that are not a multiple of a workgroup's run; the output stays channels-last."""
+    import torch.nn.functional as F
+    from f3dgaus_amd.gaussian_predictor import GroupNorm
+    torch.manual_seed(1)
+    for (N, Cc, H, W) in ((2, 128, 64, 64), (1, 256, 16, 16), (2, 384, 20, 13), (1, 512, 32, 32), (3, 128, 7, 5), (1, 1024, 9, 9)):
+        gn = GroupNorm(Cc, eps=1e-6).to(gpu_device)
+        with torch.no_grad():
+            gn.weight.uniform_(0.5, 1.5); gn.bias.uniform_(-0.5, 0.5)
+            x32 = (torch.randn(N, Cc, H, W, device=gpu_device) * 3 + 1.5).contiguous(memory_format=torch.channels_last)
+            for x in (x32, x32.bfloat16()):
+                for silu in (False, True):
+                    y = gn(x, silu=silu)
+                    assert y.dtype == x.dtype and y.is_contiguous(memory_format=torch.channels_last)
+                    ref = F.group_norm(x.double(), gn.num_groups, gn.weight.double(), gn.bias.double(), gn.eps)
+                    ref = F.silu(ref) if silu else ref
+                    err = (y.double() - ref).abs().max().item()
+                    if x.dtype == torch.float32:
+                        t = F.group_norm(x32.contiguous(), gn.num_groups, gn.weight, gn.bias, gn.eps)
+                        t = F.silu(t) if silu else t
+                        assert err <= max(2 * (t.double() - ref).abs().max().item(), 2e-6), (N, Cc, H, W, silu, err)
+                        # and the NCHW kernel gives the same numbers up to the last bit or two
+                        assert (gn(x32.contiguous(), silu=silu) - y).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
+                    else:
+                        assert err <= 2.0 ** -8 * max(1.0, ref.abs().max().item()), (N, Cc, H, W, silu, err)
+
+
+def test_backbone_channels_last_option(gpu_device):
+    """cfg['model']['backbone_layout'] = 'nhwc': the backbone with channels-last activations and filters (MIOpen's NHWC kernels, the
+    channels-last GroupNorm+SiLU kernel, no layout conversion in between). float32: the reference-generated fixture songunet.npz at the
+    float32 bar of the default layout; bf16: the bar of the bf16 option. The predictor's Gaussians equal the default layout's to float32
+    accuracy."""
+    import os
+    from f3dgaus_amd.gaussian_predictor import GaussianSplatPredictor_gtunet
+    from helpers_weights import formula_state_dict
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "songunet.npz"))
+    pred = GaussianSplatPredictor_gtunet(cameras.default_cfg()).eval()
+    sd = pred.state_dict()
+    keep = {k: v for k, v in sd.items() if k in ("ray_dirs", "sh_to_v_transform", "v_to_sh_transform") or k.endswith("resample_filter")}
+    pred.load_state_dict(formula_state_dict({k: tuple(v.shape) for k, v in sd.items()}, keep=keep))
+    pred = pred.to(gpu_device)
+    x = torch.from_numpy(g["x"]).to(gpu_device)
+    ref = torch.from_numpy(g["y"]).to(gpu_device)
+    with torch.no_grad():
+        y_nchw = pred.network_with_offset(x, N_views_xa=1)
+        pred.network_with_offset.to(memory_format=torch.channels_last)
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        y32 = pred.network_with_offset(xcl, N_views_xa=1)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y16 = pred.network_with_offset(xcl, N_views_xa=1).float()
+    e32 = ((y32 - ref).abs().max() / ref.abs().max()).item()
+    e16 = ((y16 - ref).abs().max() / ref.abs().max()).item()
+    rms16 = ((y16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    d = ((y32 - y_nchw).abs().max() / ref.abs().max()).item()
+    print(f"SongUNet channels-last vs reference fixture: fp32 max rel {e32:.2e} (vs the NCHW pass {d:.2e}); bf16 max rel {e16:.2e}, rms rel {rms16:.2e}")
+    assert e32 < 5e-5 and e16 < 0.25 and rms16 < 0.12, (e32, e16, rms16)
+    # wired through the predictor
+    cfg = cameras.default_cfg(32)
+    p0 = GaussianSplatPredictor_gtunet(cfg).to(gpu_device).eval()
+    cfg2 = cameras.default_cfg(32)
+    cfg2['model']['backbone_layout'] = 'nhwc'
+    p1 = GaussianSplatPredictor_gtunet(cfg2).to(gpu_device).eval()
+    p1.load_state_dict(p0.state_dict())
+    assert p1.backbone_layout == "nhwc"
+    torch.manual_seed(3)
+    xin = torch.rand(2, 1, 4, 32, 32, device=gpu_device)
+    rig = cameras.OrbitRig(cfg).canonical
+    args = (rig.view_to_world_transforms.expand(2, 1, 4, 4).to(gpu_device), rig.source_cv2wT_quat.expand(2, 1, 4).to(gpu_device))
+    with torch.no_grad():
+        a = p0(xin, *args, unet_depth=torch.full((2, 1, 32, 32), 7.0, device=gpu_device))
+        b = p1(xin, *args, unet_depth=torch.full((2, 1, 32, 32), 7.0, device=gpu_device))
+    for k in a:
+        assert a[k].shape == b[k].shape and (a[k] - b[k]).abs().max().item() <= 1e-4 * max(1.0, a[k].abs().max().item()), k
+    with pytest.raises(ValueError):
+        bad = cameras.default_cfg(32)
+        bad['model']['backbone_layout'] = 'nchw16'
+        GaussianSplatPredictor_gtunet(bad)
+
+
 def test_renderer_derived_maps_carry_gradients(gpu_device):
     """rendered_normal / depth_normal are differentiable in the reference (gr.py:1043-1053). With gradients enabled
     the wrapper takes the torch formulation (same values as the fused kernel) and a loss on them reaches the Gaussians."""

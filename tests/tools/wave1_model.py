@@ -21,8 +21,14 @@ if os.environ.get("REAL"):
     # view of its final orbit: how do the schedules fare on pixel-aligned splats on a real depth map?
     import torch
     from f3dgaus_amd import synthetic
-    from real_data import real_merged_set
-    g = {k: v.cpu() for k, v in real_merged_set(torch.device("cuda:0")).items()}
+    dump = os.path.join(ROOT, "gpurun_out", "real_set.npz")       # written on a GPU box by tools/dump_real_set.py (colour is irrelevant here)
+    if not torch.cuda.is_available() and os.path.exists(dump):
+        z = np.load(dump)
+        g = {k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}
+        g["features_rest"] = torch.zeros(g["xyz"].shape[0], 3, 3)
+    else:
+        from real_data import real_merged_set
+        g = {k: v.cpu() for k, v in real_merged_set(torch.device("cuda:0")).items()}
     cams = synthetic.orbit_cameras(128, resolution=256)
     vi = int(os.environ.get("VIEW", "40"))
     sc = dict(P=g["xyz"].shape[0], W=256, H=256, sh_degree=1, kernel_size=0.0, scale_modifier=1.0, tanfovx=cams["tanfovx"],

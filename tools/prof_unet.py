@@ -18,12 +18,17 @@ from f3dgaus_amd import cameras, gaussian_predictor as gp  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+nhwc = mode.endswith("_nhwc")        # fp32_nhwc / bf16_nhwc: the channels-last layout option (activations and filters)
+mode_label, mode = mode, mode.replace("_nhwc", "")
 dev = torch.device("cuda:0")
 cfg = cameras.default_cfg(256)
 torch.manual_seed(0)
 torch.backends.cudnn.benchmark = True
 pred = f3d.GaussianSplatPredictor_gtunet(cfg).to(dev).eval()
 x = torch.rand(B, 4, 256, 256, device=dev)
+if nhwc:
+    pred.network_with_offset.to(memory_format=torch.channels_last)
+    x = x.contiguous(memory_format=torch.channels_last)
 
 if mode == "bf16_resident":
     # experiment: every convolution weight / bias cast ONCE (Conv2d.forward casts `self.weight.to(x.dtype)` per call; under autocast
@@ -79,7 +84,7 @@ for ishape, wshape, oshape, dt_, e0, e1 in conv_log:
     g[0] += 1; g[1] += e0.elapsed_time(e1); g[2] += fl
 tot_ms = sum(g[1] for g in groups.values()); tot_fl = sum(g[2] for g in groups.values())
 peak = 157.3 if mode == "fp32" else 2500.0
-print(f"### {B} images, {mode}: convolutions between HIP events: {len(conv_log)} calls, {tot_ms:.1f} ms, {tot_fl / 1e12:.2f} TFLOP -> "
+print(f"### {B} images, {mode_label}: convolutions between HIP events: {len(conv_log)} calls, {tot_ms:.1f} ms, {tot_fl / 1e12:.2f} TFLOP -> "
       f"**{tot_fl / tot_ms / 1e9:.1f} TFLOP/s** ({100 * tot_fl / tot_ms / 1e9 / peak:.1f} % of the {peak:.0f} TFLOP/s dense {'fp32 vector / matrix' if mode == 'fp32' else 'bf16 MFMA'} peak)\n")
 print("| input | weight | dtype | calls | ms | GFLOP | TFLOP/s |")
 print("|---|---|---|---:|---:|---:|---:|")
@@ -95,7 +100,7 @@ ka = prof.key_averages(group_by_input_shape=True)
 dt = lambda e: getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)
 rows = sorted((e for e in ka if dt(e) > 0), key=dt, reverse=True)
 total_us = sum(dt(e) for e in rows)
-print(f"### {B} images, {mode}: {ms:.1f} ms per pass (wall, 3 passes), {total_us / 1e3:.1f} ms of device time in {len(rows)} (operator, shape) groups\n")
+print(f"### {B} images, {mode_label}: {ms:.1f} ms per pass (wall, 3 passes), {total_us / 1e3:.1f} ms of device time in {len(rows)} (operator, shape) groups\n")
 print("| operator | input shapes | calls | device ms | % | GFLOP | TFLOP/s |")
 print("|---|---|---:|---:|---:|---:|---:|")
 for e in rows[:14]:
