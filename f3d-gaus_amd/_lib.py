@@ -59,6 +59,12 @@ SIGNATURES = {
     "f3dg_pack_frames": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "f3dg_group_norm_silu": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
     "f3dg_group_norm_silu_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
+    "f3dg_group_norm_silu_pb": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p]),
+    "f3dg_group_norm_silu_pb_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p]),
+    "f3dg_group_norm_silu_nhwc_pb": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
+    "f3dg_group_norm_silu_nhwc_pb_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
+    "f3dg_residual_join": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p]),
+    "f3dg_residual_join_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p]),
     "f3dg_group_norm_silu_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p]),
     "f3dg_group_norm_silu_nhwc_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p]),
     "f3dg_set_option": (_i, [C.c_char_p, _i]),

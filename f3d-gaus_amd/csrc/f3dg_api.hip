@@ -155,7 +155,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_fused_rects") == 0) { g_f3dg_sort_fused_rects = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "pre_order") == 0) { g_f3dg_pre_order = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "pre_order") == 0) { g_f3dg_pre_order = value & 3; return F3DG_OK; }
     if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
     return F3DG_ERR_BAD_ARG;
 }

@@ -47,15 +47,27 @@ template <> struct Packet<unsigned short> {
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
+// SiLU. float32 activations: expf and an IEEE division (the backbone's float32 parity bar is 2e-5 of the reference fixture).
+// bfloat16 activations: the result is rounded to 8 bits, so hardware exp2 / reciprocal (~1 ulp of float32 each) are invisible and the
+// ~30 instructions per element of the accurate form -- which made the kernel VALU-bound -- become 5.
+template <typename T> __device__ __forceinline__ float silu_of(float v)
+{
+    if constexpr (sizeof(T) == 2)
+        return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+    else
+        return v / (1.0f + expf(-v));
+}
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(unsigned short x) { return bf16_to_f32(x); }
 __device__ __forceinline__ void from_f32(float& d, float x) { d = x; }
 __device__ __forceinline__ void from_f32(unsigned short& d, float x) { d = f32_to_bf16(x); }
 
-// T = float, or unsigned short holding bfloat16 (the bf16 option of the backbone: statistics and arithmetic stay float32 / float64)
+// T = float, or unsigned short holding bfloat16 (the bf16 option of the backbone: statistics and arithmetic stay float32 / float64).
+// pre_bias (nullable, [C] float32): added to x on the way in -- the bias of the convolution that produced x, which PyTorch-ROCm would
+// otherwise apply as a separate read + write pass behind MIOpen's kernel (108 such passes per backbone pass, profiles/r04_final/unet.md).
 template <typename T>
 __global__ void __launch_bounds__(GN_THREADS)
-group_norm_silu_kernel(int C, int HW, int groups, const T* __restrict__ x, const float* __restrict__ weight,
+group_norm_silu_kernel(int C, int HW, int groups, const T* __restrict__ x, const float* __restrict__ pre_bias, const float* __restrict__ weight,
                        const float* __restrict__ bias, float eps, int apply_silu, T* __restrict__ y)
 {
     constexpr int PN = Packet<T>::N;
@@ -70,17 +82,19 @@ group_norm_silu_kernel(int C, int HW, int groups, const T* __restrict__ x, const
     double s1 = 0.0, s2 = 0.0;
     const bool vec = HW % PN == 0;                                // true for every layer of the backbone at 256^2 / 32^2
     const size_t np = vec ? slab / PN : 0;
+    const int hwp = vec ? HW / PN : 1;
     for (size_t i = threadIdx.x; i < np; i += GN_THREADS) {
         Packet<T> p;
         p.load(xs + i * PN);
+        const float pb = pre_bias ? pre_bias[g * Cg + (int)(i / hwp)] : 0.0f;
         float a = 0.0f, b = 0.0f;
 #pragma unroll
-        for (int k = 0; k < PN; k++) { a += p.v[k]; b += p.v[k] * p.v[k]; }
+        for (int k = 0; k < PN; k++) { const float v = p.v[k] + pb; a += v; b += v * v; }
         s1 += (double)a;
         s2 += (double)b;
     }
     for (size_t i = np * PN + threadIdx.x; i < slab; i += GN_THREADS) {
-        const float v = to_f32(xs[i]);
+        const float v = to_f32(xs[i]) + (pre_bias ? pre_bias[g * Cg + (int)(i / HW)] : 0.0f);
         s1 += v; s2 += (double)(v * v);
     }
 #pragma unroll
@@ -107,17 +121,17 @@ group_norm_silu_kernel(int C, int HW, int groups, const T* __restrict__ x, const
 
     // ---- normalise, affine, (silu): the slab is re-read from L2
     if (vec) {
-        const int hwp = HW / PN;
         for (size_t i = threadIdx.x; i < np; i += GN_THREADS) {
             const int c = g * Cg + (int)(i / hwp);
+            const float pb = pre_bias ? pre_bias[c] : 0.0f;
             const float sc = weight[c] * rstd;
             const float sh = bias[c] - mean * sc;
             Packet<T> p;
             p.load(xs + i * PN);
 #pragma unroll
             for (int k = 0; k < PN; k++) {
-                float v = p.v[k] * sc + sh;
-                if (apply_silu) v = v / (1.0f + expf(-v));
+                float v = (p.v[k] + pb) * sc + sh;
+                if (apply_silu) v = silu_of<T>(v);
                 p.v[k] = v;
             }
             p.store(ys + i * PN);
@@ -125,23 +139,24 @@ group_norm_silu_kernel(int C, int HW, int groups, const T* __restrict__ x, const
     } else {
         for (size_t i = threadIdx.x; i < slab; i += GN_THREADS) {
             const int c = g * Cg + (int)(i / HW);
+            const float pb = pre_bias ? pre_bias[c] : 0.0f;
             const float sc = weight[c] * rstd;
-            float v = to_f32(xs[i]) * sc + (bias[c] - mean * sc);
-            if (apply_silu) v = v / (1.0f + expf(-v));
+            float v = (to_f32(xs[i]) + pb) * sc + (bias[c] - mean * sc);
+            if (apply_silu) v = silu_of<T>(v);
             from_f32(ys[i], v);
         }
     }
 }
 
 template <typename T>
-int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const float* weight, const float* bias, float eps,
+int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const float* pre_bias, const float* weight, const float* bias, float eps,
               int apply_silu, T* y)
 {
     if (N < 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0 || !x || !weight || !bias || !y) return F3DG_ERR_BAD_ARG;
     if (N == 0) return F3DG_OK;
     if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;       // 16-byte loads / stores
     F3DG_KLAUNCH(group_norm_silu_kernel<T>, dim3((unsigned)(N * groups)), dim3(GN_THREADS), 0, (hipStream_t)stream, C, HW,
-                       groups, x, weight, bias, eps, apply_silu, y);
+                       groups, x, pre_bias, weight, bias, eps, apply_silu, y);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
@@ -154,14 +169,16 @@ int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const 
 //   gn_nhwc_moments_kernel: thread (row, col) owns the 16-byte packet `col` of the pixels row, row + rows, ...: float sums per channel
 //       over at most GN_NHWC_PIX / rows pixels, per-channel totals over the rows in LDS, per-group totals added in float64 (atomics) to
 //       moments[n][g] = (sum, sum of squares);
-//   gn_nhwc_apply_kernel: the same mapping; scale / shift of the thread's PN channels once, then one pass: silu(x * sc + sh).
+//   gn_nhwc_apply_kernel: the same mapping; scale / shift of the thread's PN channels once, then one pass: silu((x + pre_bias) * sc + sh).
 // Two reads (the second from L2 / MALL) and one write, as the NCHW kernel.
-constexpr int GN_NHWC_PIX = 256;      // pixels per workgroup
+constexpr int GN_NHWC_PIX = 512;      // pixels per workgroup
+constexpr int GN_NHWC_SLOTS = 8;      // copies of the moments the workgroups of a sample spread their atomics over
 constexpr int GN_NHWC_MAXC = 1024;
+constexpr int GN_NHWC_UNROLL = 4;     // independent 16-byte loads in flight per thread
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-gn_nhwc_moments_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, double* __restrict__ moments)
+gn_nhwc_moments_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, const float* __restrict__ pre_bias, double* __restrict__ moments)
 {
     constexpr int PN = Packet<T>::N;
     const int ppp = C / PN;                                   // packets per pixel
@@ -169,38 +186,53 @@ gn_nhwc_moments_kernel(int C, int HW, int groups, int rows, const T* __restrict_
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * GN_NHWC_PIX;
     const int p1 = min(p0 + GN_NHWC_PIX, HW);
-    float a[PN], b[PN];
+    float a[PN], b[PN], pb[PN];
 #pragma unroll
-    for (int k = 0; k < PN; k++) { a[k] = 0.0f; b[k] = 0.0f; }
+    for (int k = 0; k < PN; k++) { a[k] = 0.0f; b[k] = 0.0f; pb[k] = (pre_bias && row < rows) ? pre_bias[col * PN + k] : 0.0f; }
     if (row < rows) {
         const T* xs = x + ((size_t)n * HW) * C + (size_t)col * PN;
-        for (int p = p0 + row; p < p1; p += rows) {
-            Packet<T> q;
-            q.load(xs + (size_t)p * C);
+        for (int p = p0 + row; p < p1; p += rows * GN_NHWC_UNROLL) {
+            Packet<T> q[GN_NHWC_UNROLL];
 #pragma unroll
-            for (int k = 0; k < PN; k++) { a[k] += q.v[k]; b[k] += q.v[k] * q.v[k]; }
+            for (int u = 0; u < GN_NHWC_UNROLL; u++)
+                if (p + u * rows < p1) q[u].load(xs + (size_t)(p + u * rows) * C);
+#pragma unroll
+            for (int u = 0; u < GN_NHWC_UNROLL; u++)
+                if (p + u * rows < p1) {
+#pragma unroll
+                    for (int k = 0; k < PN; k++) { const float v = q[u].v[k] + pb[k]; a[k] += v; b[k] += v * v; }
+                }
         }
     }
-    __shared__ float sa[GN_NHWC_MAXC], sb[GN_NHWC_MAXC];
-    for (int c = threadIdx.x; c < C; c += blockDim.x) { sa[c] = 0.0f; sb[c] = 0.0f; }
-    __syncthreads();
+    // per-channel totals over the rows: every (row, channel) has its own LDS word (rows * C <= 256 * PN), channel c is summed by thread c
+    __shared__ float sa[256 * PN], sb[256 * PN];
     if (row < rows) {
 #pragma unroll
-        for (int k = 0; k < PN; k++) { atomicAdd(&sa[col * PN + k], a[k]); atomicAdd(&sb[col * PN + k], b[k]); }
+        for (int k = 0; k < PN; k++) { sa[row * C + col * PN + k] = a[k]; sb[row * C + col * PN + k] = b[k]; }
     }
     __syncthreads();
+    __shared__ float ca[GN_NHWC_MAXC], cb[GN_NHWC_MAXC];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t1 = 0.0f, t2 = 0.0f;
+        for (int r = 0; r < rows; r++) { t1 += sa[r * C + c]; t2 += sb[r * C + c]; }
+        ca[c] = t1; cb[c] = t2;
+    }
+    __syncthreads();
+    // per-group totals in float64, added to one of GN_NHWC_SLOTS copies of the (sample, group) pair: a sample's workgroups spread their
+    // atomics over the copies (the apply kernel adds them up) instead of queueing on one address
     const int Cg = C / groups;
+    double* mslot = moments + 2 * (size_t)(blockIdx.x % GN_NHWC_SLOTS) * gridDim.y * groups;
     for (int g = threadIdx.x; g < groups; g += blockDim.x) {
         double s1 = 0.0, s2 = 0.0;
-        for (int c = g * Cg; c < (g + 1) * Cg; c++) { s1 += (double)sa[c]; s2 += (double)sb[c]; }
-        unsafeAtomicAdd(&moments[2 * ((size_t)n * groups + g)], s1);
-        unsafeAtomicAdd(&moments[2 * ((size_t)n * groups + g) + 1], s2);
+        for (int c = g * Cg; c < (g + 1) * Cg; c++) { s1 += (double)ca[c]; s2 += (double)cb[c]; }
+        unsafeAtomicAdd(&mslot[2 * ((size_t)n * groups + g)], s1);
+        unsafeAtomicAdd(&mslot[2 * ((size_t)n * groups + g) + 1], s2);
     }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, const double* __restrict__ moments,
+gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, const float* __restrict__ pre_bias, const double* __restrict__ moments,
                      const float* __restrict__ weight, const float* __restrict__ bias, float eps, int apply_silu, T* __restrict__ y)
 {
     constexpr int PN = Packet<T>::N;
@@ -212,7 +244,7 @@ gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ 
     const int p1 = min(p0 + GN_NHWC_PIX, HW);
     const int Cg = C / groups;
     const double cnt = (double)Cg * (double)HW;
-    float sc[PN], sh[PN];
+    float sc[PN], sh[PN], pb[PN];
     {
         int g_prev = -1;
         float mean = 0.0f, rstd = 0.0f;
@@ -220,8 +252,13 @@ gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ 
         for (int k = 0; k < PN; k++) {
             const int c = col * PN + k, g = c / Cg;
             if (g != g_prev) {
-                const double m = moments[2 * ((size_t)n * groups + g)] / cnt;
-                double var = moments[2 * ((size_t)n * groups + g) + 1] / cnt - m * m;
+                double m1 = 0.0, m2 = 0.0;
+                for (int sl = 0; sl < GN_NHWC_SLOTS; sl++) {
+                    const double* ms = moments + 2 * ((size_t)sl * gridDim.y * groups + (size_t)n * groups + g);
+                    m1 += ms[0]; m2 += ms[1];
+                }
+                const double m = m1 / cnt;
+                double var = m2 / cnt - m * m;
                 if (var < 0.0) var = 0.0;
                 mean = (float)m;
                 rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -229,24 +266,31 @@ gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ 
             }
             sc[k] = weight[c] * rstd;
             sh[k] = bias[c] - mean * sc[k];
+            pb[k] = pre_bias ? pre_bias[c] : 0.0f;
         }
     }
     const size_t base = ((size_t)n * HW) * C + (size_t)col * PN;
-    for (int p = p0 + row; p < p1; p += rows) {
-        Packet<T> q;
-        q.load(x + base + (size_t)p * C);
+    for (int p = p0 + row; p < p1; p += rows * GN_NHWC_UNROLL) {
+        Packet<T> q[GN_NHWC_UNROLL];
 #pragma unroll
-        for (int k = 0; k < PN; k++) {
-            float v = q.v[k] * sc[k] + sh[k];
-            if (apply_silu) v = v / (1.0f + expf(-v));
-            q.v[k] = v;
-        }
-        q.store(y + base + (size_t)p * C);
+        for (int u = 0; u < GN_NHWC_UNROLL; u++)
+            if (p + u * rows < p1) q[u].load(x + base + (size_t)(p + u * rows) * C);
+#pragma unroll
+        for (int u = 0; u < GN_NHWC_UNROLL; u++)
+            if (p + u * rows < p1) {
+#pragma unroll
+                for (int k = 0; k < PN; k++) {
+                    float v = (q[u].v[k] + pb[k]) * sc[k] + sh[k];
+                    if (apply_silu) v = silu_of<T>(v);
+                    q[u].v[k] = v;
+                }
+                q[u].store(y + base + (size_t)(p + u * rows) * C);
+            }
     }
 }
 
 template <typename T>
-int launch_gn_nhwc(void* stream, int N, int C, int HW, int groups, const T* x, const float* weight, const float* bias, float eps,
+int launch_gn_nhwc(void* stream, int N, int C, int HW, int groups, const T* x, const float* pre_bias, const float* weight, const float* bias, float eps,
                    int apply_silu, T* y, double* moments)
 {
     constexpr int PN = Packet<T>::N;
@@ -256,37 +300,155 @@ int launch_gn_nhwc(void* stream, int N, int C, int HW, int groups, const T* x, c
     if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;
     const int ppp = C / PN, rows = 256 / ppp;
     hipStream_t s = (hipStream_t)stream;
-    F3DG_HIP_CHECK(hipMemsetAsync(moments, 0, sizeof(double) * 2 * (size_t)N * groups, s));
+    F3DG_HIP_CHECK(hipMemsetAsync(moments, 0, sizeof(double) * 2 * GN_NHWC_SLOTS * (size_t)N * groups, s));
     const dim3 grid((unsigned)((HW + GN_NHWC_PIX - 1) / GN_NHWC_PIX), (unsigned)N);
-    F3DG_KLAUNCH(gn_nhwc_moments_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, moments);
-    F3DG_KLAUNCH(gn_nhwc_apply_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, moments, weight, bias, eps, apply_silu, y);
+    F3DG_KLAUNCH(gn_nhwc_moments_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, pre_bias, moments);
+    F3DG_KLAUNCH(gn_nhwc_apply_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, pre_bias, moments, weight, bias, eps, apply_silu, y);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+// ---- the residual join of a block -------------------------------------------------------------------------------------------------
+// y = ((a + bias_a[c]) + (b + bias_b[c])) * scale, the three elementwise passes behind a residual block's second convolution
+// (reference src/gaussian_predictor.py:325-327: `x = conv1(...)` [+ bias], `x = x + skip(orig)` [+ bias], `x = x * skip_scale`) in one:
+// same float32 operations in the same order, rounded to the activation type once. nhwc = 0: [N][C][HW], channel = (i / HW) % C;
+// nhwc = 1: [N][HW][C], channel = i % C. Either bias may be null. y may be a or b.
+template <typename T>
+__global__ void __launch_bounds__(256)
+residual_join_kernel(size_t n_packets, int C, int HW, int nhwc, int packet_in_channel, const T* __restrict__ a, const float* __restrict__ bias_a,
+                     const T* __restrict__ b, const float* __restrict__ bias_b, float scale, T* __restrict__ y)
+{
+    constexpr int PN = Packet<T>::N;
+    const size_t first = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (nhwc) {
+        // channels-last: C is a multiple of PN and the launch makes the stride a multiple of the packets per pixel, so a thread meets the
+        // same PN channels in every iteration: its 2 PN bias values are loaded once (as 2 PN loads per packet they were what bounded
+        // the first version of this kernel: 19 memory instructions per packet of which 3 moved data)
+        const int c0 = (int)((first * PN) % (size_t)C);
+        float ba[PN], bb[PN];
+#pragma unroll
+        for (int k = 0; k < PN; k++) { ba[k] = bias_a ? bias_a[c0 + k] : 0.0f; bb[k] = bias_b ? bias_b[c0 + k] : 0.0f; }
+        for (size_t i = first; i < n_packets; i += stride) {
+            Packet<T> pa, pb;
+            pa.load(a + i * PN);
+            pb.load(b + i * PN);
+#pragma unroll
+            for (int k = 0; k < PN; k++) {
+                const float va = bias_a ? pa.v[k] + ba[k] : pa.v[k];
+                const float vb = bias_b ? pb.v[k] + bb[k] : pb.v[k];
+                pa.v[k] = (va + vb) * scale;
+            }
+            pa.store(y + i * PN);
+        }
+        return;
+    }
+    for (size_t i = first; i < n_packets; i += stride) {
+        Packet<T> pa, pb;
+        pa.load(a + i * PN);
+        pb.load(b + i * PN);
+        const size_t e0 = i * PN;
+        // NCHW with HW a multiple of PN: a packet stays inside a channel plane; otherwise element by element
+        const int c0 = (int)((e0 / (size_t)HW) % (size_t)C);
+        const float ba0 = bias_a ? bias_a[c0] : 0.0f, bb0 = bias_b ? bias_b[c0] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < PN; k++) {
+            float ba = ba0, bb = bb0;
+            if (!packet_in_channel) {
+                const int c = (int)(((e0 + k) / (size_t)HW) % (size_t)C);
+                ba = bias_a ? bias_a[c] : 0.0f; bb = bias_b ? bias_b[c] : 0.0f;
+            }
+            const float va = bias_a ? pa.v[k] + ba : pa.v[k];
+            const float vb = bias_b ? pb.v[k] + bb : pb.v[k];
+            pa.v[k] = (va + vb) * scale;
+        }
+        pa.store(y + i * PN);
+    }
+}
+
+template <typename T>
+int launch_join(void* stream, int N, int C, int HW, int nhwc, const T* a, const float* bias_a, const T* b, const float* bias_b, float scale, T* y)
+{
+    constexpr int PN = Packet<T>::N;
+    if (N < 0 || C <= 0 || HW <= 0 || !a || !b || !y) return F3DG_ERR_BAD_ARG;
+    const size_t total = (size_t)N * C * HW;
+    if (total == 0) return F3DG_OK;
+    if (total % PN != 0 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15u)) return F3DG_ERR_BAD_ARG;
+    if (nhwc && C % PN != 0) return F3DG_ERR_BAD_ARG;
+    const size_t np = total / PN;
+    // channels-last: blocks * 256 must be a multiple of the packets per pixel (C / PN), which the kernel relies on
+    unsigned blocks = (unsigned)((np + 255) / 256 < 16383 ? (np + 255) / 256 : 16383);
+    if (nhwc) {
+        const unsigned ppp = (unsigned)(C / PN);
+        unsigned m = ppp;                       // smallest block count whose 256-fold is a multiple of ppp: ppp / gcd(ppp, 256)
+        for (unsigned t = 256; t > 1 && (m % 2u) == 0; t >>= 1) m >>= 1;
+        blocks = ((blocks + m - 1) / m) * m;
+    }
+    F3DG_KLAUNCH(residual_join_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, np, C, HW, nhwc, HW % PN == 0 ? 1 : 0, a, bias_a, b, bias_b, scale, y);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
 
 } // namespace
 
-// GroupNorm (+ SiLU) of a channels-last tensor, x and y [N][HW][C]; `moments` is scratch of 2 * N * groups doubles (zeroed here)
+extern "C" int f3dg_residual_join(void* stream, int N, int C, int HW, int nhwc, const float* a, const float* bias_a, const float* b,
+                                  const float* bias_b, float scale, float* y)
+{
+    return launch_join<float>(stream, N, C, HW, nhwc, a, bias_a, b, bias_b, scale, y);
+}
+
+extern "C" int f3dg_residual_join_bf16(void* stream, int N, int C, int HW, int nhwc, const uint16_t* a, const float* bias_a, const uint16_t* b,
+                                       const float* bias_b, float scale, uint16_t* y)
+{
+    return launch_join<unsigned short>(stream, N, C, HW, nhwc, a, bias_a, b, bias_b, scale, y);
+}
+
+// GroupNorm (+ SiLU) with the producing convolution's bias folded in (pre_bias, nullable): NCHW ...
+extern "C" int f3dg_group_norm_silu_pb(void* stream, int N, int C, int HW, int groups, const float* x, const float* pre_bias, const float* weight,
+                                       const float* bias, float eps, int apply_silu, float* y)
+{
+    return launch_gn<float>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y);
+}
+
+extern "C" int f3dg_group_norm_silu_pb_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias, const float* weight,
+                                            const float* bias, float eps, int apply_silu, uint16_t* y)
+{
+    return launch_gn<unsigned short>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y);
+}
+
+// ... and channels-last
+extern "C" int f3dg_group_norm_silu_nhwc_pb(void* stream, int N, int C, int HW, int groups, const float* x, const float* pre_bias, const float* weight,
+                                            const float* bias, float eps, int apply_silu, float* y, double* moments)
+{
+    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y, moments);
+}
+
+extern "C" int f3dg_group_norm_silu_nhwc_pb_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
+                                                 const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments)
+{
+    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y, moments);
+}
+
+// GroupNorm (+ SiLU) of a channels-last tensor, x and y [N][HW][C]; `moments` is scratch of 2 * GN_NHWC_SLOTS (= 8) * N * groups doubles (zeroed here)
 extern "C" int f3dg_group_norm_silu_nhwc(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
                                          const float* bias, float eps, int apply_silu, float* y, double* moments)
 {
-    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y, moments);
+    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y, moments);
 }
 
 extern "C" int f3dg_group_norm_silu_nhwc_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
                                               const float* bias, float eps, int apply_silu, uint16_t* y, double* moments)
 {
-    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y, moments);
+    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y, moments);
 }
 
 extern "C" int f3dg_group_norm_silu(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
                                     const float* bias, float eps, int apply_silu, float* y)
 {
-    return launch_gn<float>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y);
+    return launch_gn<float>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y);
 }
 
 extern "C" int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
                                          const float* bias, float eps, int apply_silu, uint16_t* y)
 {
-    return launch_gn<unsigned short>(stream, N, C, HW, groups, x, weight, bias, eps, apply_silu, y);
+    return launch_gn<unsigned short>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y);
 }

@@ -233,8 +233,8 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
     }
     // chunk_major (option pre_order = 1): blockIdx.x is the VIEW, so the workgroups that follow each other in dispatch order are the
     // views of ONE chunk of 256 Gaussians and its 23 KB of inputs are fetched once per XCD instead of once per view
-    const int g = (chunk_major ? blockIdx.y : blockIdx.x) * F3DG_BLOCK + threadIdx.x;
-    const int v = chunk_major ? blockIdx.x : blockIdx.y;
+    const int g = ((chunk_major & 1) ? blockIdx.y : blockIdx.x) * F3DG_BLOCK + threadIdx.x;
+    const int v = (chunk_major & 1) ? blockIdx.x : blockIdx.y;
     const size_t gs = (size_t)(v / views_per_set) * P + g;       // this view's Gaussian set: inputs are [n_sets, P, ...]
     if (g >= P)
         return;
@@ -524,10 +524,19 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
     // (behind the camera, off screen, or -- with tile culling -- nowhere above alpha 1/255) does not write its 80 bytes. (SAVE_AUX
     // calls write them all: the debug export hands the arrays out whole.)
     if (SAVE_AUX || my_tiles != 0u) {
-        cull_out[idx] = ce;
         r3.w = cec;                         // record slot 15: the ellipse's c (the depth lives in depths_out)
         float4* dst = reinterpret_cast<float4*>(rec + idx);
-        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+        if (chunk_major & 2) {
+            // (option pre_order bit 1: the 80 bytes per pair that nothing reads before the compositing kernel leave as streaming
+            // stores, so that they do not push the chunk's inputs -- and the keys / rectangles the binning stage reads next -- out of L2)
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            auto nt = [](float4* p, const float4& v) { f4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<f4*>(p)); };
+            nt(cull_out + idx, ce);
+            nt(dst, r0); nt(dst + 1, r1); nt(dst + 2, r2); nt(dst + 3, r3);
+        } else {
+            cull_out[idx] = ce;
+            dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+        }
     }
     if (SAVE_AUX) {                         // planes only the backward and the debug export read
         tiles_touched[idx] = my_tiles;
@@ -560,8 +569,8 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int chunks = (P + F3DG_BLOCK - 1) / F3DG_BLOCK;
-    const int chunk_major = g_f3dg_pre_order != 0 && chunks <= 65535;
-    dim3 grid(chunk_major ? V : chunks, chunk_major ? chunks : V, 1);
+    const int chunk_major = ((g_f3dg_pre_order & 1) && chunks <= 65535 ? 1 : 0) | (g_f3dg_pre_order & 2);
+    dim3 grid((chunk_major & 1) ? V : chunks, (chunk_major & 1) ? chunks : V, 1);
 #define F3DG_LAUNCH_PRE(AUX) F3DG_KLAUNCH(preprocess_kernel<AUX>, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales,     \
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,                          \
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,                                          \

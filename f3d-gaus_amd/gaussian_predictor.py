@@ -75,7 +75,9 @@ class Conv2d(nn.Module):
         # present in the reference state_dict for resampling convs (persistent buffer, value 0.25 everywhere)
         self.register_buffer('resample_filter', torch.full((1, 1, 2, 2), 0.25) if (up or down) else None)
 
-    def forward(self, x, N_views_xa=1):
+    def forward(self, x, N_views_xa=1, bias=True):
+        """``bias=False``: the convolution without its bias -- the caller hands ``self.bias`` to the kernel that consumes the result
+        (GroupNorm's ``pre_bias`` / the residual join), which saves the separate bias pass PyTorch-ROCm runs behind MIOpen's kernel."""
         if self.up:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
         if self.down:
@@ -84,7 +86,7 @@ class Conv2d(nn.Module):
             w = self.weight.to(x.dtype)
             if _is_nhwc(x) and not _is_nhwc(w) and w.shape[1] > 1:      # layout option "nhwc": the filter in the activations' layout
                 w = w.contiguous(memory_format=torch.channels_last)
-            x = F.conv2d(x, w, self.bias.to(x.dtype), padding=self.weight.shape[-1] // 2)
+            x = F.conv2d(x, w, self.bias.to(x.dtype) if bias else None, padding=self.weight.shape[-1] // 2)
         return x
 
 
@@ -96,32 +98,63 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_channels))
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
-    def forward(self, x, N_views_xa=1, silu=False):
+    def _fusable(self, x):
+        """Inference on a HIP device in a dtype the kernels take: the fused HIP kernels run (no autograd through them)."""
+        return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 3 and self.weight.dtype == torch.float32 and not (
+            torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))
+
+    def forward(self, x, N_views_xa=1, silu=False, pre_bias=None):
         """``silu=True`` returns ``F.silu(group_norm(x))``: the pair the residual blocks always apply together. In
         inference on a HIP device the pair is ONE fused kernel (``f3dg_group_norm_silu``); with autograd
-        or on the host (the CPU fixtures of the backbone) it is the two PyTorch ops."""
-        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 3 and self.weight.dtype == torch.float32 and not (
-                torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+        or on the host (the CPU fixtures of the backbone) it is the two PyTorch ops. ``pre_bias`` ([C] float32): the result is
+        that of ``x + pre_bias[None, :, None, None]`` -- the bias of the convolution that produced ``x`` (``Conv2d.forward(bias=False)``)."""
+        if self._fusable(x) and (pre_bias is None or pre_bias.dtype == torch.float32):
+            L = _lib.lib()
             if _is_nhwc(x) and x.shape[1] % (4 if x.dtype == torch.float32 else 8) == 0 and x.shape[1] <= 1024:
                 # layout option "nhwc": the channels-last kernel, channels-last out
                 y = torch.empty_like(x)           # preserves the strides
                 N, Cc = x.shape[0], x.shape[1]
-                mom = torch.empty(2 * N * self.num_groups, dtype=torch.float64, device=x.device)
-                fn = _lib.lib().f3dg_group_norm_silu_nhwc if x.dtype == torch.float32 else _lib.lib().f3dg_group_norm_silu_nhwc_bf16
-                rc = fn(_stream(), N, Cc, x.shape[2] * x.shape[3], self.num_groups, _lib.ptr(x), _lib.ptr(self.weight), _lib.ptr(self.bias),
-                        float(self.eps), 1 if silu else 0, _lib.ptr(y), _lib.ptr(mom))
-                _lib.check(rc, "f3dg_group_norm_silu_nhwc")
+                mom = torch.empty(2 * 8 * N * self.num_groups, dtype=torch.float64, device=x.device)     # GN_NHWC_SLOTS copies
+                fn = L.f3dg_group_norm_silu_nhwc_pb if x.dtype == torch.float32 else L.f3dg_group_norm_silu_nhwc_pb_bf16
+                rc = fn(_stream(), N, Cc, x.shape[2] * x.shape[3], self.num_groups, _lib.ptr(x), _lib.ptr(pre_bias), _lib.ptr(self.weight),
+                        _lib.ptr(self.bias), float(self.eps), 1 if silu else 0, _lib.ptr(y), _lib.ptr(mom))
+                _lib.check(rc, "f3dg_group_norm_silu_nhwc_pb")
                 return y
             xc = x.contiguous()
             y = torch.empty_like(xc)
             N, Cc = xc.shape[0], xc.shape[1]
-            fn = _lib.lib().f3dg_group_norm_silu if x.dtype == torch.float32 else _lib.lib().f3dg_group_norm_silu_bf16
-            rc = fn(_stream(), N, Cc, xc.numel() // max(N * Cc, 1), self.num_groups, _lib.ptr(xc), _lib.ptr(self.weight),
+            fn = L.f3dg_group_norm_silu_pb if x.dtype == torch.float32 else L.f3dg_group_norm_silu_pb_bf16
+            rc = fn(_stream(), N, Cc, xc.numel() // max(N * Cc, 1), self.num_groups, _lib.ptr(xc), _lib.ptr(pre_bias), _lib.ptr(self.weight),
                     _lib.ptr(self.bias), float(self.eps), 1 if silu else 0, _lib.ptr(y))
-            _lib.check(rc, "f3dg_group_norm_silu")
+            _lib.check(rc, "f3dg_group_norm_silu_pb")
             return y
+        if pre_bias is not None:
+            x = x + pre_bias.to(x.dtype).reshape(1, -1, *([1] * (x.dim() - 2)))
         y = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
         return F.silu(y) if silu else y
+
+
+def residual_join(a, bias_a, b, bias_b, scale):
+    """((a + bias_a) + (b + bias_b)) * scale with per-channel biases (either may be None): the tail of a residual block. One HIP
+    kernel (``f3dg_residual_join``) for inference tensors on a HIP device that share a dense layout (NCHW or channels-last); the
+    PyTorch ops otherwise. Writes into ``a``'s storage when it can."""
+    def tb(t, bias):
+        return t if bias is None else t + bias.to(t.dtype).reshape(1, -1, 1, 1)
+    ok = (a.is_cuda and a.dim() == 4 and a.dtype in (torch.float32, torch.bfloat16) and b.dtype == a.dtype and a.shape == b.shape
+          and not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad))
+          and all(t is None or (t.dtype == torch.float32 and t.is_contiguous()) for t in (bias_a, bias_b))
+          and a.numel() % (4 if a.dtype == torch.float32 else 8) == 0)
+    if ok:
+        nhwc = _is_nhwc(a)
+        same = (_is_nhwc(b) if nhwc else b.is_contiguous()) and (nhwc or a.is_contiguous()) and not (
+            nhwc and a.shape[1] % (4 if a.dtype == torch.float32 else 8))
+        if same and (a.data_ptr() | b.data_ptr()) % 16 == 0:
+            N, Cc, H, W = a.shape
+            fn = _lib.lib().f3dg_residual_join if a.dtype == torch.float32 else _lib.lib().f3dg_residual_join_bf16
+            _lib.check(fn(_stream(), N, Cc, H * W, 1 if nhwc else 0, _lib.ptr(a), _lib.ptr(bias_a), _lib.ptr(b), _lib.ptr(bias_b), float(scale),
+                          _lib.ptr(a)), "f3dg_residual_join")
+            return a
+    return (tb(a, bias_a) + tb(b, bias_b)) * scale
 
 
 class UNetBlock(nn.Module):
@@ -148,11 +181,23 @@ class UNetBlock(nn.Module):
 
     def forward(self, x, emb=None, N_views_xa=1):
         orig = x
-        x = self.conv0(self.norm0(x, silu=True))
-        x = self.norm1(x, silu=True)
-        x = self.conv1(F.dropout(x, p=self.dropout, training=self.training))
-        x = x + (self.skip(orig) if self.skip is not None else orig)
-        x = x * self.skip_scale
+        if self.norm0._fusable(x) and not self.training:
+            # inference on a HIP device: the three convolutions run without their biases, which go to the kernels that read the results
+            # (norm1 takes conv0's; the residual join takes conv1's and the skip convolution's, adds, and scales): same float32
+            # operations in the same order as the lines below, five elementwise passes fewer
+            x = self.conv0(self.norm0(x, silu=True), bias=False)
+            x = self.norm1(x, silu=True, pre_bias=self.conv0.bias)
+            x = self.conv1(x, bias=False)
+            if self.skip is not None:
+                x = residual_join(x, self.conv1.bias, self.skip(orig, bias=False), self.skip.bias, self.skip_scale)
+            else:
+                x = residual_join(x, self.conv1.bias, orig, None, self.skip_scale)
+        else:
+            x = self.conv0(self.norm0(x, silu=True))
+            x = self.norm1(x, silu=True)
+            x = self.conv1(F.dropout(x, p=self.dropout, training=self.training))
+            x = x + (self.skip(orig) if self.skip is not None else orig)
+            x = x * self.skip_scale
         if self.num_heads:
             if N_views_xa != 1:      # fold the views into the token axis (gaussian_predictor.py:333-338)
                 B, Cc, H, W = x.shape
@@ -309,9 +354,10 @@ class GaussianSplatPredictor_gtunet(nn.Module):
         # extension: "bf16" runs the backbone's convolutions under bfloat16 autocast with bf16 activations between
         # the layers (GroupNorm statistics, attention and the splat head stay float32); "fp32" (default) is the reference's precision
         self.backbone_dtype = str(m.get('backbone_dtype', 'fp32'))
-        # extension: "nhwc" keeps the backbone's activations (and filters) channels-last, the layout of MIOpen's fastest kernels on
-        # gfx950 -- GroupNorm+SiLU is the channels-last HIP kernel, nothing converts in between; "nchw" (default) is torch's layout
-        self.backbone_layout = str(m.get('backbone_layout', 'nchw'))
+        # extension: "nhwc" (default for inference on a HIP device) keeps the backbone's activations and filters channels-last, the layout
+        # of MIOpen's fastest kernels on gfx950 -- GroupNorm+SiLU and the residual join are channels-last HIP kernels, nothing converts in
+        # between (fp32 pass 92 -> 81 ms, bf16 30 -> 24 ms per 8 images; the reference fixture within 1.0e-5); "nchw" is torch's layout
+        self.backbone_layout = str(m.get('backbone_layout', 'nhwc'))
         if self.backbone_layout not in ("nchw", "nhwc"):
             raise ValueError("backbone_layout must be 'nchw' or 'nhwc'")
         self.init_ray_dirs()

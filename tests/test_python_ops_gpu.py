@@ -310,6 +310,55 @@ def test_group_norm_silu_channels_last_kernel(gpu_device):
                         assert err <= 2.0 ** -8 * max(1.0, ref.abs().max().item()), (N, Cc, H, W, silu, err)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_bias_folding_and_residual_join(dtype, gpu_device):
+    """GroupNorm(pre_bias=) and residual_join() -- the kernels that take over the convolutions' bias passes and the residual add + scale
+    of a block (f3dg_group_norm_silu*_pb, f3dg_residual_join) -- against the unfused PyTorch expressions, in both layouts; and a whole
+    residual block through the fused path against the same block through the unfused lines."""
+    from f3dgaus_amd import gaussian_predictor as gp
+    dt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    tol = 2e-6 if dtype == "fp32" else 2.0 ** -7
+    torch.manual_seed(5)
+    for (N, Cc, H, W) in ((2, 128, 32, 32), (1, 384, 12, 10), (2, 36, 10, 6)):
+        gn = gp.GroupNorm(Cc, eps=1e-6).to(gpu_device)
+        with torch.no_grad():
+            gn.weight.uniform_(0.5, 1.5); gn.bias.uniform_(-0.5, 0.5)
+            pb = torch.randn(Cc, device=gpu_device)
+            x = (torch.randn(N, Cc, H, W, device=gpu_device) * 2 + 0.5).to(dt)
+            b = torch.randn(N, Cc, H, W, device=gpu_device).to(dt)
+            pb2 = torch.randn(Cc, device=gpu_device)
+            for layout in ("nchw", "nhwc"):
+                if layout == "nhwc" and Cc % 8:
+                    continue
+                conv = (lambda t: t.contiguous(memory_format=torch.channels_last)) if layout == "nhwc" else (lambda t: t.contiguous())
+                xl, bl = conv(x), conv(b)
+                y = gn(xl, silu=True, pre_bias=pb)
+                ref = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double() + pb.double().reshape(1, -1, 1, 1), gn.num_groups,
+                                                                              gn.weight.double(), gn.bias.double(), gn.eps))
+                assert (y.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()) * (4 if dtype == "fp32" else 1), (N, Cc, layout)
+                for ba, bb in ((pb, pb2), (pb, None), (None, None)):
+                    j = gp.residual_join(xl.clone(), ba, bl, bb, 0.70710678)
+                    rj = ((x.float() + (0 if ba is None else ba.reshape(1, -1, 1, 1))) + (b.float() + (0 if bb is None else bb.reshape(1, -1, 1, 1)))) * 0.70710678
+                    assert j.dtype == dt and (j.float() - rj).abs().max().item() <= tol * max(1.0, rj.abs().max().item()), (N, Cc, layout)
+    # a whole block, with a skip convolution (channel change) and without
+    for cin, cout in ((128, 256), (256, 256)):
+        blk = gp.UNetBlock(cin, cout).to(gpu_device).eval()
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, gp.Conv2d) and m.bias is not None:
+                    m.bias.uniform_(-0.3, 0.3)
+            blk.conv1.weight.mul_(3e4)          # (init_weight 1e-5 would hide conv1 behind the skip path)
+            x = torch.randn(2, cin, 32, 32, device=gpu_device)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == "bf16"):
+                fused = blk(x)
+                blk.train()                      # the unfused lines (dropout p = 0.1 is the only difference: switch it off)
+                blk.dropout = 0.0
+                plain = blk(x)
+                blk.eval()
+            err = (fused.float() - plain.float()).abs().max().item() / plain.float().abs().max().item()
+            assert err <= (2e-6 if dtype == "fp32" else 3e-2), (cin, cout, err)
+
+
 def test_backbone_channels_last_option(gpu_device):
     """cfg['model']['backbone_layout'] = 'nhwc': the backbone with channels-last activations and filters (MIOpen's NHWC kernels, the
     channels-last GroupNorm+SiLU kernel, no layout conversion in between). float32: the reference-generated fixture songunet.npz at the
@@ -341,12 +390,12 @@ def test_backbone_channels_last_option(gpu_device):
     assert e32 < 5e-5 and e16 < 0.25 and rms16 < 0.12, (e32, e16, rms16)
     # wired through the predictor
     cfg = cameras.default_cfg(32)
+    cfg['model']['backbone_layout'] = 'nchw'
     p0 = GaussianSplatPredictor_gtunet(cfg).to(gpu_device).eval()
     cfg2 = cameras.default_cfg(32)
-    cfg2['model']['backbone_layout'] = 'nhwc'
     p1 = GaussianSplatPredictor_gtunet(cfg2).to(gpu_device).eval()
     p1.load_state_dict(p0.state_dict())
-    assert p1.backbone_layout == "nhwc"
+    assert p1.backbone_layout == "nhwc" and p0.backbone_layout == "nchw"        # channels-last is the default
     torch.manual_seed(3)
     xin = torch.rand(2, 1, 4, 32, 32, device=gpu_device)
     rig = cameras.OrbitRig(cfg).canonical

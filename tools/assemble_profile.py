@@ -138,17 +138,20 @@ def main():
         open(os.path.join(dst, "integrate.md"), "w").write("\n".join(out))
 
     # ---- every bench line of the run
-    out = ["# Bench lines of the evidence run (tools/collect_r02.sh), one MI355X", ""]
+    out = ["# Bench lines of the evidence run (tools/collect_r0N.sh), one MI355X", ""]
     for log, cmd in (("bench_default", "python bench.py` (C2; fast arithmetic, the reference arithmetic and the D2H-inclusive rate in one line)"),
                      ("bench_sigma005", "python bench.py --sigma0 0.05 --no-cpu-baseline` (SURVEY 8d's second sweep)"),
                      ("bench_nocull", "python bench.py --tile-cull 0 --no-cpu-baseline` (the reference's tile lists)"),
                      ("bench_589k", "python bench.py --gaussians 589824 --views 128 --no-cpu-baseline` (the merged set of a final orbit)"),
+                     ("bench_real", "python bench.py --data real` (the real image's merged set, 589,824 Gaussians x 128 views)"),
                      ("bench_dropin", "python bench.py --workload dropin --views 60` (render_predicted_more_v2_gof, one view per call, 65,536 Gaussians)"),
                      ("bench_dropin_589k", "python bench.py --workload dropin --views 60 --gaussians 589824`"),
                      ("bench_c5", "python bench.py --workload c5 --steps 3 --warmup 1`"),
                      ("bench_c4_fp32", "python bench.py --workload c4 --images 16 --steps 2 --warmup 1`"),
                      ("bench_c4_bf16", "python bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone bf16`"),
-                     ("bench_c4_bf16_64", "python bench.py --workload c4 --images 64 --steps 1 --warmup 1 --backbone bf16`")):
+                     ("bench_c4_bf16_64", "python bench.py --workload c4 --images 64 --steps 1 --warmup 1 --backbone bf16`"),
+                     ("bench_c4_fp32_nchw", "python bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone-layout nchw`"),
+                     ("bench_c4_bf16_nchw", "python bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone bf16 --backbone-layout nchw`")):
         path = os.path.join(src, log + ".log")
         if os.path.exists(path):
             out += ["`" + cmd + ":", "", "```", last_json(path) or "(no line: " + open(path).read()[-300:] + ")", "```", ""]

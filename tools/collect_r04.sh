@@ -73,8 +73,12 @@ rm -f $O/c5_stats/c5_kernel_trace.csv
 python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 > $O/bench_c4_fp32.log 2>&1
 python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone bf16 > $O/bench_c4_bf16.log 2>&1
 python $R/bench.py --workload c4 --images 64 --steps 1 --warmup 1 --backbone bf16 > $O/bench_c4_bf16_64.log 2>&1
+python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone-layout nchw > $O/bench_c4_fp32_nchw.log 2>&1
+python $R/bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone bf16 --backbone-layout nchw > $O/bench_c4_bf16_nchw.log 2>&1
 # backbone operator tables
-for cfg in "8 fp32" "8 bf16" "8 bf16_resident" "64 fp32" "64 bf16" "64 bf16_resident"; do python $R/tools/prof_unet.py $cfg >> $O/unet.md 2>> $O/unet.err; done
+# (the channels-last layout is the default of the predictor; plain "fp32" / "bf16" = torch's NCHW layout with the same fused kernels)
+for cfg in "8 fp32_nhwc" "8 bf16_nhwc" "64 bf16_nhwc" "8 fp32" "8 bf16" "64 bf16"; do python $R/tools/prof_unet.py $cfg 2>> $O/unet.err | grep -v "^$" | head -64 >> $O/unet.md; done
+python $R/tools/ubench_conv_layout.py 2>/dev/null | grep -v amdgpu > $O/conv_layout.md
 python $R/tools/culled_fraction.py > $O/culled.md 2>&1
 # integrate (Gaussians -> points)
 python $R/tools/bench_integrate.py > $O/bench_integrate.log 2>&1
@@ -86,4 +90,4 @@ cd $R
 python tests/tools/parity_report.py > $O/parity_report.md 2>&1
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
 tail -3 $O/pytest_gpu.log
-for f in bench_default bench_sigma005 bench_nocull bench_589k bench_real bench_dropin bench_c5 bench_c4_fp32 bench_c4_bf16 bench_c4_bf16_64; do grep '^{' $O/$f.log | tail -1 | cut -c1-300; done
+for f in bench_default bench_sigma005 bench_nocull bench_589k bench_real bench_dropin bench_c5 bench_c4_fp32 bench_c4_bf16 bench_c4_bf16_64 bench_c4_fp32_nchw bench_c4_bf16_nchw; do grep '^{' $O/$f.log | tail -1 | cut -c1-300; done

@@ -84,9 +84,24 @@ def main():
         # scheduling"); float64 and transcendental ones for longer, so this is a LOWER bound of the issue-slot utilisation
         valu["issue_utilisation_lower_bound"] = round(valu["SQ_INSTS_VALU"] * 2 / (SIMDS * cycles), 3)
         valu["kernel_us_rocprof"] = kernel_us
+        # the same at the clock the chip actually held during the launch (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8), with the
+        # quarter-rate transcendentals (v_exp / v_rcp / v_rsq: 8 cycles instead of 2) counted: the fraction of all SIMD cycles of the
+        # launch in which a VALU instruction was issuing
+        try:
+            grbm = counters(os.path.join(src, "pmc_grbm"))
+            sq2 = counters(os.path.join(src, "pmc_sq2"))
+            g = [v for k, v in grbm.items() if k == rk and v.get("GRBM_GUI_ACTIVE")]
+            t2 = [v for k, v in sq2.items() if k == rk and v.get("SQ_INSTS_VALU_TRANS_F32")]
+            if g:
+                cyc = sum(g[0]["GRBM_GUI_ACTIVE"]) / len(g[0]["GRBM_GUI_ACTIVE"]) / 8.0
+                trans = (sum(t2[0]["SQ_INSTS_VALU_TRANS_F32"]) / len(t2[0]["SQ_INSTS_VALU_TRANS_F32"])) if t2 else 0.0
+                valu["effective_clock_ghz"] = round(cyc / (kernel_us * 1e3), 3)
+                valu["valu_issue_frac"] = round((valu["SQ_INSTS_VALU"] * 2 + trans * 6) / (SIMDS * cyc), 3)
+        except Exception as ex:      # (older runs have no GRBM pass)
+            valu["valu_issue_frac_error"] = str(ex)
     # HBM traffic of the other two stages per forward call: every kernel of the call that is not the projection / compositing kernel is
     # binning; bytes = 2 x FETCH_SIZE + WRITE_SIZE summed over a call's dispatches (calls = dispatches of preprocess_kernel)
-    n_calls = max(len(fetch.get("preprocess_kernel", {}).get("FETCH_SIZE", [])), 1)
+    n_calls = max(sum(len(v.get("FETCH_SIZE", [])) for k, v in fetch.items() if k.startswith("preprocess_kernel")), 1)
     def stage_bytes(pred):
         tot = 0.0
         for k in fetch:
