@@ -1,11 +1,14 @@
-// f3dg_groupnorm.hip -- fused GroupNorm (+ optional SiLU) for the SongUNet backbone of the predictor.
+// f3dg_groupnorm.hip -- what the SongUNet backbone of the predictor needs between MIOpen's convolutions:
+//   * fused GroupNorm (+ SiLU), NCHW and channels-last, float32 and bfloat16 activations, optionally with the bias of the convolution
+//     that produced the input folded in (f3dg_group_norm_silu*, reference src/gaussian_predictor.py:250-262 GroupNorm, :318-323
+//     `silu(norm(x))`);
+//   * the residual join of a block (f3dg_residual_join, :325-327): second convolution's bias + skip path (+ its bias) + skip_scale.
 //
-// The backbone calls GroupNorm 78 times per pass, each followed by SiLU in the residual blocks
-// (reference src/gaussian_predictor.py:250-262 GroupNorm, :318-323 `silu(norm(x))`). On PyTorch-ROCm that is three
-// bandwidth-bound kernels per call (row moments, scale/shift, silu: five passes over the tensor); here it is ONE kernel:
+// The backbone calls GroupNorm 78 times per pass, each followed by SiLU in the residual blocks. On PyTorch-ROCm that is three
+// bandwidth-bound kernels per call (row moments, scale/shift, silu: five passes over the tensor); the NCHW kernel is ONE:
 // a workgroup owns one (sample, group) slab of Cg x H x W contiguous floats, accumulates sum and sum of squares in
 // float64, and re-reads the slab (<= 1 MiB: L2-resident) to write silu(weight * (x - mean) * rstd + bias). Two HBM
-// passes (one read, one write) instead of five.
+// passes (one read, one write) instead of five. The channels-last pair of kernels is described where it is defined.
 #include "f3dg_common.h"
 
 namespace {

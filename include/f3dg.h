@@ -355,6 +355,13 @@ int f3dg_residual_join_bf16(void* stream, int N, int C, int HW, int nhwc, const 
  * bare `continue` for every pixel of the tile, so all outputs and gradients are unchanged (asserted by the tests on every
  * scene); num_rendered and the exported lists are then SHORTER than the reference's. 0 = the reference's lists, bit for bit.
  * f3dg_integrate always uses the reference's lists.
+ * Round 4, all bit-identical and measured without gain, hence off: "render_tail" (default 0; N > 0: a quadrant's wave of
+ * render3s_fwd_kernel changes to the tail schedule once at most N of its 64 pixels are unsaturated: 64 entries per step, the ellipse test
+ * for the live pixels only, records gathered for the entries some live pixel passes); "sort_fused_rects" (default 0; 1: a view's last
+ * depth-sort pass also delivers its tile rectangles in sorted order instead of gsort_gather_rects_kernel); "pre_order" (default 0;
+ * bit 0: the projection grid runs chunk-major -- the views of one chunk of 256 Gaussians follow each other --, bit 1: the record and
+ * the ellipse leave as non-temporal stores). "render_count" (default 0): the counting variant of render3s_fwd_kernel
+ * (f3dg_debug_render_counts); "render_wpb" (default 1; 4: a tile's four quadrant waves are one workgroup).
  * Returns F3DG_ERR_BAD_ARG for unknown names. */
 int f3dg_set_option(const char* name, int value);
 

@@ -103,6 +103,9 @@ def test_round3_host_logic(f3d):
         assert L.f3dg_set_option(name, 1) == 0, name
     for name, v in ((b"render_kernel", 3), (b"bwd_occ", 5), (b"render_lds_pad", 0), (b"small_debug", 0), (b"time_launches", 0), (b"small_path", 2)):
         assert L.f3dg_set_option(name, v) == 0
+    for name, v in ((b"render_tail", 16), (b"render_tail", -1), (b"sort_fused_rects", 1), (b"sort_fused_rects", 0), (b"pre_order", 3), (b"pre_order", 0),
+                    (b"render_count", 0), (b"render_wpb", 1)):      # round 4's measured-and-off switches
+        assert L.f3dg_set_option(name, v) == 0, name
     assert L.f3dg_set_option(b"no_such_option", 1) == _lib.ERR_BAD_ARG
     assert L.f3dg_debug_launch_count(1) >= 0 and L.f3dg_debug_launch_count(0) == 0
     # the per-tile slots of the small-call path exist for one or two views of at most 2^18 Gaussians only: 4096 x 4 B per (view, tile)
