@@ -728,7 +728,8 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
                      "achieved": gbs(b_bwd, stage_ms[3] / n), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(b_bwd, stage_ms[3] / n) / HBM_PEAK_GBS,
                      "traffic": None, "formula": "80 R + 60 W H V + 68 C (R = instances_per_step, the reference's num_rendered; C = contributing "
                                                  "pairs, counted by the kernel)",
-                     "frac_on_processed_instances": gbs(80.0 * R_proc + 60.0 * RES * RES * V + 68.0 * pairs.value, stage_ms[3] / n) / HBM_PEAK_GBS},
+                     "frac_on_processed_instances": gbs(80.0 * R_proc + 60.0 * RES * RES * V + 68.0 * pairs.value, stage_ms[3] / n) / HBM_PEAK_GBS,
+                     **c5_profile_record(stage_ms[3] / n)},
         "rooflines_other": {
             "render3s_fwd_kernel<SAVE_AUX=true, FAST=false>": {"bound": "hbm", "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": stage_ms[2] / n,
                                                                "achieved": gbs(b_fwd, stage_ms[2] / n), "unit": "GB/s",
@@ -754,6 +755,27 @@ def measured_copy_bandwidth(device, nbytes=1 << 30, reps=5):
     e1.record()
     torch.cuda.synchronize()
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def c5_profile_record(bwd_ms):
+    """Counter figures of the compositing backward from the newest committed C5 profile (profiles/*/c5_traffic.json, written by
+    tools/assemble_profile.py from separate rocprofv3 --pmc passes of `bench.py --workload c5`): the HBM bytes per launch and what
+    fraction of the roofline they are at THIS run's kernel time -- next to the formula's 68 C atomic term, which the wave reduction never issues."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "c5_traffic.json"))):
+        try:
+            best = (f, json.load(open(f)))
+        except Exception:
+            pass
+    if best is None:
+        return {"traffic_from_profiles": None}
+    f, t = best
+    tb = t.get("traffic_bytes_per_launch")
+    return {"traffic_from_profiles": {"bytes_per_launch": tb, "kernel": t.get("kernel"), "source": os.path.relpath(f, os.path.dirname(os.path.abspath(__file__))),
+                                      "note": "builder-side PMC passes, not measured in this run"},
+            "frac_on_counter_traffic": (tb / (bwd_ms * 1e-3) / 8e12) if tb else None,
+            "valu_from_profiles": t.get("valu")}
 
 
 def profiles_record(P, V, RES, views_per_call, mode, tile_cull=1, sigma0=0.01):

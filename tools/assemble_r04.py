@@ -95,7 +95,8 @@ def main():
         ab = sys.argv[3]
         out = ["# A/B lines of round 4's second GPU session (`tools/ab_r04b.sh`): per-stage ms min / median / max over the steps, frame hash", ""]
         for f, title in (("ab_fused.log", "## option sort_fused_rects (the rectangle gather inside a view's last depth pass)"),
-                         ("ab_tail.log", "## option render_tail = N (the tail schedule of the one-wave compositing kernel from at most N live pixels on)")):
+                         ("ab_tail.log", "## option render_tail = N (the tail schedule of the one-wave compositing kernel from at most N live pixels on)"),
+                         ("../r04c/ab_pre_order.log", "## option pre_order (1: chunk-major projection grid, 2: streaming stores for the record + ellipse, 3: both) -- `tools/ab_r04c.sh`")):
             p = os.path.join(ab, f)
             if os.path.exists(p):
                 out += [title, "", "```"] + [x.rstrip() for x in open(p) if "amdgpu.ids" not in x] + ["```", ""]
