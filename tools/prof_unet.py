@@ -18,8 +18,10 @@ from f3dgaus_amd import cameras, gaussian_predictor as gp  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+graph = mode.endswith("_graph")      # ..._graph: the pass replayed from the HIP graph the predictor captures for small batches (wall time only)
+mode = mode.replace("_graph", "")
 nhwc = mode.endswith("_nhwc")        # fp32_nhwc / bf16_nhwc: the channels-last layout option (activations and filters)
-mode_label, mode = mode, mode.replace("_nhwc", "")
+mode_label, mode = mode + ("_graph" if graph else ""), mode.replace("_nhwc", "")
 dev = torch.device("cuda:0")
 cfg = cameras.default_cfg(256)
 torch.manual_seed(0)
@@ -47,14 +49,35 @@ def run():
         return pred.network_with_offset(x)
 
 
+if graph:
+    # the same pass captured into a HIP graph (torch.cuda.CUDAGraph, static input) and replayed: is a small pass bound by host launches?
+    eager = run
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            eager()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_out = eager()
+
+    def run():
+        g.replay()
+        return static_out
 for _ in range(3):
     y = run()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(3):
+for _ in range(10 if graph else 3):
     y = run()
 torch.cuda.synchronize()
-ms = (time.perf_counter() - t0) / 3 * 1e3
+ms = (time.perf_counter() - t0) / (10 if graph else 3) * 1e3
+if graph:
+    ye = eager()
+    print(f"### {B} images, {mode_label}: {ms:.2f} ms per pass (wall, 10 replays); max |graph - eager| = {(y.float() - ye.float()).abs().max().item():.3g} "
+          f"of {ye.float().abs().max().item():.3g}\n")
+    sys.exit(0)
 
 # ---- every convolution of the pass between two HIP events: milliseconds, FLOPs (2 N Cout Hout Wout Cin k^2) and TFLOP/s per shape.
 # (torch's with_flops knows aten::conv2d but the device time sits on aten::miopen_convolution and the kernels below it, so the
