@@ -63,9 +63,10 @@ def parse():
                          "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
     ap.add_argument("--backbone", choices=["fp32", "bf16"], default="fp32",
                     help="c4: precision of the SongUNet backbone (bf16 = the opt-in autocast option, SURVEY 8f-3)")
-    ap.add_argument("--backbone-layout", choices=["nchw", "nhwc"], default="nhwc",
-                    help="c4: memory layout of the SongUNet backbone (nhwc, the default: channels-last activations and filters -- MIOpen's NHWC "
-                         "kernels + the channels-last GroupNorm+SiLU / residual-join kernels; nchw: torch's layout)")
+    ap.add_argument("--backbone-layout", choices=["auto", "nchw", "nhwc"], default="auto",
+                    help="c4: memory layout of the SongUNet backbone (auto, the default: channels-last for passes of two images or more; nhwc: "
+                         "channels-last activations and filters -- MIOpen's NHWC kernels + the channels-last GroupNorm+SiLU / residual-join "
+                         "kernels; nchw: torch's layout)")
     ap.add_argument("--tile-cull", type=int, choices=[0, 1], default=1,
                     help="1 (library default): a Gaussian is instantiated only in the tiles its alpha >= 1/255 ellipse reaches; "
                          "0: the reference's tile lists (every tile of the 3-sigma square)")

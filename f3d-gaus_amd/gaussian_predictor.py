@@ -75,6 +75,31 @@ class Conv2d(nn.Module):
         # present in the reference state_dict for resampling convs (persistent buffer, value 0.25 everywhere)
         self.register_buffer('resample_filter', torch.full((1, 1, 2, 2), 0.25) if (up or down) else None)
 
+    def _filter(self, dtype, nhwc):
+        """The filter in the activations' dtype and layout. In inference the converted copy (bfloat16 under the bf16 option, channels-last
+        under the nhwc layout) is kept until the parameter changes (its version counter or storage) instead of being rebuilt per call:
+        108 cast / transpose kernels per pass otherwise."""
+        w = self.weight
+        nhwc = nhwc and w.shape[1] > 1 and (w.shape[2] > 1 or w.shape[3] > 1)       # (1x1 filters and single-channel ones are both layouts at once)
+        if dtype == w.dtype and not nhwc:
+            return w
+        if torch.is_grad_enabled() and w.requires_grad:
+            t = w.to(dtype)
+            return t.contiguous(memory_format=torch.channels_last) if nhwc else t
+        try:
+            key = (w._version, w.data_ptr(), dtype, nhwc)
+        except RuntimeError:            # (inference-mode tensors have no version counter: no cache)
+            t = w.to(dtype)
+            return t.contiguous(memory_format=torch.channels_last) if nhwc else t
+        cached = self.__dict__.get("_filter_cache")
+        if cached is None or cached[0] != key:
+            t = w.detach().to(dtype)
+            if nhwc:
+                t = t.contiguous(memory_format=torch.channels_last)
+            cached = (key, t)
+            self.__dict__["_filter_cache"] = cached
+        return cached[1]
+
     def forward(self, x, N_views_xa=1, bias=True):
         """``bias=False``: the convolution without its bias -- the caller hands ``self.bias`` to the kernel that consumes the result
         (GroupNorm's ``pre_bias`` / the residual join), which saves the separate bias pass PyTorch-ROCm runs behind MIOpen's kernel."""
@@ -83,10 +108,7 @@ class Conv2d(nn.Module):
         if self.down:
             x = F.avg_pool2d(x, 2)
         if self.weight is not None:
-            w = self.weight.to(x.dtype)
-            if _is_nhwc(x) and not _is_nhwc(w) and w.shape[1] > 1:      # layout option "nhwc": the filter in the activations' layout
-                w = w.contiguous(memory_format=torch.channels_last)
-            x = F.conv2d(x, w, self.bias.to(x.dtype) if bias else None, padding=self.weight.shape[-1] // 2)
+            x = F.conv2d(x, self._filter(x.dtype, _is_nhwc(x)), self.bias.to(x.dtype) if bias else None, padding=self.weight.shape[-1] // 2)
         return x
 
 
@@ -354,12 +376,15 @@ class GaussianSplatPredictor_gtunet(nn.Module):
         # extension: "bf16" runs the backbone's convolutions under bfloat16 autocast with bf16 activations between
         # the layers (GroupNorm statistics, attention and the splat head stay float32); "fp32" (default) is the reference's precision
         self.backbone_dtype = str(m.get('backbone_dtype', 'fp32'))
-        # extension: "nhwc" (default for inference on a HIP device) keeps the backbone's activations and filters channels-last, the layout
-        # of MIOpen's fastest kernels on gfx950 -- GroupNorm+SiLU and the residual join are channels-last HIP kernels, nothing converts in
-        # between (fp32 pass 92 -> 81 ms, bf16 30 -> 24 ms per 8 images; the reference fixture within 1.0e-5); "nchw" is torch's layout
-        self.backbone_layout = str(m.get('backbone_layout', 'nhwc'))
-        if self.backbone_layout not in ("nchw", "nhwc"):
-            raise ValueError("backbone_layout must be 'nchw' or 'nhwc'")
+        # extension: "nhwc" keeps the backbone's activations and filters channels-last, the layout of MIOpen's fastest kernels on gfx950 --
+        # GroupNorm+SiLU and the residual join are channels-last HIP kernels, nothing converts in between (fp32 pass 92 -> 82 ms, bf16
+        # 30 -> 25 ms per 8 images; the reference fixture within 1.0e-5); "nchw" is torch's layout, which is faster for ONE image per pass
+        # (14.7 against 16.9 ms: three launches per channels-last GroupNorm instead of one, and a pass of one image is ~500 dependent
+        # dispatches of small grids); "auto" (default) = nhwc for passes of two images or more (four with the bf16 option), on a HIP device
+        # without autograd
+        self.backbone_layout = str(m.get('backbone_layout', 'auto'))
+        if self.backbone_layout not in ("auto", "nchw", "nhwc"):
+            raise ValueError("backbone_layout must be 'auto', 'nchw' or 'nhwc'")
         self.init_ray_dirs()
         self.init_sh_transform_matrices()
 
@@ -407,11 +432,10 @@ class GaussianSplatPredictor_gtunet(nn.Module):
         x = x.reshape(B * Nv, *x.shape[2:])
         v2w = source_cameras_view_to_world.reshape(B * Nv, 4, 4)
         quat = source_cv2wT_quat.reshape(B * Nv, 4)
-        if self.backbone_layout == "nhwc" and x.is_cuda and not torch.is_grad_enabled():
-            if not getattr(self, "_nhwc_filters", False):       # once: the filters in the activations' layout
-                self.network_with_offset.to(memory_format=torch.channels_last)
-                self._nhwc_filters = True
-            x = x.contiguous(memory_format=torch.channels_last)
+        # ("auto": measured crossover -- fp32 25.9 against 26.4 ms at two images, bf16 11.5 against 10.8 at two and 24.2 against 25.4 at eight)
+        if x.is_cuda and not torch.is_grad_enabled() and (self.backbone_layout == "nhwc" or (
+                self.backbone_layout == "auto" and x.shape[0] >= (4 if self.backbone_dtype == "bf16" else 2))):
+            x = x.contiguous(memory_format=torch.channels_last)       # (the filters follow per convolution: Conv2d._filter)
         if self.backbone_dtype == "bf16" and x.is_cuda and not torch.is_grad_enabled():
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)

@@ -395,7 +395,7 @@ def test_backbone_channels_last_option(gpu_device):
     cfg2 = cameras.default_cfg(32)
     p1 = GaussianSplatPredictor_gtunet(cfg2).to(gpu_device).eval()
     p1.load_state_dict(p0.state_dict())
-    assert p1.backbone_layout == "nhwc" and p0.backbone_layout == "nchw"        # channels-last is the default
+    assert p1.backbone_layout == "auto" and p0.backbone_layout == "nchw"        # auto: channels-last for this pass of two images
     torch.manual_seed(3)
     xin = torch.rand(2, 1, 4, 32, 32, device=gpu_device)
     rig = cameras.OrbitRig(cfg).canonical
@@ -405,6 +405,23 @@ def test_backbone_channels_last_option(gpu_device):
         b = p1(xin, *args, unet_depth=torch.full((2, 1, 32, 32), 7.0, device=gpu_device))
     for k in a:
         assert a[k].shape == b[k].shape and (a[k] - b[k]).abs().max().item() <= 1e-4 * max(1.0, a[k].abs().max().item()), k
+    # the channels-last filter copies are kept per convolution until the parameter changes: an in-place update must be seen
+    conv = p1.network_with_offset.encoder.enc["64x64_block0"].conv0
+    assert conv.__dict__.get("_filter_cache") is not None and conv.__dict__["_filter_cache"][1].is_contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        delta = 0.05 * torch.randn_like(conv.weight)          # (not a scaling: the GroupNorm behind the convolution would undo it)
+        for p in (p0, p1):
+            p.network_with_offset.encoder.enc["64x64_block0"].conv0.weight.add_(delta)
+        a2 = p0(xin, *args, unet_depth=torch.full((2, 1, 32, 32), 7.0, device=gpu_device))
+        b2 = p1(xin, *args, unet_depth=torch.full((2, 1, 32, 32), 7.0, device=gpu_device))
+    assert torch.equal(conv.__dict__["_filter_cache"][1], conv.weight) and conv.__dict__["_filter_cache"][0][0] == conv.weight._version
+    for k in a2:
+        assert (a2[k] - b2[k]).abs().max().item() <= 1e-4 * max(1.0, a2[k].abs().max().item()), k
+    # one image per pass stays in torch's layout under "auto"
+    with torch.no_grad():
+        c1 = p1(xin[:1], args[0][:1], args[1][:1], unet_depth=torch.full((1, 1, 32, 32), 7.0, device=gpu_device))
+    for k in c1:
+        assert (c1[k] - b2[k][:1]).abs().max().item() <= 1e-4 * max(1.0, c1[k].abs().max().item()), k
     with pytest.raises(ValueError):
         bad = cameras.default_cfg(32)
         bad['model']['backbone_layout'] = 'nchw16'
