@@ -114,9 +114,12 @@ class Gatherer:
         if self.world == 1:
             return
         frames = frames_u8.to(self.comm_device)
-        self.pending.append((self.dist.gather(frames, self.buf, dst=0, async_op=True), frames))
-        while len(self.pending) > 1:
+        # the previous step's gather has had this whole step's rendering to finish; it is waited for BEFORE the next one is issued, because
+        # both write rank 0's buffers: RCCL runs a communicator's collectives in issue order, gloo's worker threads need not (seen once as
+        # a stale frame in tests/test_dist_cpu.py::test_c4_step_gather_gloo_world2)
+        while self.pending:
             self.pending.pop(0)[0].wait()
+        self.pending.append((self.dist.gather(frames, self.buf, dst=0, async_op=True), frames))
 
     def barrier(self):
         while self.pending:

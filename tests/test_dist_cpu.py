@@ -38,12 +38,15 @@ def _worker(rank, world, port, n_items, q):
 
 
 
-def _run_world2(target, extra_args, attempts=2):
+def _run_world2(target, extra_args, attempts=3):
     """Two spawned ranks on a free local port; rank 0's result from the queue. An ephemeral port can be taken between its
-    probe and the rendezvous (or a loaded host can miss a timeout): one retry on a fresh port before failing."""
+    probe and the rendezvous (or a loaded host can miss a timeout): two retries on fresh ports, a moment apart, before failing."""
     import queue as _queue
+    import time as _time
     last = None
-    for _ in range(attempts):
+    for attempt in range(attempts):
+        if attempt:
+            _time.sleep(1.0 + attempt)
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -63,7 +66,7 @@ def _run_world2(target, extra_args, attempts=2):
         if out is not None and all(p.exitcode == 0 for p in procs):
             return out
         last = last or RuntimeError("exit codes %s" % [p.exitcode for p in procs])
-    raise AssertionError("world_size-2 gloo run failed twice: %r" % (last,))
+    raise AssertionError("world_size-2 gloo run failed %d times: %r" % (attempts, last))
 
 
 @pytest.mark.parametrize("n_items", [5, 8])
