@@ -428,6 +428,30 @@ def test_backbone_channels_last_option(gpu_device):
         GaussianSplatPredictor_gtunet(bad)
 
 
+def test_unet_gs_in_module_render_loop(gpu_device):
+    """Unet_GS_gtunet(..., render=True) (reference src/unet_gs.py:77-93): the frames and median depths it returns are the per-image
+    renderer calls, stacked."""
+    res, B = 64, 3
+    cfg = cameras.default_cfg(res)
+    model = f3d.Unet_GS_gtunet(cfg, renderer=f3d.render_predicted_more_v2_gof).to(gpu_device).eval()
+    rig = cameras.OrbitRig(cfg)
+    cano, ob = rig.canonical, rig.orbit(B)
+    torch.manual_seed(2)
+    x = torch.rand(B, 1, 4, res, res, device=gpu_device)
+    bg = torch.zeros(B, 3, device=gpu_device)
+    wv, fp, cc = (t.to(gpu_device) for t in (ob.world_view_transforms, ob.full_proj_transforms, ob.camera_centers))
+    with torch.no_grad():
+        frames, depths, g = model(x, bg, cano.view_to_world_transforms.expand(B, 1, 4, 4).to(gpu_device),
+                                  cano.source_cv2wT_quat.expand(B, 1, 4).to(gpu_device), render=True, world_view_transforms=wv,
+                                  full_proj_transforms=fp, camera_centers=cc, config=cfg, image_size=res,
+                                  unet_depth=torch.full((B, 1, res, res), 7.0, device=gpu_device))
+        assert frames.shape == (B, 3, res, res) and depths.shape == (B, 1, res, res) and g["xyz"].shape == (B, res * res, 3)
+        for b in range(B):
+            od = f3d.render_predicted_more_v2_gof(g, b, wv[b:b + 1], fp[b:b + 1], cc[b:b + 1], bg[b:b + 1], cfg)
+            assert torch.equal(od["render"].reshape(3, res, res), frames[b]) and torch.equal(od["rendered_depth"].reshape(1, res, res), depths[b])
+        assert float(frames.max()) > 0 and bool(torch.isfinite(frames).all())
+
+
 def test_renderer_derived_maps_carry_gradients(gpu_device):
     """rendered_normal / depth_normal are differentiable in the reference (gr.py:1043-1053). With gradients enabled
     the wrapper takes the torch formulation (same values as the fused kernel) and a loss on them reaches the Gaussians."""
