@@ -36,7 +36,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / tensor sharing fail with hipIpcGetMemHandle otherwise); the variable is
+# exported on the boxes already -- kept here for launches whose environment was rebuilt
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
