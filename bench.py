@@ -166,7 +166,7 @@ def main():
         _lib.check(L.f3dg_set_option(b"render_round", int(os.environ["F3DG_RENDER_ROUND"])), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
-    for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad"), ("F3DG_BWD_OCC", b"bwd_occ"), ("F3DG_RENDER_SLIDE", b"render_slide"), ("F3DG_RENDER_LOWOCC", b"render_lowocc"), ("F3DG_RENDER_TAIL", b"render_tail"), ("F3DG_SMALL_DEBUG", b"small_debug")):     # A/B switches of render3
+    for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad"), ("F3DG_BWD_OCC", b"bwd_occ"), ("F3DG_RENDER_SLIDE", b"render_slide"), ("F3DG_RENDER_LOWOCC", b"render_lowocc"), ("F3DG_RENDER_TAIL", b"render_tail"), ("F3DG_SMALL_DEBUG", b"small_debug"), ("F3DG_RENDER_PACK_TH", b"render_pack_th"), ("F3DG_RENDER_PACK", b"render_pack")):     # A/B switches of render3
         if os.environ.get(env):
             _lib.check(L.f3dg_set_option(opt, int(os.environ[env])), "f3dg_set_option")
     _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
@@ -388,11 +388,25 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         _lib.check(L.f3dg_set_option(b"render_count", 1), "f3dg_set_option")
         cbuf = (C.c_ulonglong * 16)()
         L.f3dg_debug_render_counts(cbuf, 1)
+        L.f3dg_debug_render4_counts(None, 1)
         step()
         gat.barrier()
         _lib.check(L.f3dg_debug_render_counts(cbuf, 1), "f3dg_debug_render_counts")
         _lib.check(L.f3dg_set_option(b"render_count", 0), "f3dg_set_option")
-        if cbuf[5]:
+        c4 = (C.c_ulonglong * 16)()
+        _lib.check(L.f3dg_debug_render4_counts(c4, 1), "f3dg_debug_render4_counts")
+        if c4[5]:       # the rank-packed kernel (render_kernel = 4) ran: its own counters
+            pairs = int(c4[4]) + int(c4[9])
+            counts = {"list_entries_staged": int(c4[0]), "list_entries_scanned": int(c4[1]), "fused_trips": int(c4[2]), "slides": int(c4[3]),
+                      "fused_lane_trips": int(c4[4]), "waves": int(c4[5]), "packed_batches": int(c4[6]), "blend_trips": int(c4[7]),
+                      "pairs_evaluated_in_dense_trips": int(c4[8]), "pairs_reaching_a_blend_trip": int(c4[9]),
+                      "phase2_lane_trips": pairs,
+                      # lanes doing useful work in the trips that carry the stateless two thirds of a pair's arithmetic
+                      "stateless_lane_utilisation": (int(c4[4]) + int(c4[8])) / (64.0 * (int(c4[2]) + int(c4[6]))) if c4[2] + c4[6] else None,
+                      "blend_trip_lane_utilisation": int(c4[9]) / (64.0 * int(c4[7])) if c4[7] else None,
+                      "note": "one untimed step with option render_count = 1 (render4_fwd_kernel with work counters); a fused trip runs a pair's "
+                              "whole arithmetic in the pixel's lane, a packed batch = one dense trip (stateless part, one pair per lane) + its blend trips"}
+        elif cbuf[5]:
             counts = {"list_entries_staged": int(cbuf[0]), "list_entries_scanned": int(cbuf[1]), "phase2_wave_trips": int(cbuf[2]),
                       "slides": int(cbuf[3]), "phase2_lane_trips": int(cbuf[4]), "waves": int(cbuf[5]),
                       "phase2_lane_utilisation": cbuf[4] / (64.0 * cbuf[2]) if cbuf[2] else None,
@@ -444,12 +458,14 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         rf["frac_on_staged_entries"] = gbs(b_staged, rf["ms_per_launch"]) / HBM_PEAK_GBS
         rf["bytes_read_per_launch_counted"] = b_staged
         rf["kernel_counters"] = counts
-        if rf["frac"] > 1.0:
+        # `frac` never exceeds what the kernel read: where the formula on the handed list entries is more than 1.3 x the counted
+        # figure (saturated quadrants stop long before their tile's list ends) the counted one is the primary number
+        if rf["frac"] > 1.3 * rf["frac_on_staged_entries"]:
             rf["frac_formula_on_all_list_entries"] = rf["frac"]
             rf["frac"] = rf["frac_on_staged_entries"]
             rf["achieved"] = gbs(b_staged, rf["ms_per_launch"])
             rf["units"] = ("COUNTED by the kernel: 4 B x list entries scanned + 80 B x list entries staged + 36 B x pixels + 8 B x tiles -- the "
-                           "72 B x list-entry formula gives a fraction above 1 here (frac_formula_on_all_list_entries) because saturated "
+                           "72 B x list-entry formula gives more than 1.3 x that here (frac_formula_on_all_list_entries) because saturated "
                            "quadrants never read most of their tile's list")
     # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes, which cannot run inside this process): `traffic` stays
     # null in this line; the figure of the newest committed profile of THIS configuration is under traffic_from_profiles, with its source

@@ -117,6 +117,7 @@ int g_f3dg_render_cull = 1;
 int g_f3dg_render_queue = 1;
 int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
+int g_f3dg_render_pack = -1;
 int g_f3dg_render_dma = 1;
 int g_f3dg_render_wpb = 1;
 int g_f3dg_render_count = 0;
@@ -137,7 +138,9 @@ extern "C" int f3dg_set_option(const char* name, int value)
 {
     if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; return F3DG_OK; }
+    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; if (value == 4) g_f3dg_render_pack = 1; return F3DG_OK; }
+    if (name && strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) { std::lock_guard<std::mutex> lock(g_small_mutex); g_small_disabled.clear(); } return F3DG_OK; }
     if (name && strcmp(name, "small_debug") == 0) { g_f3dg_small_debug = value; return F3DG_OK; }
     if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }

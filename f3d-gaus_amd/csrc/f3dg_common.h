@@ -249,6 +249,13 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
                        float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels = 0u);
 
+// the rank-packed compositing forward (f3dg_render4.hip; option render_kernel = 4, inference launches)
+extern int g_f3dg_render_pack;         // -1 (default): inference launches in the reference's arithmetic take render4; 1: all inference launches; 0: none
+extern int g_f3dg_render_pack_th;      // trips of a slide with at most this many participating pixels are packed (default 32; 0: never)
+int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+                        const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
+                        float* out_color, int fast, unsigned skip_channels, int count);
+
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated);
 int f3dg_launch_integrate_pass1(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgLayout& L,

@@ -164,11 +164,12 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
     st.C1 = fmaf(cg, w, st.C1);
     st.C2 = fmaf(cb, w, st.C2);
     if (NORMAL) {
-        const float inv_len = __builtin_amdgcn_rsqf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)) + 1e-7f);
-        const float wn = -w * inv_len;
-        st.C3 = fmaf(n0, wn, st.C3);
-        st.C4 = fmaf(n1, wn, st.C4);
-        st.C5 = fmaf(n2, wn, st.C5);
+        // (the unit normal is formed first and then weighted -- the order of f3dg_blend.h, where the packed schedule of
+        // f3dg_render4.hip hands it from the lane that evaluated the pair to the lane that owns the pixel)
+        const float ninv = -__builtin_amdgcn_rsqf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)) + 1e-7f);
+        st.C3 = fmaf(n0 * ninv, w, st.C3);
+        st.C4 = fmaf(n1 * ninv, w, st.C4);
+        st.C5 = fmaf(n2 * ninv, w, st.C5);
     }
     if (Tr > 0.5f) {
         st.C6 = t;
@@ -1437,6 +1438,12 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
             F3DG_HIP_CHECK(hipGetLastError());
             return F3DG_OK;
         }
+        // the rank-packed kernel of f3dg_render4.hip (option render_pack: 1 = every inference launch, -1 = the default: inference launches
+        // in the reference's arithmetic, whose stateless part is 2.5 x as long -- measured -38 % on the real merged set, -6 % at C2; in
+        // fast arithmetic the packed trips' hand-over costs what they save: 8.4-8.7 against 8.6 ms)
+        if (!save_aux && g_f3dg_render_slide && (g_f3dg_render_pack == 1 || (g_f3dg_render_pack < 0 && !g_f3dg_render_fast && g_f3dg_render_wpb == 1 && g_f3dg_render_tail == 0)))
+            return f3dg_launch_render4(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
+                                       g_f3dg_render_fast, skip_channels, g_f3dg_render_count);
         if (g_f3dg_render_slide) {
 #define F3DG_R3S_ARGS s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib, tail_n
             // render_tail = N > 0 (one-wave workgroups only): the tail schedule once at most N pixels of a quadrant are unsaturated

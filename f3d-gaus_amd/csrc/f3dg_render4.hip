@@ -1,0 +1,423 @@
+// f3dg_render4.hip -- compositing forward with RANK-PACKED trips (option render_kernel = 4).
+//
+// render3s_fwd_kernel (f3dg_render.hip) gives every pixel of an 8x8 quadrant a lane; in a phase-2 trip every pixel that still has a
+// passing entry in the window pops its next one and runs the whole loop body of renderCUDA (reference RAST/cuda_rasterizer/
+// forward.cu:493-583) on it. A trip costs the wave ~95 issue slots whether 64 pixels take part or 3 -- and on pixel-aligned splats over
+// a real depth map (the reference's production data, visualize.py:293-340) 56 % of the trips have fewer than 16 takers: the entries of
+// a 32-entry half-window lie on one iso-depth contour, the pixels under it get ~14 of them, the average pixel 3 (lane utilisation 0.24;
+// 0.63 on the synthetic C2 recipe).
+//
+// Two thirds of a trip do not depend on the pixel's running state (f3dg_blend.h: f3dg_pair_eval -- quadric, error-free quotient, exp,
+// NDC depth, unit normal); only the last third (f3dg_pair_apply: the transmittance recurrence and the accumulators) is serial per
+// pixel. This kernel keeps render3s's scan / staging / phase 1 / sliding half-windows and splits phase 2 of a slide in two regimes:
+//   * FUSED trips, as before, while more than `pack_th` pixels take part;
+//   * then PACKED batches. A batch takes the next R pending entries of every pixel (R ranks: as many as fit 64 pairs, at most what the
+//     pixels that hold the window back still need), writes the (pixel, slot) pairs to a 64-entry LDS queue in pixel-major order
+//     (offset of pixel p = sum over ranks of mbcnt of the rank's ballot), evaluates the stateless part ONE PAIR PER LANE (the ray of
+//     the pair's pixel comes by ds_bpermute from the lane that owns it, the record from the staged window), and then runs R short
+//     trips in which the owning lanes pull their pair's six numbers by ds_bpermute and apply the recurrence.
+// Per pixel the sequence of blended entries and every operation on them is unchanged, so the images are bit-identical to render3s in
+// either arithmetic mode (tests/test_raster_forward_gpu.py). LDS per wave: 4 KB of records + 512 B of id ring + 128 B of pair queue;
+// 8 waves per SIMD as before. Inference launches only (a SAVE_AUX forward stays on render3s).
+#include "f3dg_blend.h"
+#include "f3dg_ellipse.h"
+
+#include <stdio.h>
+#include <string.h>
+
+extern const char* g_f3dg_last_render_kernel;
+int g_f3dg_render_pack_th = 32;       // option render_pack_th: trips with at most this many participating pixels are packed (0: never)
+
+// work counters (option render_count = 1; f3dg_debug_render_counts rows 16..): [0] staged entries, [1] scanned, [2] fused trips,
+// [3] slides, [4] lane-trips of fused trips, [5] waves, [6] packed batches (= dense trips), [7] blend trips of packed batches,
+// [8] pairs evaluated in dense trips, [9] pairs blended or rejected in blend trips
+__device__ unsigned long long g_f3dg_counts4[64][16];
+
+namespace {
+
+#ifndef F3DG_R4_PARK
+#define F3DG_R4_PARK 1              // 1: a batch's results go to its blend trips through LDS (parked); 0: by ds_bpermute from the dense lanes' registers
+#endif
+#ifndef F3DG_R4_FLAT
+#define F3DG_R4_FLAT 1              // 1: the blend trips of fast arithmetic run the branch-free recurrence (f3dg_pair_apply_flat)
+#endif
+#ifndef F3DG_R4_FLAT_FUSED
+#define F3DG_R4_FLAT_FUSED 0        // 1: the fused trips of fast arithmetic run the branch-free recurrence as well (measured: no gain)
+#endif
+#define F3DG_R4_WIN 64
+#define F3DG_R4_RING 128
+#define F3DG_R4_MAXR 10             // ranks per packed batch (two 32-bit registers of 6-bit slots)
+#define F3DG_R4_FLAG 0x80000000u
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// keeps the pixel state in ONE set of registers across the packed batches (without it the register allocator parks the twelve
+// accumulators in a second set around the dense trip: 24 v_mov per batch)
+#define F3DG_R4_PIN(st) asm volatile("" : "+v"((st).Tr), "+v"((st).C0), "+v"((st).C1), "+v"((st).C2), "+v"((st).C3), "+v"((st).C4), "+v"((st).C5), \
+                                          "+v"((st).C6), "+v"((st).C7), "+v"((st).dist1), "+v"((st).dist2), "+v"((st).distortion))
+
+__device__ __forceinline__ float pull(int addr, float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+}
+
+template <bool FAST, bool NORMAL, bool DIST, bool COUNT>
+__global__ void __launch_bounds__(64, 8)
+render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                   const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                   float* __restrict__ out_color, int pack_th)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x;
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const unsigned n = range.y - range.x;
+
+    __shared__ float4 sR[4][F3DG_R4_WIN];          // records, [16-byte chunk][slot]; slots 0..31 and 32..63 are the two halves of the window
+    __shared__ unsigned sQ[F3DG_R4_RING];          // ids of kept entries not staged yet, ring
+#if F3DG_R4_PARK
+    // the parking area of a packed batch: what the dense trip hands to the blend trips, [position in the queue]. The queue itself
+    // (sK: 64 x u16, (owning lane << 6) | physical slot) is read by the dense trip before it parks its results and aliases the first
+    // 128 bytes. (Aliasing the id ring as well -- its pending ids parked in a register between slides, 5,632 instead of 6,144 bytes,
+    // 29 instead of 26 waves per CU -- measured 1.5-2.5 % SLOWER on the real merged set: occupancy is not what limits this kernel.)
+    __shared__ float4 sPark[(NORMAL || DIST) ? 64 : 32];       // full: (alpha, t, m, nn0)        lean: 64 x (alpha, t)
+    __shared__ float2 sPark2[(NORMAL || DIST) ? 64 : 1];       // full: (nn1, nn2)
+    unsigned short* sK = reinterpret_cast<unsigned short*>(sPark);
+#else
+    __shared__ unsigned short sK[64];              // pair queue of a packed batch: (owning lane << 6) | physical slot
+#endif
+
+    const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vcull = cull + (size_t)view * P;
+    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+    const unsigned hl = lane & 31u;               // entry of a half this lane tests in phase 1 ...
+    const unsigned row4 = (lane >> 5) * 4u;       // ... against the pixels of rows row4 .. row4 + 3
+
+    bool done = !inside;
+    F3dgPixel st;
+    f3dg_pixel_init(st);
+
+    unsigned n_staged = 0, n_fused = 0, n_slides = 0, n_lane_fused = 0, n_batches = 0, n_blend_trips = 0, n_dense_pairs = 0, n_blend_pairs = 0;
+    unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
+    unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
+    unsigned long long pass = 0ull;               // per pixel: bits 0..31 older half, 32..63 newer half, in list order
+    unsigned idn = lane < n ? point_list[range.x + lane] : 0u;
+    if (__ballot(!done) != 0ull)
+    for (;;) {
+        // ---- scan: keep the entries whose box reaches this quadrant until 32 are pending
+        while (qpend < 32u && cursor < n) {
+            const unsigned idm = idn, pos = cursor + lane;
+            cursor += 64u;
+            idn = cursor + lane < n ? point_list[range.x + cursor + lane] : 0u;
+            const bool keep = pos < n && (idm & qbit) != 0u;
+            const unsigned long long kb = __ballot(keep);
+            if (keep) sQ[(qhead + qpend + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u))) & (F3DG_R4_RING - 1)] = idm & F3DG_ID_MASK;
+            qpend += (unsigned)__popcll(kb);
+        }
+        const unsigned m = qpend < 32u ? qpend : 32u;
+        if (m == 0u && __ballot(pass != 0ull) == 0ull)
+            break;                                // nothing left to stage, nothing left in the newer half
+        wave_lds_fence();
+
+        // ---- stage m entries into the retired half; lanes e and e + 32 both take entry e
+        const unsigned base = flip * 32u;
+        float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float ec = 0.0f;
+        if (hl < m) {
+            const unsigned id = sQ[(qhead + hl) & (F3DG_R4_RING - 1)];
+            if (lane < 32u) {
+                const float4* src = reinterpret_cast<const float4*>(vrec + id);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                     (__attribute__((address_space(3))) void*)&sR[c][base], 16, 0, 0);
+            }
+            e4 = vcull[id];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_fence();
+        if (hl < m) ec = sR[3][base + hl].w;
+        qhead += m;
+        qpend -= m;
+        if (COUNT) { n_staged += m; n_slides++; }
+
+        // ---- phase 1: the 32 new entries against the quadrant's 64 pixels
+        int fresh = 0;
+        if (m != 0u) {
+            const float u0 = hl < m ? (float)qx0 - e4.x : __builtin_nanf("");     // NaN: every comparison below is false
+            const float v0 = (float)(qy0 + row4) - e4.y;
+            float dxx[8], adx[8], dyy[4], cdy[4];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                dxx[q] = u0 + (float)q;
+                adx[q] = e4.z * dxx[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                dyy[q] = v0 + (float)q;
+                cdy[q] = ec * dyy[q] * dyy[q];
+            }
+            half_ballots<0>(fresh, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+        }
+        // ---- slide: the newer half becomes the older one, the fresh bits the newer one
+        pass = (pass >> 32) | (done ? 0ull : ((unsigned long long)(unsigned)fresh << 32));
+        flip ^= 1u;
+        const unsigned xr = flip << 5;            // logical slot j (0..31 older, 32..63 newer) lives in physical slot j ^ xr
+
+        // ---- phase 2a: fused trips while many pixels take part (a divergent loop: a pixel leaves it when its mask is empty; the
+        // ballots are taken over the pixels still inside)
+#ifdef F3DG_R4_NOPACK       // experiment: the fused loop without its population test
+        while (pass != 0ull && __ballot((unsigned)pass != 0u) != 0ull) {
+#else
+        while (pass != 0ull && __ballot((unsigned)pass != 0u) != 0ull && (int)__popcll(__ballot(true)) > pack_th) {
+#endif
+            const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
+            pass &= pass - 1;
+            if (COUNT) n_lane_fused++;
+            const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
+            const F3dgPair pr = f3dg_pair_eval<FAST, NORMAL, DIST, F3DG_R4_FLAT_FUSED != 0>(ray_x, ray_y, q0, q1, q2);
+            // keeps the loads 16 bytes wide (ds_read_b96 takes twice the LDS cycles); placed behind the evaluation so that the
+            // arithmetic on the first chunks starts while the last ones are still on their way
+            asm volatile("" :: "v"(q2.w), "v"(q3.w), "v"(pr.alpha));
+#if F3DG_R4_FLAT_FUSED
+            if (FAST)
+                done = f3dg_pair_apply_flat<NORMAL, DIST>(st, F3DG_R4_FLAG | j, pr, q3.x, q3.y, q3.z);
+            else
+#endif
+            if (pr.alpha != 0.0f)
+                done = f3dg_pair_apply<FAST, NORMAL, DIST>(st, F3DG_R4_FLAG | j, pr, q3.x, q3.y, q3.z);
+            if (done) pass = 0ull;
+            if (COUNT && __builtin_ctzll(__ballot(true)) == (int)lane) n_fused++;
+        }
+
+        // ---- phase 2b: packed batches until every live pixel has finished the older half
+        // (bottom-tested on purpose: with the exit test at the top the structurizer routes the exit through the block behind the body,
+        // the state at the loop header stays live across the body in a second set of registers, and every batch pays 24 v_mov)
+        if (__ballot((unsigned)pass != 0u) != 0ull)
+        do {
+            F3DG_R4_PIN(st);
+            const unsigned cnt = (unsigned)__popcll(pass);        // pending entries of this pixel in the window (0 for a finished pixel)
+            const unsigned need = (unsigned)__popc((unsigned)pass);   // ... of them in the older half
+            // rank 0 always fits (at most 64 pixels have a pending entry) and is always needed (some pixel holds the window back)
+            unsigned R = 0, total = 0, off = 0;
+            do {
+                const unsigned long long b = __ballot(cnt > R);
+                off = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, off));
+                total += (unsigned)__popcll(b);
+                R++;
+            } while (__ballot(need > R) != 0ull && total + (unsigned)__popcll(__ballot(cnt > R)) <= 64u && R < F3DG_R4_MAXR);
+            const unsigned c = cnt < R ? cnt : R;                 // this pixel's pairs of the batch, at queue positions off .. off + c - 1
+            unsigned long long slots = 0ull;                      // their physical slots, 6 bits each
+            {
+                unsigned i = 0;
+#pragma nounroll
+                do {
+                    if (i < c) {
+                        const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
+                        pass &= pass - 1;
+                        sK[off + i] = (unsigned short)((lane << 6) | j);
+                        slots |= (unsigned long long)j << (6u * i);
+                    }
+                } while (++i < R);
+            }
+            wave_lds_fence();
+
+            // dense trip: lane q evaluates pair q of the queue (lanes beyond `total` evaluate a stale pair nobody pulls)
+            F3dgPair pr;
+            {
+                const unsigned k = (unsigned)sK[lane];
+                const int owner = (int)((k >> 6) << 2);
+                const float rx = pull(owner, ray_x), ry = pull(owner, ray_y);
+                const unsigned j = k & 63u;
+                const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j];
+                pr = f3dg_pair_eval<FAST, NORMAL, DIST, F3DG_R4_FLAT != 0>(rx, ry, q0, q1, q2);
+                asm volatile("" :: "v"(q2.w), "v"(pr.alpha));
+            }
+            if (COUNT) { n_batches++; n_blend_trips += R; n_dense_pairs += total; }
+
+#if F3DG_R4_PARK
+            // park the results (every lane has read its queue entry: the queue's bytes may go), then the blend trips: a divergent loop,
+            // every owning lane walks ITS pairs of the batch through the recurrence, the wave runs as long as the longest of them
+            wave_lds_fence();
+            if (NORMAL || DIST) {
+                sPark[lane] = make_float4(pr.alpha, pr.t, pr.m, pr.nn0);
+                sPark2[lane] = make_float2(pr.nn1, pr.nn2);
+            } else {
+                reinterpret_cast<float2*>(sPark)[lane] = make_float2(pr.alpha, pr.t);
+            }
+            wave_lds_fence();
+            {
+                unsigned i = 0;
+                while (i < c && !done) {
+                    const unsigned j = (unsigned)slots & 63u;
+                    slots >>= 6;
+                    const float4 q3 = sR[3][j];
+                    F3dgPair mine;
+                    if (NORMAL || DIST) {
+                        const float4 a = sPark[off + i];
+                        const float2 b = sPark2[off + i];
+                        mine.alpha = a.x; mine.t = a.y; mine.m = a.z; mine.nn0 = a.w; mine.nn1 = b.x; mine.nn2 = b.y;
+                    } else {
+                        const float2 a = reinterpret_cast<const float2*>(sPark)[off + i];
+                        mine.alpha = a.x; mine.t = a.y; mine.m = 0.0f; mine.nn0 = mine.nn1 = mine.nn2 = 0.0f;
+                    }
+                    if (COUNT) n_blend_pairs++;
+#if F3DG_R4_FLAT
+                    if (FAST)
+                        done = f3dg_pair_apply_flat<NORMAL, DIST>(st, F3DG_R4_FLAG | j, mine, q3.x, q3.y, q3.z);
+                    else
+#endif
+                    if (mine.alpha != 0.0f)
+                        done = f3dg_pair_apply<FAST, NORMAL, DIST>(st, F3DG_R4_FLAG | j, mine, q3.x, q3.y, q3.z);
+                    asm volatile("" :: "v"(q3.w));
+                    i++;
+                }
+            }
+            wave_lds_fence();          // the next batch's queue overwrites the parking area
+#else
+            // R blend trips: every owning lane pulls its pair's numbers and applies the recurrence
+            F3DG_R4_PIN(st);
+            int src = (int)(off << 2);
+            unsigned i = 0;
+#pragma nounroll
+            do {
+                // (the colour of this trip's pair: requested before the pulls, needed last)
+                const unsigned j = (unsigned)slots & 63u;
+                const float4 q3 = sR[3][j];
+                F3dgPair mine;
+                mine.alpha = pull(src, pr.alpha);
+                mine.t = pull(src, pr.t);
+                mine.m = DIST ? pull(src, pr.m) : 0.0f;
+                mine.nn0 = NORMAL ? pull(src, pr.nn0) : 0.0f;
+                mine.nn1 = NORMAL ? pull(src, pr.nn1) : 0.0f;
+                mine.nn2 = NORMAL ? pull(src, pr.nn2) : 0.0f;
+                if (i < c && !done) {
+                    if (COUNT) n_blend_pairs++;
+                    if (mine.alpha != 0.0f) {
+                        asm volatile("" :: "v"(q3.w));
+                        done = f3dg_pair_apply<FAST, NORMAL, DIST>(st, F3DG_R4_FLAG | j, mine, q3.x, q3.y, q3.z);
+                    }
+                }
+                src += 4;
+                slots >>= 6;
+            } while (++i < R);
+#endif
+            if (done) pass = 0ull;
+        } while (__ballot((unsigned)pass != 0u) != 0ull);
+
+        if (__ballot(!done) == 0ull)
+            break;
+    }
+    if (COUNT) {
+        unsigned a = n_lane_fused, b = n_blend_pairs;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += (unsigned)__shfl_xor((int)a, o, 64);
+            b += (unsigned)__shfl_xor((int)b, o, 64);
+        }
+        unsigned f = n_fused;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) f += (unsigned)__shfl_xor((int)f, o, 64);
+        if (lane == 0) {
+            unsigned long long* c = g_f3dg_counts4[blockIdx.x & 63u];
+            atomicAdd(&c[0], (unsigned long long)n_staged);
+            atomicAdd(&c[1], (unsigned long long)(cursor < n ? cursor : n));
+            atomicAdd(&c[2], (unsigned long long)f);
+            atomicAdd(&c[3], (unsigned long long)n_slides);
+            atomicAdd(&c[4], (unsigned long long)a);
+            atomicAdd(&c[5], 1ull);
+            atomicAdd(&c[6], (unsigned long long)n_batches);
+            atomicAdd(&c[7], (unsigned long long)n_blend_trips);
+            atomicAdd(&c[8], (unsigned long long)n_dense_pairs);
+            atomicAdd(&c[9], (unsigned long long)b);
+        }
+    }
+
+    // (the pixel's coordinates are formed again from an opaque copy of the lane id: kept live across the loop they cost the two registers
+    // that make the difference between 64 VGPRs and spilling)
+    unsigned lane_e = threadIdx.x;
+    asm volatile("" : "+v"(lane_e));
+    const unsigned out_x = qx0 + (lane_e & 7u), out_y = qy0 + (lane_e >> 3);
+    if (out_x < (unsigned)W && out_y < (unsigned)H) {
+        const size_t HW = (size_t)H * W;
+        const size_t pix_id = (size_t)W * out_y + out_x;
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        if (NORMAL) {
+            out[3 * HW + pix_id] = st.C3;
+            out[4 * HW + pix_id] = st.C4;
+            out[5 * HW + pix_id] = st.C5;
+        }
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        if (DIST) out[8 * HW + pix_id] = distortion;
+    }
+}
+
+char g_kernel_name4[160] = "";
+
+} // namespace
+
+int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+                        const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
+                        float* out_color, int fast, unsigned skip_channels, int count)
+{
+    const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    const int T = tiles_x * tiles_y;
+    const dim3 grid((unsigned)V * (unsigned)T * 4u);
+    const bool lean = (skip_channels & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION)) == (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION);
+    const int th = g_f3dg_render_pack_th;
+#define F3DG_R4_ARGS s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, th
+#define F3DG_LAUNCH4(FST, NRM, DST, CNT) F3DG_KLAUNCH((render4_fwd_kernel<FST, NRM, DST, CNT>), grid, dim3(64), 0, F3DG_R4_ARGS)
+    if (count && !lean) { if (fast) F3DG_LAUNCH4(true, true, true, true); else F3DG_LAUNCH4(false, true, true, true); }
+    else if (lean) { if (fast) F3DG_LAUNCH4(true, false, false, false); else F3DG_LAUNCH4(false, false, false, false); }
+    else { if (fast) F3DG_LAUNCH4(true, true, true, false); else F3DG_LAUNCH4(false, true, true, false); }
+#undef F3DG_LAUNCH4
+#undef F3DG_R4_ARGS
+    snprintf(g_kernel_name4, sizeof g_kernel_name4, "render4_fwd_kernel<FAST=%s, NORMAL=%s, DIST=%s%s, pack_th=%d>", fast ? "true" : "false",
+             lean ? "false" : "true", lean ? "false" : "true", count && !lean ? ", COUNT=true" : "", th);
+    g_f3dg_last_render_kernel = g_kernel_name4;
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+// debug: the work counters of render4's counting variant (option render_count = 1), summed over all launches since the last reset:
+// h_out[16] = { staged, scanned, fused trips, slides, lane-trips of fused trips, waves, packed batches, blend trips, pairs evaluated in
+// dense trips, pairs that reached a blend trip, 0... }
+extern "C" int f3dg_debug_render4_counts(unsigned long long* h_out, int reset)
+{
+    static unsigned long long rows[64][16];
+    F3DG_HIP_CHECK(hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_f3dg_counts4), sizeof rows));
+    if (h_out)
+        for (int k = 0; k < 16; k++) {
+            h_out[k] = 0;
+            for (int r = 0; r < 64; r++) h_out[k] += rows[r][k];
+        }
+    if (reset) {
+        memset(rows, 0, sizeof rows);
+        F3DG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_f3dg_counts4), rows, sizeof rows));
+    }
+    return F3DG_OK;
+}

@@ -362,6 +362,12 @@ int f3dg_residual_join_bf16(void* stream, int N, int C, int HW, int nhwc, const 
  * bit 0: the projection grid runs chunk-major -- the views of one chunk of 256 Gaussians follow each other --, bit 1: the record and
  * the ellipse leave as non-temporal stores). "render_count" (default 0): the counting variant of render3s_fwd_kernel
  * (f3dg_debug_render_counts); "render_wpb" (default 1; 4: a tile's four quadrant waves are one workgroup).
+ * Round 5: "render_pack" (default -1) sends inference launches to the rank-packed kernel (f3dg_render4.hip: the trips of a slide in
+ * which at most "render_pack_th" pixels (default 32; 0: none, 64: all) take part are packed -- the stateless two thirds of the loop body
+ * of forward.cu:493-583 evaluated one (pixel, Gaussian) pair per lane for pairs of different pixels, the recurrence left to the lane
+ * that owns the pixel); bit-identical to render3s_fwd_kernel. -1: inference launches in the reference's arithmetic ("render_fast" 0:
+ * -38 % on the real merged set, -6 % at C2), 1: every inference launch, 0: none ("render_kernel" = 4 is shorthand for 3 + render_pack 1).
+ * A SAVE_AUX forward stays on render3s_fwd_kernel.
  * Returns F3DG_ERR_BAD_ARG for unknown names. */
 int f3dg_set_option(const char* name, int value);
 
@@ -388,6 +394,12 @@ int f3dg_profile_collect_calls(double* h_stage_ms, int* h_calls, double* h_per_c
  * trips of slides that began with <= 8 / <= 24 live pixels, those slides, 0 ... }. */
 const char* f3dg_debug_last_render_kernel(void);
 int f3dg_debug_render_counts(unsigned long long* h_out8, int reset);
+/* The counters of the rank-packed kernel's counting variant (render_kernel = 4 with render_count = 1): h_out[SIXTEEN] = { list entries
+ * staged, scanned, fused trips, slides, lane-trips of fused trips, waves, packed batches (= dense trips), blend trips of the batches,
+ * pairs evaluated in dense trips, pairs that reached a blend trip, 0 ... }. */
+int f3dg_debug_render4_counts(unsigned long long* h_out, int reset);
+/* Diagnostic (tools/pmc_pass1.sh): resident workgroups per CU of the two pass-1 kernels of f3dg_integrate as the runtime computes it. */
+int f3dg_debug_pass1_occupancy(int* rays_blocks, int* cull_blocks);
 
 /* BLOCKING: number of contributing (pixel, Gaussian) pairs the last f3dg_backward on this workspace blended back through --
  * "C" of the byte formula 80 R + 60 W H + 68 C of the compositing backward. */

@@ -298,6 +298,48 @@ def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
     assert L.f3dg_set_option(b"no_such_option", 1) == _lib.ERR_BAD_ARG
 
 
+@pytest.mark.parametrize("name", ["F2_oblique_aniso", "F5_odd_size", "F6_small_splats", "F9_long_tile_lists", "C1", "pixel_aligned", "thin"])
+def test_packed_schedule_bit_identical(name, gpu_device):
+    """The rank-packed compositing kernel (option render_pack, csrc/f3dg_render4.hip) evaluates the stateless part of sparse
+    trips for pairs of different pixels in one wave trip and hands the results to the lanes that own the pixels. Per pixel the
+    sequence of blended entries and every operation on them is render3s's: the inference outputs must be bit-identical for every
+    packing threshold (64: every trip packed, 0: none), and meet the oracle."""
+    from f3dgaus_amd import _lib
+    extra = {"C1": dict(P=65536, res=(256, 256), s0=0.01, view="oblique"),
+             "pixel_aligned": dict(P=65536, res=(256, 256), s0=0.01, view="oblique", n_views=3, seed=3),
+             "thin": dict(P=40000, res=(120, 88), s0=0.03, view="oblique", n_views=3, seed=7)}
+    scene = make_scene(**(SCENES[name] if name in SCENES else extra[name]))
+    if name == "thin":
+        scene["opacities"] = scene["opacities"] * 0.04        # nothing saturates: every quadrant walks its whole list
+    L = _lib.lib()
+    try:
+        L.f3dg_set_option(b"render_lowocc", 0)
+        assert L.f3dg_set_option(b"render_pack", 0) == 0
+        a = run_hip(scene, gpu_device, save_aux=False)          # render3s
+        assert b"render3s" in L.f3dg_debug_last_render_kernel()
+        assert L.f3dg_set_option(b"render_pack", 1) == 0
+        variants = []
+        for th in (64, 32, 12, 3, 0):
+            assert L.f3dg_set_option(b"render_pack_th", th) == 0
+            variants.append(run_hip(scene, gpu_device, save_aux=False))
+        assert b"render4" in L.f3dg_debug_last_render_kernel()
+        # the default: packed for inference launches in the reference's arithmetic, render3s in fast arithmetic
+        L.f3dg_set_option(b"render_pack", -1)
+        L.f3dg_set_option(b"render_pack_th", 32)
+        variants.append(run_hip(scene, gpu_device, save_aux=False))
+        import helpers
+        assert (b"render4" if helpers.RENDER_MODE == "exact" else b"render3s") in L.f3dg_debug_last_render_kernel()
+    finally:
+        L.f3dg_set_option(b"render_pack", -1)
+        L.f3dg_set_option(b"render_pack_th", 32)
+        L.f3dg_set_option(b"render_lowocc", 1)
+    for b in variants:
+        assert np.array_equal(a["out_color"].view(np.uint32), b["out_color"].view(np.uint32))
+    for v in range(scene["viewmatrix"].shape[0]):
+        o = run_oracle(scene, view=v)
+        assert_render_parity(variants[1]["out_color"][v], o["out_color"], "packed %s view %d" % (name, v))
+
+
 @pytest.mark.parametrize("tail", [64, 16, 3])
 def test_tail_schedule_thin_coverage(tail, gpu_device):
     """The tail schedule of the one-wave kernel (option render_tail) on the case it exists for: long tile lists of faint
