@@ -204,20 +204,22 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     chunks = [(a, min(a + args.views_per_call, V)) for a in range(0, V, args.views_per_call)]
     workspaces = {}
 
+    call_opts = {"exact": None, "tile_cull": None}     # per-call settings (F3DG_FLAG_EXACT / _NO_TILE_CULL): None = the process default
+
     def render_chunk(a, b, check, out=out):
         o, r, ws = f3d.rasterize_views(
             g["xyz"], g["opacity"], cams["viewmatrix"][a:b], cams["projmatrix"][a:b], cams["campos"][a:b], bg,
             image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs,
             scales=g["scaling"], rotations=g["rotation"], sh_degree=1, workspace=workspaces.get(b - a), out=out[a:b],
-            radii=radii[a:b], save_aux=False, check=check)
+            radii=radii[a:b], save_aux=False, check=check, **call_opts)
         return ws
 
     # calibration passes (untimed). First with the reference's tile lists: R_total = the reference's num_rendered, the unit count of
     # SURVEY 8d's byte formulas (the workload's size, whatever the implementation then skips). Then in the benched configuration:
     # sizes every chunk's workspace (capacity = max over chunks, +25 %) and counts the instances the launches really process.
-    _lib.check(L.f3dg_set_option(b"tile_cull", 0), "f3dg_set_option")
+    call_opts["tile_cull"] = False
     R_total = sum(render_chunk(a, b, check=True).num_rendered for a, b in chunks)
-    _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
+    call_opts["tile_cull"] = None
     counts = []
     for a, b in chunks:
         ws = render_chunk(a, b, check=True)
@@ -374,10 +376,10 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     # (3) the same build in the reference's own arithmetic (float32 with the float64 island, forward.cu:511-579), frames left in HBM
     exact = None
     if args.render_mode == "fast" and not args.no_exact:
-        _lib.check(L.f3dg_set_option(b"render_fast", 0), "f3dg_set_option")
+        call_opts["exact"] = True
         e_x, st_x, nc_x, _, rows_x = measure(step, 1, args.steps)
         kernel_name_x = L.f3dg_debug_last_render_kernel().decode()
-        _lib.check(L.f3dg_set_option(b"render_fast", 1), "f3dg_set_option")
+        call_opts["exact"] = None
         e_x = max_over_ranks(e_x, dist, world, comm_device if world > 1 else device)
         exact = (e_x, st_x, nc_x, rows_x, kernel_name_x)
 
@@ -710,9 +712,8 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
     dpix[:, 7] = 0
     kw = dict(image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"],
               rotations=g["rotation"], sh_degree=1, save_aux=True)
-    _lib.check(L.f3dg_set_option(b"tile_cull", 0), "f3dg_set_option")       # the reference's num_rendered: unit count of the byte formulas
-    R = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, **kw)[2].num_rendered
-    _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
+    # the reference's num_rendered: unit count of the byte formulas (per call: F3DG_FLAG_NO_TILE_CULL)
+    R = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, tile_cull=False, **kw)[2].num_rendered
     out, radii, ws = f3d.rasterize_views(g["xyz"], g["opacity"], cams["viewmatrix"], cams["projmatrix"], cams["campos"], bg, **kw)
     R_proc = ws.num_rendered
 

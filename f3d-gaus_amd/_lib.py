@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libf3dg_hip.so")
 
 OK, ERR_BAD_ARG, ERR_WORKSPACE, ERR_OVERFLOW, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 FLAG_SAVE_AUX, FLAG_BG_PER_VIEW, FLAG_SKIP_NORMAL, FLAG_SKIP_DISTORTION = 1, 2, 4, 8
+FLAG_EXACT, FLAG_FAST, FLAG_NO_TILE_CULL, FLAG_NO_SMALL_PATH = 16, 32, 64, 128
 PENDING = 1
 
 _ERR_TEXT = {

@@ -285,7 +285,8 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.offsets = take(VP * sizeof(unsigned));
     L.clamped = take(VP);
     L.rects = take(VP * sizeof(uint2));
-    L.gsort = take(7 * VP * sizeof(unsigned));
+    // (planes 4..6 exist for option sort_fused_rects only -- off by default, 3 x V x P x 4 bytes: 400 MB at C3's 512 views x 65,536)
+    L.gsort = take((g_f3dg_sort_fused_rects ? 7 : 4) * VP * sizeof(unsigned));
     L.scan_tmp = take((size_t)L.scan_tmp_elems * sizeof(unsigned));
     L.keys[0] = take(C * 8);
     L.keys[1] = take(C * 4);
@@ -402,14 +403,16 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     // without a set offset, and view2gaussian_precomp is [n_views, P, 10] of ONE set
     if (n_sets > 1 && (save_aux || view2gaussian_precomp != nullptr)) return F3DG_ERR_BAD_ARG;
     // small-call path (f3dg_small.hip): inference calls of one or two views of a modest set go projection -> per-tile sort -> compositing
-    const int small = g_f3dg_small_path && !save_aux && n_sets == 1 && P > 0 && L.small_cap != 0 && g_f3dg_render_kernel == 3 &&
-                      !small_disabled((unsigned)P, (unsigned)n_views, (unsigned)W, (unsigned)H);
+    // what this call runs with: the process-wide defaults of f3dg_set_option, overridden by the call's own flags
+    const int fast = (flags & F3DG_FLAG_EXACT) ? 0 : (flags & F3DG_FLAG_FAST) ? 1 : f3dg_render_uses_fast(save_aux);
+    const int tile_cull = (flags & F3DG_FLAG_NO_TILE_CULL) ? 0 : g_f3dg_tile_cull;
+    const int small = g_f3dg_small_path && !(flags & F3DG_FLAG_NO_SMALL_PATH) && !save_aux && n_sets == 1 && P > 0 && L.small_cap != 0 &&
+                      g_f3dg_render_kernel == 3 && !small_disabled((unsigned)P, (unsigned)n_views, (unsigned)W, (unsigned)H);
     // (the header is initialised by the first workgroup of the projection kernel; without Gaussians there is no such launch)
-    const F3dgHeaderInit hinit = { hdr, (unsigned)max_rendered, (unsigned)f3dg_render_uses_fast(save_aux), (unsigned)save_aux, (unsigned)small,
+    const F3dgHeaderInit hinit = { hdr, (unsigned)max_rendered, (unsigned)fast, (unsigned)save_aux, (unsigned)small,
                                    { (unsigned)P, (unsigned)n_views, (unsigned)W, (unsigned)H } };
     if (P == 0)
-        F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered, (unsigned)f3dg_render_uses_fast(save_aux),
-                     (unsigned)save_aux);
+        F3DG_KLAUNCH(init_header_kernel, dim3(1), dim3(64), 0, s, hdr, (unsigned)max_rendered, (unsigned)fast, (unsigned)save_aux);
 
     if (P == 0) {
         F3DG_KLAUNCH(fill_background_kernel, dim3(1024), dim3(256), 0, s, n_views, HW, background,
@@ -429,7 +432,7 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     rc = run_geometry(s, ws, L, n_views, views_per_set, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                       rotations, cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                       tan_fovy, focal_x, focal_y, kernel_size, radii_used, save_aux,
-                      save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, g_f3dg_tile_cull, prof, hinit, small);
+                      save_aux || g_f3dg_render_kernel == 1 /* the culling box: backward + the pixel-lane kernel */, tile_cull, prof, hinit, small);
     if (rc != F3DG_OK) return rc;
 
     rc = f3dg_launch_render(s, n_views, P, W, H, focal_x, focal_y, hdr,
@@ -441,7 +444,7 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
                               (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color,
                               reinterpret_cast<float*>(ws + L.final_T),
                               reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux,
-                              flags & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION));
+                              flags & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION), fast);
     prof_mark(prof, ST_RENDER, s);
     return rc;
 }
@@ -623,22 +626,30 @@ extern "C" int f3dg_status_post(void* stream, const void* workspace)
 {
     if (!workspace) return F3DG_ERR_BAD_ARG;
     int ticket = -1;
+    StatusSlot sl = { nullptr, nullptr, false };
     {
+        // the slot is COPIED under the lock (another thread's post may grow the vector), and a slot whose creation fails is not kept
         std::lock_guard<std::mutex> lock(g_status_mutex);
         for (size_t i = 0; i < g_status.size(); i++)
             if (!g_status[i].busy) { ticket = (int)i; break; }
         if (ticket < 0) {
-            StatusSlot sl = { nullptr, nullptr, false };
-            F3DG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.host), sizeof(F3dgHeader), hipHostMallocDefault));
-            F3DG_HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-            g_status.push_back(sl);
+            StatusSlot fresh = { nullptr, nullptr, false };
+            F3DG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&fresh.host), sizeof(F3dgHeader), hipHostMallocDefault));
+            const hipError_t e = hipEventCreateWithFlags(&fresh.ev, hipEventDisableTiming);
+            if (e != hipSuccess) { (void)hipHostFree(fresh.host); return f3dg_set_hip_error(e, "hipEventCreateWithFlags"); }
+            g_status.push_back(fresh);
             ticket = (int)g_status.size() - 1;
         }
         g_status[ticket].busy = true;
+        sl = g_status[ticket];
     }
-    const StatusSlot sl = g_status[ticket];
-    F3DG_HIP_CHECK(hipMemcpyAsync(sl.host, workspace, sizeof(F3dgHeader), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    F3DG_HIP_CHECK(hipEventRecord(sl.ev, (hipStream_t)stream));
+    hipError_t e = hipMemcpyAsync(sl.host, workspace, sizeof(F3dgHeader), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipEventRecord(sl.ev, (hipStream_t)stream);
+    if (e != hipSuccess) {          // the slot goes back: nothing will ever complete it
+        std::lock_guard<std::mutex> lock(g_status_mutex);
+        g_status[ticket].busy = false;
+        return f3dg_set_hip_error(e, "f3dg_status_post");
+    }
     return ticket;
 }
 

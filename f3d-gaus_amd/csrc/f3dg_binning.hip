@@ -242,7 +242,7 @@ struct ScatterShared {
     u32 sval[F3DG_SORT_CHUNK];
 };
 
-// What a view's LAST depth pass adds (option sort_fused_rects, the default): the element's payload is a Gaussian id and its final
+// What a view's LAST depth pass adds with option sort_fused_rects (off by default: measured equal): the element's payload is a Gaussian id and its final
 // position is known, so the pass also fetches that Gaussian's tile rectangle and writes it -- and its area = tiles touched, the input
 // of the prefix sum that places the instances -- at the sorted position. This is the one random gather of the path (an 8-byte read
 // per 128-byte line, from the view's 8 P bytes in its XCD's L2); inside the pass it flies behind the other chunks' LDS work of the CU

@@ -247,7 +247,7 @@ extern int g_f3dg_render_fast;         // 1 (default): float64 island of the ble
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
-                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels = 0u);
+                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels = 0u, int fast = -1 /* -1: the process default */);
 
 // the rank-packed compositing forward (f3dg_render4.hip; option render_kernel = 4, inference launches)
 extern int g_f3dg_render_pack;         // -1 (default): inference launches in the reference's arithmetic take render4; 1: all inference launches; 0: none

@@ -44,7 +44,7 @@
 #include <stdio.h>
 #include <string.h>
 
-extern const char* g_f3dg_last_render_kernel;
+extern thread_local const char* g_f3dg_last_render_kernel;
 
 namespace {
 
@@ -1397,7 +1397,7 @@ render3l_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
 } // namespace
 
 namespace {
-char g_kernel_name[160] = "";
+thread_local char g_kernel_name[160] = "";       // (per host thread: the library is called from several)
 void note_kernel(const char* base, int save_aux, int fast, const char* extra)
 {
     snprintf(g_kernel_name, sizeof g_kernel_name, "%s<SAVE_AUX=%s, FAST=%s%s>", base, save_aux ? "true" : "false", fast ? "true" : "false", extra);
@@ -1410,7 +1410,7 @@ int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
-                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels)
+                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels, int fast)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
@@ -1418,7 +1418,9 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     // fast arithmetic is for inference calls. A SAVE_AUX forward feeds f3dg_backward, which rebuilds every pixel's transmittance
     // back to front by dividing final_T by (1 - alpha) with ITS alphas: they must be the forward's to the bit, or the 1e-6 relative
     // difference is amplified by 1 / (1 - alpha) per layer (measured at C5: compositing-stage gradients 2.5e-5 vs 1.8e-6 off the oracle).
-    const int g_f3dg_render_fast = f3dg_render_uses_fast(save_aux);
+    // (the arithmetic is the CALL's: f3dg_forward_sets resolves its flags against the process default and records the choice in the
+    // workspace header for the backward)
+    const int g_f3dg_render_fast = fast < 0 ? f3dg_render_uses_fast(save_aux) : fast;
     if (g_f3dg_render_kernel == 3) {
         const dim3 grid3((unsigned)V * (unsigned)T * 4u);
 #define F3DG_LAUNCH3D(AUX, FST, DMA, OCC) F3DG_KLAUNCH((render3_fwd_kernel<AUX, FST, DMA, OCC>), grid3, dim3(64), (size_t)g_f3dg_render_lds_pad, s, V, P, W, H, tiles_x, T,  \
@@ -1549,7 +1551,7 @@ extern "C" int f3dg_debug_render_counts(unsigned long long* h_out8, int reset)
 }
 
 // the compositing forward kernel the last f3dg_launch_render of this process launched (what `roofline.kernel` of bench.py prints)
-const char* g_f3dg_last_render_kernel = "";
+thread_local const char* g_f3dg_last_render_kernel = "";
 extern "C" const char* f3dg_debug_last_render_kernel(void) { return g_f3dg_last_render_kernel; }
 
 // debug: read (and optionally reset) the phase-timing counters of a -DF3DG_TIMING build (zeros otherwise)

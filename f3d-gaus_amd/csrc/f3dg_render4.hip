@@ -25,7 +25,7 @@
 #include <stdio.h>
 #include <string.h>
 
-extern const char* g_f3dg_last_render_kernel;
+extern thread_local const char* g_f3dg_last_render_kernel;
 int g_f3dg_render_pack_th = 32;       // option render_pack_th: trips with at most this many participating pixels are packed (0: never)
 
 // work counters (option render_count = 1; f3dg_debug_render_counts rows 16..): [0] staged entries, [1] scanned, [2] fused trips,
@@ -376,7 +376,7 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     }
 }
 
-char g_kernel_name4[160] = "";
+thread_local char g_kernel_name4[160] = "";
 
 } // namespace
 

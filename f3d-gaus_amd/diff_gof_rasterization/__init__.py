@@ -75,11 +75,13 @@ class Workspace:
 
     def fits(self, P, W, H, n_views, max_rendered):
         """True (and the workspace now describes that call) if the buffer is large enough for it."""
-        if (self.P, self.W, self.H, self.n_views) == (P, W, H, n_views) and self.max_rendered >= max_rendered:
-            return True
-        need = _lib.lib().f3dg_workspace_bytes(int(P), int(W), int(H), int(n_views), int(max_rendered))
+        same = (self.P, self.W, self.H, self.n_views) == (P, W, H, n_views) and self.max_rendered >= max_rendered
+        # (asked again even for the same five numbers: the carving also depends on process options, e.g. sort_fused_rects)
+        need = _lib.lib().f3dg_workspace_bytes(int(P), int(W), int(H), int(n_views), int(self.max_rendered if same else max_rendered))
         if need == 0 or need > self.buffer.numel():
             return False
+        if same:
+            return True
         self.P, self.W, self.H, self.n_views, self.max_rendered = int(P), int(W), int(H), int(n_views), int(max_rendered)
         return True
 
@@ -146,7 +148,8 @@ def _check_inputs(means3D, sh, colors_precomp, opacities, scales, rotations, cov
 def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg, *, image_height, image_width,
                     tanfovx, tanfovy, sh=None, colors_precomp=None, scales=None, rotations=None, cov3Ds_precomp=None,
                     view2gaussian_precomp=None, sh_degree=0, scale_modifier=1.0, kernel_size=0.0, workspace=None,
-                    max_rendered=None, save_aux=False, out=None, radii=None, check=True, n_sets=1, channels="all"):
+                    max_rendered=None, save_aux=False, out=None, radii=None, check=True, n_sets=1, channels="all",
+                    exact=None, tile_cull=None, small_path=None):
     """Render ``n_views`` cameras of the same Gaussians in ONE launch sequence (f3dg_forward_batched).
 
     viewmatrices / projmatrices: [V,4,4] (any leading singleton dims), camposs [V,3], bg [3] or [V,3].
@@ -161,6 +164,11 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
     ``channels="rgb_depth_alpha"`` (inference only; the build's own batched loops): the compositing kernel neither accumulates nor
     writes the normal (3..5) and distortion (8) planes of ``color`` -- they hold whatever the buffer held -- and the channels it
     does write (0..2, 6, 7) are bit-identical to the 9-channel call (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION).
+
+    Per-call settings (``None`` = the process-wide default of ``f3dg_set_option``): ``exact=True`` composites this call in the
+    reference's float32 / float64 operation order (F3DG_FLAG_EXACT: what a consumer of the distortion channel wants), ``exact=False``
+    in the fast arithmetic (F3DG_FLAG_FAST); ``tile_cull=False`` builds the reference's tile lists (F3DG_FLAG_NO_TILE_CULL);
+    ``small_path=False`` keeps one- and two-view calls on the general launch sequence (F3DG_FLAG_NO_SMALL_PATH).
     """
     L = _lib.lib()
     device = means3D.device
@@ -188,6 +196,12 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
         flags |= _lib.FLAG_SKIP_NORMAL | _lib.FLAG_SKIP_DISTORTION
     elif channels != "all":
         raise RuntimeError('channels must be "all" or "rgb_depth_alpha"')
+    if exact is not None:
+        flags |= _lib.FLAG_EXACT if exact else _lib.FLAG_FAST
+    if tile_cull is not None and not tile_cull:
+        flags |= _lib.FLAG_NO_TILE_CULL
+    if small_path is not None and not small_path:
+        flags |= _lib.FLAG_NO_SMALL_PATH
 
     means3D = _dev_f32(means3D, device)
     sh = _dev_f32(sh, device)
@@ -309,12 +323,13 @@ def cpu_deep_copy_tuple(input_tuple):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        view2gaussian_precomp, raster_settings):
+                        view2gaussian_precomp, raster_settings, exact=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, view2gaussian_precomp, raster_settings)
+                                     cov3Ds_precomp, view2gaussian_precomp, raster_settings, exact)
 
 
-def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp):
+def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp,
+                  exact=None):
     """One reference-shaped rasterizer call (one view): (color [1,9,H,W], radii [1,P], workspace). Shared by the autograd Function
     and by the wrapper's inference path (`rasterize_nograd`)."""
     device = means3D.device
@@ -334,7 +349,7 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
             colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp,
             view2gaussian_precomp=view2gaussian_precomp, sh_degree=rs.sh_degree, scale_modifier=rs.scale_modifier,
             kernel_size=rs.kernel_size, workspace=workspace, save_aux=needs_grad, check=check, out=out, radii=radii,
-            max_rendered=max_rendered)
+            max_rendered=max_rendered, exact=exact)
 
     if rs.debug:
         # rast_py:88-98: keep a host copy of the arguments (in the order of the reference's tuple, rast_py:61-84) and dump
@@ -367,10 +382,11 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
     return color, radii, ws
 
 
-def rasterize_nograd(means3D, sh, colors_precomp, opacities, scales, rotations, raster_settings):
+def rasterize_nograd(means3D, sh, colors_precomp, opacities, scales, rotations, raster_settings, exact=None):
     """The inference call of `GaussianRasterizer_GOF.forward` without the nn.Module and autograd.Function around it (the wrapper's
-    own no-grad path: ~30 us of host time per call less). Returns (color [9,H,W], radii [P])."""
-    color, radii, _ = _forward_impl(raster_settings, False, means3D, sh, colors_precomp, opacities, scales, rotations, None, None)
+    own no-grad path: ~30 us of host time per call less). Returns (color [9,H,W], radii [P]). ``exact``: see `rasterize_views`."""
+    color, radii, _ = _forward_impl(raster_settings, False, means3D, sh, colors_precomp, opacities, scales, rotations, None, None,
+                                    exact=exact)
     return color[0], radii[0]
 
 
@@ -380,11 +396,11 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                view2gaussian_precomp, raster_settings):
+                view2gaussian_precomp, raster_settings, exact=None):
         rs = raster_settings
         needs_grad = any(ctx.needs_input_grad)      # (grad mode is always off inside Function.forward)
         color, radii, ws = _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                         view2gaussian_precomp)
+                                         view2gaussian_precomp, exact=exact)
         ctx.raster_settings = rs
         ctx.num_rendered = ws.num_rendered
         ctx.workspace = ws if needs_grad else None
@@ -629,9 +645,12 @@ def integrate_points(prepared, points3D, alpha_min=None, want_outputs=True):
 
 
 class GaussianRasterizer_GOF(nn.Module):
-    def __init__(self, raster_settings):
+    def __init__(self, raster_settings, exact=None):
+        """``raster_settings``: the reference's 14-field tuple (rast_py:168-182). ``exact`` (this build's one addition, keyword only in
+        spirit): True / False select the compositing arithmetic of THIS rasterizer's calls (see `rasterize_views`), None the process default."""
         super().__init__()
         self.raster_settings = raster_settings
+        self.exact = exact
 
     def markVisible(self, positions):
         """bool[P]: view-space z > 0.2 (rast_py:190-199 -> rasterizer_impl.cu:172-186)."""
@@ -672,7 +691,7 @@ class GaussianRasterizer_GOF(nn.Module):
             view2gaussian_precomp = empty
 
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, view2gaussian_precomp, raster_settings)
+                                   cov3D_precomp, view2gaussian_precomp, raster_settings, self.exact)
 
     def integrate(self, points3D, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
                   rotations=None, cov3D_precomp=None, view2gaussian_precomp=None):

@@ -62,4 +62,4 @@ def rasterize_backward(ctx, grad_out_color):
     return (g["dL_dmeans3D"], g["dL_dmeans2D"][0], none_if_empty(sh, g["dL_dsh"]),
             none_if_empty(colors_precomp, g["dL_dcolors"][0]), g["dL_dopacity"],
             none_if_empty(scales, g["dL_dscales"]), none_if_empty(rotations, g["dL_drotations"]),
-            None, None, None)
+            None, None, None, None)       # cov3Ds_precomp, view2gaussian_precomp, raster_settings, exact

@@ -21,6 +21,16 @@ from .diff_gof_rasterization import (GaussianRasterizationSettings_GOF, Gaussian
                                      rasterize_views)
 
 
+def _raster_exact(cfg):
+    """cfg['model']['raster_exact'] -> True / False / None (absent: the process default of f3dg_set_option("render_fast"))."""
+    try:
+        m = cfg['model']
+        v = m.get('raster_exact', None) if hasattr(m, 'get') else (m['raster_exact'] if 'raster_exact' in m else None)
+    except (KeyError, TypeError):
+        return None
+    return None if v is None else bool(v)
+
+
 def focal2fov(focal, pixels):
     return 2 * math.atan(pixels / (2 * focal))
 
@@ -145,7 +155,10 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
         kernel_size=kernel_size, subpixel_offset=subpixel_offset, bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=world_view_transform, projmatrix=full_proj_transform, sh_degree=cfg['model']['max_sh_degree'],
         campos=camera_center, prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer_GOF(raster_settings=raster_settings) if (torch.is_grad_enabled() or points3D is not None) else None
+    # cfg['model']['raster_exact'] (this build's key; absent = the process default): True composites THIS call in the reference's
+    # float32 / float64 order -- what a consumer of `distortion_map` asks for --, False in the fast arithmetic
+    exact = _raster_exact(cfg)
+    rasterizer = GaussianRasterizer_GOF(raster_settings=raster_settings, exact=exact) if (torch.is_grad_enabled() or points3D is not None) else None
 
     means3D = xyz
     means2D = screenspace_points
@@ -165,7 +178,7 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
         # inference: the same call without the nn.Module / autograd.Function wrapping (host time; the kernels are the same)
         shs = _cat_sh(get("features_dc"), get("features_rest")) if override_color is None else None
         rendered_image, radii = rasterize_nograd(means3D, shs, None if override_color is None else get("rgbs"), opacity, scales,
-                                                 rotations, raster_settings)
+                                                 rotations, raster_settings, exact=exact)
     elif override_color is None:
         shs = _cat_sh(get("features_dc"), get("features_rest"))
         rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None,
@@ -311,7 +324,7 @@ def render_views(pc: dict, bs, world_view_transforms, full_proj_transforms, came
             image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, sh=shs, colors_precomp=colors,
             scales=take(pc["scaling"]), rotations=take(pc["rotation"]), sh_degree=cfg['model']['max_sh_degree'],
             scale_modifier=scaling_modifier, kernel_size=kernel_size, workspace=workspace, check=check, n_sets=n_sets,
-            channels=channels)
+            channels=channels, exact=_raster_exact(cfg))
         lean = channels != "all"
         nw = dn = None
         if epilogue:

@@ -69,6 +69,19 @@ extern "C" {
  * with F3DG_FLAG_SAVE_AUX and by the kernels of one- or two-view launches (which then write all nine). */
 #define F3DG_FLAG_SKIP_NORMAL 4u
 #define F3DG_FLAG_SKIP_DISTORTION 8u
+/* Per-call selection of what f3dg_set_option sets as process-wide DEFAULTS (round 5). The reference hands every knob of a call through
+ * GaussianRasterizationSettings_GOF (RAST/diff_gof_rasterization/__init__.py:168-182); these bits do the same for the knobs this build
+ * adds, so that two streams / threads can render with different settings at the same time:
+ *   F3DG_FLAG_EXACT          the compositing of this call runs the reference's float32 / float64 operation order, whatever "render_fast" says
+ *                            (a consumer of the distortion channel -- 3-17 % relative off in fast arithmetic -- asks for it per call);
+ *   F3DG_FLAG_FAST           ... runs the fast arithmetic, also with F3DG_FLAG_SAVE_AUX (the backward repeats the forward's alpha from the
+ *                            workspace header, so the pair stays consistent); EXACT wins when both are given;
+ *   F3DG_FLAG_NO_TILE_CULL   the reference's tile lists (every tile of the 3-sigma square, forward.cu:364-374) instead of the culled ones;
+ *   F3DG_FLAG_NO_SMALL_PATH  the general launch sequence also for the shapes the three-launch small-call path serves. */
+#define F3DG_FLAG_EXACT 16u
+#define F3DG_FLAG_FAST 32u
+#define F3DG_FLAG_NO_TILE_CULL 64u
+#define F3DG_FLAG_NO_SMALL_PATH 128u
 
 #define F3DG_TILE 16             /* BLOCK_X = BLOCK_Y = 16, RAST/cuda_rasterizer/config.h:16-17 */
 #define F3DG_OUT_CHANNELS 9      /* RGB, normal xyz, median depth, alpha, distortion: auxiliary.h:21-24 */

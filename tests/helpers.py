@@ -82,13 +82,15 @@ def run_hip(scene, device, save_aux=True, max_rendered=None):
             tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], sh=dev(scene["shs"]),
             colors_precomp=dev(scene["colors_precomp"]), scales=dev(scene["scales"]), rotations=dev(scene["rotations"]),
             sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"], kernel_size=scene["kernel_size"],
-            save_aux=save_aux)
+            save_aux=save_aux, exact=_exact_flag())
         culled = (culled[0].clone(), culled[1].clone(), culled[2].num_rendered)
-    assert _lib.lib().f3dg_set_option(b"tile_cull", 0) == 0
-    try:
-        return _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled)
-    finally:
-        _lib.lib().f3dg_set_option(b"tile_cull", 1)
+    # (per call -- F3DG_FLAG_NO_TILE_CULL --, not through the process-wide option)
+    return _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled)
+
+
+def _exact_flag():
+    """The per-call arithmetic selection of the module fixture's RENDER_MODE (None: the process default)."""
+    return None if RENDER_MODE is None else RENDER_MODE == "exact"
 
 
 def _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled):
@@ -99,7 +101,7 @@ def _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled):
         tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], sh=dev(scene["shs"]),
         colors_precomp=dev(scene["colors_precomp"]), scales=dev(scene["scales"]), rotations=dev(scene["rotations"]),
         sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"], kernel_size=scene["kernel_size"],
-        save_aux=save_aux, max_rendered=max_rendered)
+        save_aux=save_aux, max_rendered=max_rendered, tile_cull=False, exact=_exact_flag())
     V, P, W, H = scene["viewmatrix"].shape[0], scene["P"], scene["W"], scene["H"]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     cap = ws.max_rendered

@@ -143,3 +143,14 @@ def test_stream_cache_and_alias_modules(f3d):
     assert list(c) == [4, 2, 9] and c.get(77) is None
     import f3dgaus_amd.diff_gof_rasterization.backward as b
     assert b.__spec__.name == "f3d-gaus_amd.diff_gof_rasterization.backward" and b.__package__ == "f3d-gaus_amd.diff_gof_rasterization"
+
+
+def test_flag_constants_match_the_header():
+    """The flag bits of f3dg_forward_sets as Python sees them are the header's."""
+    import re
+    from f3dgaus_amd import _lib
+    text = open(HEADER).read() if "HEADER" in globals() else open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "f3dg.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define F3DG_FLAG_(\w+)\s+(\d+)u", text)}
+    for name in ("SAVE_AUX", "BG_PER_VIEW", "SKIP_NORMAL", "SKIP_DISTORTION", "EXACT", "FAST", "NO_TILE_CULL", "NO_SMALL_PATH"):
+        assert getattr(_lib, "FLAG_" + name) == defs[name], name
+    assert len(set(defs.values())) == len(defs)
