@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--render-mode", choices=["fast", "exact"], default=os.environ.get("F3DG_RENDER_MODE", "fast"),
                     help="compositing arithmetic: fast = error-free float32 pairs for the float64 island (default, parity-gated "
                          "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
-    ap.add_argument("--backbone", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--backbone", choices=["fp32", "bf16", "fp16"], default="fp32",
                     help="c4: precision of the SongUNet backbone (bf16 = the opt-in autocast option, SURVEY 8f-3)")
     ap.add_argument("--backbone-layout", choices=["auto", "nchw", "nhwc"], default="auto",
                     help="c4: memory layout of the SongUNet backbone (auto, the default: channels-last for passes of two images or more; nhwc: "

@@ -50,6 +50,29 @@ template <> struct Packet<unsigned short> {
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
+// 8 float16 (the fp16 option of the backbone: 10 mantissa bits at the bf16 MFMA rate; T = _Float16)
+template <> struct Packet<_Float16> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const _Float16* p)
+    {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] & 0xFFFFu));
+            v[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] >> 16));
+        }
+    }
+    __device__ __forceinline__ void store(_Float16* p) const
+    {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            w[i] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * i]) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
 // SiLU. float32 activations: expf and an IEEE division (the backbone's float32 parity bar is 2e-5 of the reference fixture).
 // bfloat16 activations: the result is rounded to 8 bits, so hardware exp2 / reciprocal (~1 ulp of float32 each) are invisible and the
 // ~30 instructions per element of the accurate form -- which made the kernel VALU-bound -- become 5.
@@ -64,8 +87,10 @@ __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(unsigned short x) { return bf16_to_f32(x); }
 __device__ __forceinline__ void from_f32(float& d, float x) { d = x; }
 __device__ __forceinline__ void from_f32(unsigned short& d, float x) { d = f32_to_bf16(x); }
+__device__ __forceinline__ float to_f32(_Float16 x) { return (float)x; }
+__device__ __forceinline__ void from_f32(_Float16& d, float x) { d = (_Float16)x; }
 
-// T = float, or unsigned short holding bfloat16 (the bf16 option of the backbone: statistics and arithmetic stay float32 / float64).
+// T = float, unsigned short holding bfloat16, or _Float16 (the bf16 / fp16 options of the backbone: statistics and arithmetic stay float32 / float64).
 // pre_bias (nullable, [C] float32): added to x on the way in -- the bias of the convolution that produced x, which PyTorch-ROCm would
 // otherwise apply as a separate read + write pass behind MIOpen's kernel (108 such passes per backbone pass, profiles/r04_final/unet.md).
 template <typename T>
@@ -170,12 +195,11 @@ int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const 
 // layout only pays if GroupNorm keeps it. x is [N][HW][C]: a group's Cg channels are 8..64 bytes of every pixel's C-vector, so a
 // workgroup takes a run of pixels with ALL channels (whole lines), and the moments of a (sample, group) are summed across workgroups:
 //   gn_nhwc_moments_kernel: thread (row, col) owns the 16-byte packet `col` of the pixels row, row + rows, ...: float sums per channel
-//       over at most GN_NHWC_PIX / rows pixels, per-channel totals over the rows in LDS, per-group totals added in float64 (atomics) to
-//       moments[n][g] = (sum, sum of squares);
+//       over at most GN_NHWC_PIX / rows pixels, per-channel totals over the rows in LDS, per-group totals in float64 written to
+//       partial[n][block][g] = (sum, sum of squares); gn_nhwc_finish_kernel adds the blocks in order -> (mean, rstd) per (sample, group);
 //   gn_nhwc_apply_kernel: the same mapping; scale / shift of the thread's PN channels once, then one pass: silu((x + pre_bias) * sc + sh).
 // Two reads (the second from L2 / MALL) and one write, as the NCHW kernel.
 constexpr int GN_NHWC_PIX = 512;      // pixels per workgroup
-constexpr int GN_NHWC_SLOTS = 8;      // copies of the moments the workgroups of a sample spread their atomics over
 constexpr int GN_NHWC_MAXC = 1024;
 constexpr int GN_NHWC_UNROLL = 4;     // independent 16-byte loads in flight per thread
 
@@ -221,22 +245,42 @@ gn_nhwc_moments_kernel(int C, int HW, int groups, int rows, const T* __restrict_
         ca[c] = t1; cb[c] = t2;
     }
     __syncthreads();
-    // per-group totals in float64, added to one of GN_NHWC_SLOTS copies of the (sample, group) pair: a sample's workgroups spread their
-    // atomics over the copies (the apply kernel adds them up) instead of queueing on one address
+    // per-group totals in float64, one (sum, sum of squares) pair per WORKGROUP: partial[n][block][g]. No atomics -- the second stage
+    // (gn_nhwc_finish_kernel) adds a sample's blocks up in block order, so the statistics, and with them the whole backbone pass, are
+    // bit-reproducible from run to run (until round 5 the blocks added into 8 atomic slots in arrival order)
     const int Cg = C / groups;
-    double* mslot = moments + 2 * (size_t)(blockIdx.x % GN_NHWC_SLOTS) * gridDim.y * groups;
+    double* part = moments + 2 * ((size_t)n * gridDim.x + blockIdx.x) * groups;
     for (int g = threadIdx.x; g < groups; g += blockDim.x) {
         double s1 = 0.0, s2 = 0.0;
         for (int c = g * Cg; c < (g + 1) * Cg; c++) { s1 += (double)ca[c]; s2 += (double)cb[c]; }
-        unsafeAtomicAdd(&mslot[2 * ((size_t)n * groups + g)], s1);
-        unsafeAtomicAdd(&mslot[2 * ((size_t)n * groups + g) + 1], s2);
+        part[2 * g] = s1;
+        part[2 * g + 1] = s2;
     }
+}
+
+// second stage: thread (n, g) adds the nb partial pairs of its (sample, group) in block order and leaves mean and 1 / sqrt(var + eps) as
+// two floats behind the partials (stats[n][g]): the apply kernel's threads read them instead of each recomputing them in float64
+__global__ void __launch_bounds__(256)
+gn_nhwc_finish_kernel(int N, int groups, int nb, double cnt, float eps, const double* __restrict__ partial, float2* __restrict__ stats)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * groups) return;
+    const int n = i / groups, g = i % groups;
+    double m1 = 0.0, m2 = 0.0;
+    for (int b = 0; b < nb; b++) {
+        const double* p = partial + 2 * (((size_t)n * nb + b) * groups + g);
+        m1 += p[0]; m2 += p[1];
+    }
+    const double m = m1 / cnt;
+    double var = m2 / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    stats[i] = make_float2((float)m, (float)(1.0 / sqrt(var + (double)eps)));
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, const float* __restrict__ pre_bias, const double* __restrict__ moments,
-                     const float* __restrict__ weight, const float* __restrict__ bias, float eps, int apply_silu, T* __restrict__ y)
+gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ x, const float* __restrict__ pre_bias, const float2* __restrict__ stats,
+                     const float* __restrict__ weight, const float* __restrict__ bias, int apply_silu, T* __restrict__ y)
 {
     constexpr int PN = Packet<T>::N;
     const int ppp = C / PN;
@@ -246,31 +290,14 @@ gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ 
     const int p0 = blockIdx.x * GN_NHWC_PIX;
     const int p1 = min(p0 + GN_NHWC_PIX, HW);
     const int Cg = C / groups;
-    const double cnt = (double)Cg * (double)HW;
     float sc[PN], sh[PN], pb[PN];
-    {
-        int g_prev = -1;
-        float mean = 0.0f, rstd = 0.0f;
 #pragma unroll
-        for (int k = 0; k < PN; k++) {
-            const int c = col * PN + k, g = c / Cg;
-            if (g != g_prev) {
-                double m1 = 0.0, m2 = 0.0;
-                for (int sl = 0; sl < GN_NHWC_SLOTS; sl++) {
-                    const double* ms = moments + 2 * ((size_t)sl * gridDim.y * groups + (size_t)n * groups + g);
-                    m1 += ms[0]; m2 += ms[1];
-                }
-                const double m = m1 / cnt;
-                double var = m2 / cnt - m * m;
-                if (var < 0.0) var = 0.0;
-                mean = (float)m;
-                rstd = (float)(1.0 / sqrt(var + (double)eps));
-                g_prev = g;
-            }
-            sc[k] = weight[c] * rstd;
-            sh[k] = bias[c] - mean * sc[k];
-            pb[k] = pre_bias ? pre_bias[c] : 0.0f;
-        }
+    for (int k = 0; k < PN; k++) {
+        const int c = col * PN + k;
+        const float2 st = stats[(size_t)n * groups + c / Cg];        // (mean, rstd)
+        sc[k] = weight[c] * st.y;
+        sh[k] = bias[c] - st.x * sc[k];
+        pb[k] = pre_bias ? pre_bias[c] : 0.0f;
     }
     const size_t base = ((size_t)n * HW) * C + (size_t)col * PN;
     for (int p = p0 + row; p < p1; p += rows * GN_NHWC_UNROLL) {
@@ -303,10 +330,13 @@ int launch_gn_nhwc(void* stream, int N, int C, int HW, int groups, const T* x, c
     if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;
     const int ppp = C / PN, rows = 256 / ppp;
     hipStream_t s = (hipStream_t)stream;
-    F3DG_HIP_CHECK(hipMemsetAsync(moments, 0, sizeof(double) * 2 * GN_NHWC_SLOTS * (size_t)N * groups, s));
-    const dim3 grid((unsigned)((HW + GN_NHWC_PIX - 1) / GN_NHWC_PIX), (unsigned)N);
+    const int nb = (HW + GN_NHWC_PIX - 1) / GN_NHWC_PIX;
+    float2* stats = reinterpret_cast<float2*>(moments + 2 * (size_t)N * nb * groups);
+    const dim3 grid((unsigned)nb, (unsigned)N);
     F3DG_KLAUNCH(gn_nhwc_moments_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, pre_bias, moments);
-    F3DG_KLAUNCH(gn_nhwc_apply_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, pre_bias, moments, weight, bias, eps, apply_silu, y);
+    F3DG_KLAUNCH(gn_nhwc_finish_kernel, dim3((unsigned)((N * groups + 255) / 256)), dim3(256), 0, s, N, groups, nb, (double)(C / groups) * (double)HW, eps,
+                 moments, stats);
+    F3DG_KLAUNCH(gn_nhwc_apply_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, pre_bias, stats, weight, bias, apply_silu, y);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
@@ -405,6 +435,21 @@ extern "C" int f3dg_residual_join_bf16(void* stream, int N, int C, int HW, int n
     return launch_join<unsigned short>(stream, N, C, HW, nhwc, a, bias_a, b, bias_b, scale, y);
 }
 
+extern "C" int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const uint16_t* a, const float* bias_a, const uint16_t* b,
+                                      const float* bias_b, float scale, uint16_t* y)
+{
+    return launch_join<_Float16>(stream, N, C, HW, nhwc, reinterpret_cast<const _Float16*>(a), bias_a, reinterpret_cast<const _Float16*>(b), bias_b, scale,
+                                 reinterpret_cast<_Float16*>(y));
+}
+
+// bytes of the `moments` scratch of the channels-last GroupNorm: the workgroups' partial sums + the (mean, rstd) pairs
+extern "C" size_t f3dg_group_norm_nhwc_scratch_bytes(int N, int HW, int groups)
+{
+    if (N <= 0 || HW <= 0 || groups <= 0) return 0;
+    const size_t nb = (size_t)(HW + GN_NHWC_PIX - 1) / GN_NHWC_PIX;
+    return sizeof(double) * 2 * (size_t)N * nb * groups + sizeof(float2) * (size_t)N * groups;
+}
+
 // GroupNorm (+ SiLU) with the producing convolution's bias folded in (pre_bias, nullable): NCHW ...
 extern "C" int f3dg_group_norm_silu_pb(void* stream, int N, int C, int HW, int groups, const float* x, const float* pre_bias, const float* weight,
                                        const float* bias, float eps, int apply_silu, float* y)
@@ -418,7 +463,20 @@ extern "C" int f3dg_group_norm_silu_pb_bf16(void* stream, int N, int C, int HW, 
     return launch_gn<unsigned short>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y);
 }
 
+extern "C" int f3dg_group_norm_silu_pb_f16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias, const float* weight,
+                                           const float* bias, float eps, int apply_silu, uint16_t* y)
+{
+    return launch_gn<_Float16>(stream, N, C, HW, groups, reinterpret_cast<const _Float16*>(x), pre_bias, weight, bias, eps, apply_silu, reinterpret_cast<_Float16*>(y));
+}
+
 // ... and channels-last
+extern "C" int f3dg_group_norm_silu_nhwc_pb_f16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
+                                                const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments)
+{
+    return launch_gn_nhwc<_Float16>(stream, N, C, HW, groups, reinterpret_cast<const _Float16*>(x), pre_bias, weight, bias, eps, apply_silu,
+                                    reinterpret_cast<_Float16*>(y), moments);
+}
+
 extern "C" int f3dg_group_norm_silu_nhwc_pb(void* stream, int N, int C, int HW, int groups, const float* x, const float* pre_bias, const float* weight,
                                             const float* bias, float eps, int apply_silu, float* y, double* moments)
 {
@@ -431,7 +489,7 @@ extern "C" int f3dg_group_norm_silu_nhwc_pb_bf16(void* stream, int N, int C, int
     return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y, moments);
 }
 
-// GroupNorm (+ SiLU) of a channels-last tensor, x and y [N][HW][C]; `moments` is scratch of 2 * GN_NHWC_SLOTS (= 8) * N * groups doubles (zeroed here)
+// GroupNorm (+ SiLU) of a channels-last tensor, x and y [N][HW][C]; `moments` is scratch of f3dg_group_norm_nhwc_scratch_bytes(N, HW, groups) bytes
 extern "C" int f3dg_group_norm_silu_nhwc(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
                                          const float* bias, float eps, int apply_silu, float* y, double* moments)
 {

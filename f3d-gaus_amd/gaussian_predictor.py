@@ -58,6 +58,10 @@ def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
 
 
+_HALF_DTYPES = (torch.bfloat16, torch.float16)
+_KERNEL_SUFFIX = {torch.float32: "", torch.bfloat16: "_bf16", torch.float16: "_f16"}      # of the GroupNorm / residual-join entry points
+
+
 class Conv2d(nn.Module):
     """Convolution with optional x2 up / down resampling BEFORE the convolution (gaussian_predictor.py:137-178 with
     resample_filter [1,1], fused_resample False). kernel = 0 means "resample only"."""
@@ -87,7 +91,7 @@ class Conv2d(nn.Module):
             t = w.to(dtype)
             return t.contiguous(memory_format=torch.channels_last) if nhwc else t
         try:
-            key = (w._version, w.data_ptr(), dtype, nhwc)
+            key = (w._version, w.data_ptr(), w.device, dtype, nhwc)
         except RuntimeError:            # (inference-mode tensors have no version counter: no cache)
             t = w.to(dtype)
             return t.contiguous(memory_format=torch.channels_last) if nhwc else t
@@ -99,6 +103,21 @@ class Conv2d(nn.Module):
             cached = (key, t)
             self.__dict__["_filter_cache"] = cached
         return cached[1]
+
+    def invalidate_filter_cache(self):
+        """Drops the converted filter copy. The cache key (version counter, storage pointer, device) notices optimizer steps, in-place
+        tensor methods, ``load_state_dict`` and ``.to()`` -- but NOT writes through ``param.data`` (``param.data.copy_()``, ``.mul_()``: EMA
+        swaps, manual weight surgery) or through a raw pointer, which leave the version counter alone: after such a write call this (or
+        ``GaussianSplatPredictor_gtunet.invalidate_filter_cache()``), or the backbone keeps convolving with the old filters."""
+        self.__dict__.pop("_filter_cache", None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_filter_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_filter_cache()
+        return super()._apply(fn, *args, **kwargs)
 
     def forward(self, x, N_views_xa=1, bias=True):
         """``bias=False``: the convolution without its bias -- the caller hands ``self.bias`` to the kernel that consumes the result
@@ -122,7 +141,7 @@ class GroupNorm(nn.Module):
 
     def _fusable(self, x):
         """Inference on a HIP device in a dtype the kernels take: the fused HIP kernels run (no autograd through them)."""
-        return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 3 and self.weight.dtype == torch.float32 and not (
+        return x.is_cuda and x.dtype in _KERNEL_SUFFIX and x.dim() >= 3 and self.weight.dtype == torch.float32 and not (
             torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))
 
     def forward(self, x, N_views_xa=1, silu=False, pre_bias=None):
@@ -136,8 +155,9 @@ class GroupNorm(nn.Module):
                 # layout option "nhwc": the channels-last kernel, channels-last out
                 y = torch.empty_like(x)           # preserves the strides
                 N, Cc = x.shape[0], x.shape[1]
-                mom = torch.empty(2 * 8 * N * self.num_groups, dtype=torch.float64, device=x.device)     # GN_NHWC_SLOTS copies
-                fn = L.f3dg_group_norm_silu_nhwc_pb if x.dtype == torch.float32 else L.f3dg_group_norm_silu_nhwc_pb_bf16
+                HW = x.shape[2] * x.shape[3]
+                mom = torch.empty(L.f3dg_group_norm_nhwc_scratch_bytes(N, HW, self.num_groups) // 8 + 1, dtype=torch.float64, device=x.device)
+                fn = getattr(L, "f3dg_group_norm_silu_nhwc_pb" + _KERNEL_SUFFIX[x.dtype])
                 rc = fn(_stream(), N, Cc, x.shape[2] * x.shape[3], self.num_groups, _lib.ptr(x), _lib.ptr(pre_bias), _lib.ptr(self.weight),
                         _lib.ptr(self.bias), float(self.eps), 1 if silu else 0, _lib.ptr(y), _lib.ptr(mom))
                 _lib.check(rc, "f3dg_group_norm_silu_nhwc_pb")
@@ -145,7 +165,7 @@ class GroupNorm(nn.Module):
             xc = x.contiguous()
             y = torch.empty_like(xc)
             N, Cc = xc.shape[0], xc.shape[1]
-            fn = L.f3dg_group_norm_silu_pb if x.dtype == torch.float32 else L.f3dg_group_norm_silu_pb_bf16
+            fn = getattr(L, "f3dg_group_norm_silu_pb" + _KERNEL_SUFFIX[x.dtype])
             rc = fn(_stream(), N, Cc, xc.numel() // max(N * Cc, 1), self.num_groups, _lib.ptr(xc), _lib.ptr(pre_bias), _lib.ptr(self.weight),
                     _lib.ptr(self.bias), float(self.eps), 1 if silu else 0, _lib.ptr(y))
             _lib.check(rc, "f3dg_group_norm_silu_pb")
@@ -162,7 +182,7 @@ def residual_join(a, bias_a, b, bias_b, scale):
     PyTorch ops otherwise. Writes into ``a``'s storage when it can."""
     def tb(t, bias):
         return t if bias is None else t + bias.to(t.dtype).reshape(1, -1, 1, 1)
-    ok = (a.is_cuda and a.dim() == 4 and a.dtype in (torch.float32, torch.bfloat16) and b.dtype == a.dtype and a.shape == b.shape
+    ok = (a.is_cuda and a.dim() == 4 and a.dtype in _KERNEL_SUFFIX and b.dtype == a.dtype and a.shape == b.shape
           and not (torch.is_grad_enabled() and (a.requires_grad or b.requires_grad))
           and all(t is None or (t.dtype == torch.float32 and t.is_contiguous()) for t in (bias_a, bias_b))
           and a.numel() % (4 if a.dtype == torch.float32 else 8) == 0)
@@ -172,7 +192,7 @@ def residual_join(a, bias_a, b, bias_b, scale):
             nhwc and a.shape[1] % (4 if a.dtype == torch.float32 else 8))
         if same and (a.data_ptr() | b.data_ptr()) % 16 == 0:
             N, Cc, H, W = a.shape
-            fn = _lib.lib().f3dg_residual_join if a.dtype == torch.float32 else _lib.lib().f3dg_residual_join_bf16
+            fn = getattr(_lib.lib(), "f3dg_residual_join" + _KERNEL_SUFFIX[a.dtype])
             _lib.check(fn(_stream(), N, Cc, H * W, 1 if nhwc else 0, _lib.ptr(a), _lib.ptr(bias_a), _lib.ptr(b), _lib.ptr(bias_b), float(scale),
                           _lib.ptr(a)), "f3dg_residual_join")
             return a
@@ -361,6 +381,13 @@ def splat_head(net_out, depth, ray_dirs, view_to_world, cam_quat, squre_clip=100
 
 
 class GaussianSplatPredictor_gtunet(nn.Module):
+    def invalidate_filter_cache(self):
+        """Forget every convolution's converted filter copy (see ``Conv2d.invalidate_filter_cache``: needed after writes through
+        ``param.data`` or raw pointers, which no version counter sees)."""
+        for mod in self.modules():
+            if isinstance(mod, Conv2d):
+                mod.invalidate_filter_cache()
+
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
@@ -373,9 +400,22 @@ class GaussianSplatPredictor_gtunet(nn.Module):
                 "network_with_offset, max_sh_degree 1, anisotropic, no origin_distances / uncertainty head)")
         split_dimensions, scale_inits, bias_inits = self.get_splits_and_inits(True, cfg)
         self.network_with_offset = networkCallBack(cfg, m['name'], split_dimensions, scale=scale_inits, bias=bias_inits)
-        # extension: "bf16" runs the backbone's convolutions under bfloat16 autocast with bf16 activations between
-        # the layers (GroupNorm statistics, attention and the splat head stay float32); "fp32" (default) is the reference's precision
+        # extension: "bf16" / "fp16" run the backbone's convolutions under bfloat16 / float16 autocast with 16-bit activations
+        # between the layers (GroupNorm statistics, attention and the splat head stay float32); "fp32" (default) is the reference's
+        # precision. bf16 costs the colour of a frame (RGB 24 dB against the fp32 backbone on the real image); fp16 has three more
+        # mantissa bits at the same MFMA rate, and every activation is GroupNorm-bounded (profiles/r05_final/fp16_frames.md)
         self.backbone_dtype = str(m.get('backbone_dtype', 'fp32'))
+        if self.backbone_dtype not in ("fp32", "bf16", "fp16"):
+            raise ValueError("backbone_dtype must be 'fp32', 'bf16' or 'fp16'")
+        # extension: inference passes of more than `backbone_chunk` images run as chunks of that many (the images of a pass are
+        # independent: cross-view attention couples only the Nv views of one image, and chunks are whole images). Why: MIOpen's find step
+        # BENCHMARKS its candidate kernels at the real problem size the first time a process (a box without a find-db) meets a shape --
+        # measured on a fresh MI355X box 43 s for the first 8-image fp32 pass, 85 s at 16, 6-7 minutes at 64 -- and its fast find mode
+        # (MIOPEN_FIND_MODE=2: 2.7 s) picks kernels 2.3x (fp32) to 12x (bf16) slower. The fp32 backbone's cost per image is flat from 8
+        # images on (10.7 / 10.2 / 10.2 ms at 8 / 16 / 64), so its default is 8: a 64-image pass is eight 8-image passes, first use
+        # bounded at 43 s whatever the batch. 0 = never chunk: the default of the 16-bit options, whose MFMA kernels still gain from
+        # larger batches (2.3 against 2.8 ms per image at 64 / 16 images) -- set it there to bound the first use as well.
+        self.backbone_chunk = int(m.get('backbone_chunk', 8 if self.backbone_dtype == "fp32" else 0))
         # extension: "nhwc" keeps the backbone's activations and filters channels-last, the layout of MIOpen's fastest kernels on gfx950 --
         # GroupNorm+SiLU and the residual join are channels-last HIP kernels, nothing converts in between (fp32 pass 92 -> 82 ms, bf16
         # 30 -> 25 ms per 8 images; the reference fixture within 1.0e-5); "nchw" is torch's layout, which is faster for ONE image per pass
@@ -432,18 +472,28 @@ class GaussianSplatPredictor_gtunet(nn.Module):
         x = x.reshape(B * Nv, *x.shape[2:])
         v2w = source_cameras_view_to_world.reshape(B * Nv, 4, 4)
         quat = source_cv2wT_quat.reshape(B * Nv, 4)
-        # ("auto": measured crossover -- fp32 25.9 against 26.4 ms at two images, bf16 11.5 against 10.8 at two and 24.2 against 25.4 at eight)
-        if x.is_cuda and not torch.is_grad_enabled() and (self.backbone_layout == "nhwc" or (
-                self.backbone_layout == "auto" and x.shape[0] >= (4 if self.backbone_dtype == "bf16" else 2))):
-            x = x.contiguous(memory_format=torch.channels_last)       # (the filters follow per convolution: Conv2d._filter)
-        if self.backbone_dtype == "bf16" and x.is_cuda and not torch.is_grad_enabled():
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)
-            net_out = net_out.float()
-        elif self.backbone_dtype not in ("fp32", "bf16"):
-            raise ValueError("backbone_dtype must be 'fp32' or 'bf16'")
+        inference = x.is_cuda and not torch.is_grad_enabled()
+        half = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self.backbone_dtype) if inference else None
+
+        def backbone(xc):
+            # ("auto": measured crossover -- fp32 25.9 against 26.4 ms at two images, bf16 11.5 against 10.8 at two and 24.2 against 25.4 at eight)
+            if inference and (self.backbone_layout == "nhwc" or (self.backbone_layout == "auto" and xc.shape[0] >= (4 if half is not None else 2))):
+                xc = xc.contiguous(memory_format=torch.channels_last)       # (the filters follow per convolution: Conv2d._filter)
+            if half is not None:
+                with torch.autocast("cuda", dtype=half):
+                    return self.network_with_offset(xc, film_camera_emb=None, N_views_xa=N_views_xa).float()
+            return self.network_with_offset(xc, film_camera_emb=None, N_views_xa=N_views_xa)
+
+        step = self.backbone_chunk * N_views_xa if self.backbone_chunk > 0 else 0
+        if inference and step and x.shape[0] > step:
+            net_out = None
+            for i in range(0, x.shape[0], step):
+                part = backbone(x[i:i + step])
+                if net_out is None:
+                    net_out = torch.empty((x.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+                net_out[i:i + step] = part
         else:
-            net_out = self.network_with_offset(x, film_camera_emb=None, N_views_xa=N_views_xa)
+            net_out = backbone(x)
         net_out = net_out.contiguous()                  # (the splat head reads planar channels)
         H, W = net_out.shape[-2:]
         depth = unet_depth.reshape(B * Nv, 1, H, W)

@@ -310,7 +310,10 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
                               const float* bias, float eps, int apply_silu, uint16_t* y);
 /* The same for channels-last activations (the backbone's "nhwc" layout option: MIOpen's NHWC convolution kernels without the layout
  * transposes around them): x, y [N,HW,C] contiguous, C a multiple of 4 (float32) / 8 (bfloat16) and at most 1024;
- * `moments` is scratch of 16 * N * groups doubles (8 copies of the (sum, sum of squares) pairs; cleared by the call). Same statistics, same formula. */
+ * `moments` is scratch of f3dg_group_norm_nhwc_scratch_bytes(N, HW, groups) bytes: one (sum, sum of squares) pair per workgroup, sample
+ * and group, added up in workgroup order by a second-stage kernel -- no atomics, the statistics are bit-reproducible from run to run
+ * (round 5; until then the workgroups added into 8 atomic slots in arrival order). Same statistics, same formula. */
+size_t f3dg_group_norm_nhwc_scratch_bytes(int N, int HW, int groups);
 int f3dg_group_norm_silu_nhwc(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
                               const float* bias, float eps, int apply_silu, float* y, double* moments);
 int f3dg_group_norm_silu_nhwc_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
@@ -326,6 +329,12 @@ int f3dg_group_norm_silu_nhwc_pb(void* stream, int N, int C, int HW, int groups,
                                  const float* bias, float eps, int apply_silu, float* y, double* moments);
 int f3dg_group_norm_silu_nhwc_pb_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
                                       const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments);
+/* ... and with IEEE float16 activations in and out (the fp16 option of the backbone, round 5: the bf16 MFMA rate with 10 mantissa bits
+ * instead of 7; every activation of the backbone is GroupNorm-bounded). Weight / bias and all arithmetic float32, the moments float64. */
+int f3dg_group_norm_silu_pb_f16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias, const float* weight,
+                                const float* bias, float eps, int apply_silu, uint16_t* y);
+int f3dg_group_norm_silu_nhwc_pb_f16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
+                                     const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments);
 /* The residual join of a backbone block (src/gaussian_predictor.py:325-327: the second convolution's bias, `x = x + skip(orig)` with the
  * skip convolution's bias, `x = x * skip_scale`) as ONE elementwise pass: y = ((a + bias_a[c]) + (b + bias_b[c])) * scale in float32,
  * the reference's order. a, b, y [N,C,HW] (nhwc = 0) or [N,HW,C] (nhwc = 1), 16-byte aligned, N*C*HW a multiple of 4 (float32) / 8
@@ -334,6 +343,8 @@ int f3dg_residual_join(void* stream, int N, int C, int HW, int nhwc, const float
                        const float* bias_b, float scale, float* y);
 int f3dg_residual_join_bf16(void* stream, int N, int C, int HW, int nhwc, const uint16_t* a, const float* bias_a, const uint16_t* b,
                             const float* bias_b, float scale, uint16_t* y);
+int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const uint16_t* a, const float* bias_a, const uint16_t* b,
+                           const float* bias_b, float scale, uint16_t* y);
 
 /* Runtime switches (process-wide). Known names: "render_pretest" (default 1): the compositing kernel first runs a
  * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;

@@ -156,6 +156,10 @@ def test_c5_one_million_gaussians_32_views_forward_backward(gpu_device):
 def cycle_loop_check(device, B, res, V=8, seed=0):
     """cycle_aggregate (batched renders, in-place merge) against the reference-shaped loop (visualize.py:283-340: per-view
     renderer calls, per-view predictor calls, torch.cat merge) run with the same operators. Random weights."""
+    return _cycle_loop_check(device, B, res, V, seed)
+
+
+def _cycle_loop_check(device, B, res, V, seed):
     torch.manual_seed(seed)
     cfg = cameras.default_cfg(res)
     model = f3d.Unet_GS_gtunet(cfg, renderer=f3d.render_predicted_more_v2_gof).to(device).eval()
@@ -173,13 +177,18 @@ def cycle_loop_check(device, B, res, V=8, seed=0):
         x0 = torch.cat([images, torch.ones_like(images[:, :1])], 1).unsqueeze(1)
         _, _, gsb = model(x0, bg, cano.view_to_world_transforms.expand(B, 1, 4, 4).to(device),
                           cano.source_cv2wT_quat.expand(B, 1, 4).to(device), unet_depth=depth)
-        # two U-Net passes over the same input may differ by GEMM/conv algorithm noise (MIOpen may pick another kernel for the same shape
-        # when its workspace budget differs) and by the summation order of the channels-last GroupNorm's float64 atomics; the splat head is
-        # deterministic. (1e-5 until round 4, when one full-suite run in four failed in this function and passed re-run alone: a
-        # structural error would be O(1), so the bars for noise are now 1e-4 here and 1e-3 after the re-predictions)
+        # two U-Net passes over the same input. The build's own kernels are run-to-run bit-reproducible (the channels-last GroupNorm sums
+        # its partial moments in a fixed order since round 5) and so is the attention; what is not are three of MIOpen's 36 convolution
+        # configurations -- the 3x3 / 1x1 convolutions with 256 / 512 input channels at 32x32, split-K kernels that add with atomics --
+        # measured by tools/unet_determinism.py: 2e-6 absolute on a backbone output of 4.6, which the splat head turns into 5.5e-6 ..
+        # 8.1e-6 relative on the Gaussians (four runs, profiles/r05_final/unet_determinism.md). MIOpen's deterministic attribute is no
+        # way out (it falls back to kernels 200x slower: 15 s per 8-image pass). Bars: 3e-5 here (round 4: 1e-4), 1e-4 after the
+        # re-predictions (round 4: 1e-3; measured 1.6e-6 .. 2.2e-6)
+        first = worst = 0.0
         for k in gsb:
             d = (gsb[k] - merged[k][:, :HW]).abs().max().item()
-            assert d <= 1e-4 * max(1.0, gsb[k].abs().max().item()), (k, d)
+            first = max(first, d / max(1.0, gsb[k].abs().max().item()))
+            assert d <= 3e-5 * max(1.0, gsb[k].abs().max().item()), (k, d)
         # from here on use the SAME first-pass Gaussians for both loops (sigma ~ 0.01 scenes amplify 1-ulp input differences to
         # 1e-2 in the render), so renders must agree bit for bit
         gsb = {k: merged[k][:, :HW].contiguous() for k in gsb}
@@ -203,7 +212,9 @@ def cycle_loop_check(device, B, res, V=8, seed=0):
     for k in ref:
         assert ref[k].shape == merged[k].shape, k
         d = (ref[k] - merged[k]).abs().max().item()
-        assert d <= 1e-3 * max(1.0, ref[k].abs().max().item()), (k, d)
+        worst = max(worst, d / max(1.0, ref[k].abs().max().item()))
+        assert d <= 1e-4 * max(1.0, ref[k].abs().max().item()), (k, d)
+    print(f"cycle_loop_check B={B} V={V}: first pass max rel {first:.2e} (bar 3e-5), merged sets max rel {worst:.2e} (bar 1e-4)")
     return merged, cfg, rig
 
 
@@ -221,11 +232,12 @@ def test_c3_cycle_aggregation_full_batch_64_at_256(V, gpu_device):
     loop was held against the reference-shaped loop at B = 8 only). The same check at B = 64 -- every cycle render bit-identical to the
     per-image, per-view renderer calls, the merged sets equal to the reference-shaped concatenation -- and two views of two images' merged
     sets through the oracle at full size. V = 8 is C3 itself (589,824 Gaussians per merged set), V = 2 the same loop with two cycle views.
-    Both take 6-7 minutes on a fresh box whatever V is (MIOpen prepares its batch-64 kernels on first use), four times the rest of the GPU
-    suite together, so they run with F3DG_SLOW_TESTS=1 only: both passed on MI355X in round 4 (profiles/r04_final/c3_full_batch.log)."""
+    Until round 4 the first 64-image backbone pass spent 6-7 minutes in MIOpen on a fresh box; the predictor now runs fp32 passes of more
+    than 8 images as chunks of 8 (cfg['model']['backbone_chunk']: the per-image cost is flat from 8 on, and the 8-image shapes are the
+    ones test_c3_cycle_aggregation_batch_8_at_256 has prepared already): V = 8 -- C3 itself -- runs in the default suite; the two-view variant stays behind F3DG_SLOW_TESTS."""
     import os
-    if not os.environ.get("F3DG_SLOW_TESTS"):
-        pytest.skip("C3's cycle loop at B = 64 takes 6-7 minutes on a fresh box: set F3DG_SLOW_TESTS=1")
+    if V != 8 and not os.environ.get("F3DG_SLOW_TESTS"):
+        pytest.skip("the two-view variant of C3's cycle loop at B = 64: set F3DG_SLOW_TESTS=1")
     B, res = 64, 256
     merged, cfg, rig = cycle_loop_check(gpu_device, B, res, V=V)
     assert merged["xyz"].shape == (B, (1 + V) * 65536, 3)

@@ -359,6 +359,79 @@ def test_conv_bias_folding_and_residual_join(dtype, gpu_device):
             assert err <= (2e-6 if dtype == "fp32" else 3e-2), (cin, cout, err)
 
 
+def test_backbone_fp16_option_and_deterministic_groupnorm(gpu_device):
+    """Round 5: (a) the fp16 option of the backbone (float16 autocast, float16 activations through the fused GroupNorm+SiLU and residual
+    join kernels): the kernels against float64 torch at one float16 rounding, the reference-generated fixture songunet.npz at a bar 8x
+    tighter than the bf16 option's; (b) the channels-last GroupNorm's statistics are summed in a fixed order (one partial pair per
+    workgroup + a second-stage kernel, no atomics): two runs are bit-identical in every activation type."""
+    import os
+    import torch.nn.functional as F
+    from f3dgaus_amd.gaussian_predictor import GaussianSplatPredictor_gtunet, GroupNorm, residual_join
+    from helpers_weights import formula_state_dict
+    torch.manual_seed(0)
+    for dt, ulp in ((torch.float16, 2.0 ** -11), (torch.bfloat16, 2.0 ** -8), (torch.float32, 1e-6)):
+        for (N, Cc, H, W), nhwc in (((2, 128, 64, 64), False), ((2, 128, 64, 64), True), ((3, 256, 32, 32), True), ((2, 36, 10, 6), False)):
+            gn = GroupNorm(Cc, eps=1e-6).to(gpu_device)
+            with torch.no_grad():
+                gn.weight.uniform_(0.5, 1.5); gn.bias.uniform_(-0.5, 0.5)
+                x = (torch.randn(N, Cc, H, W, device=gpu_device) * 3 + 1.5).to(dt)
+                pb = torch.randn(Cc, device=gpu_device) * 0.3
+                if nhwc:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                for silu in (False, True):
+                    y = gn(x, silu=silu, pre_bias=pb)
+                    y2 = gn(x, silu=silu, pre_bias=pb)
+                    assert y.dtype == dt and torch.equal(y, y2), (dt, nhwc, silu)            # (b): run-to-run bit-identical
+                    ref = F.group_norm(x.double() + pb.double().reshape(1, -1, 1, 1), gn.num_groups, gn.weight.double(), gn.bias.double(), gn.eps)
+                    ref = F.silu(ref) if silu else ref
+                    err = (y.double() - ref).abs().max().item()
+                    assert err <= 2 * ulp * max(1.0, ref.abs().max().item()), (dt, N, Cc, H, W, nhwc, silu, err)
+        a = torch.randn(2, 64, 16, 16, device=gpu_device).to(dt)
+        b = torch.randn(2, 64, 16, 16, device=gpu_device).to(dt)
+        ba, bb = torch.randn(64, device=gpu_device), torch.randn(64, device=gpu_device)
+        want = ((a.double() + ba.double().reshape(1, -1, 1, 1)) + (b.double() + bb.double().reshape(1, -1, 1, 1))) * 0.7071067811865476
+        with torch.no_grad():
+            got = residual_join(a.clone(), ba, b, bb, 0.7071067811865476)
+        assert got.dtype == dt and (got.double() - want).abs().max().item() <= 2 * ulp * want.abs().max().item()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "songunet.npz"))
+    pred = GaussianSplatPredictor_gtunet(cameras.default_cfg()).eval()
+    sd = pred.state_dict()
+    keep = {k: v for k, v in sd.items() if k in ("ray_dirs", "sh_to_v_transform", "v_to_sh_transform") or k.endswith("resample_filter")}
+    pred.load_state_dict(formula_state_dict({k: tuple(v.shape) for k, v in sd.items()}, keep=keep))
+    pred = pred.to(gpu_device)
+    x = torch.from_numpy(g["x"]).to(gpu_device)
+    ref = torch.from_numpy(g["y"]).to(gpu_device)
+    errs = {}
+    with torch.no_grad():
+        for name, xin in (("nchw", x), ("nhwc", x.contiguous(memory_format=torch.channels_last))):
+            with torch.autocast("cuda", dtype=torch.float16):
+                y16 = pred.network_with_offset(xin, N_views_xa=1).float()
+            assert bool(torch.isfinite(y16).all()), name
+            errs[name] = (((y16 - ref).abs().max() / ref.abs().max()).item(), ((y16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
+    print("SongUNet fp16 option vs reference fixture (max rel, rms rel):", {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in errs.items()})
+    # measured on MI355X (profiles/r05_final/fp16_frames.md); the bf16 option's bars are 0.25 / 0.12
+    for name, (emax, erms) in errs.items():
+        assert emax < 0.03 and erms < 0.015, (name, emax, erms)
+    # wired through the predictor, with chunked passes: 5 images as chunks of 2 + 2 + 1 against one pass of 5
+    cfg = cameras.default_cfg(32)
+    cfg['model']['backbone_dtype'] = 'fp16'
+    cfg['model']['backbone_chunk'] = 2
+    p16 = GaussianSplatPredictor_gtunet(cfg).to(gpu_device).eval()
+    assert p16.backbone_dtype == "fp16" and p16.backbone_chunk == 2
+    xin = torch.rand(5, 1, 4, 32, 32, device=gpu_device)
+    rig = cameras.OrbitRig(cfg).canonical
+    v2w = rig.view_to_world_transforms.expand(5, 1, 4, 4).to(gpu_device)
+    quat = rig.source_cv2wT_quat.expand(5, 1, 4).to(gpu_device)
+    depth = torch.rand(5, 1, 32, 32, device=gpu_device) * 2 + 6.667
+    with torch.no_grad():
+        chunked = p16(xin, v2w, quat, unet_depth=depth)
+        p16.backbone_chunk = 0
+        whole = p16(xin, v2w, quat, unet_depth=depth)
+    for k in whole:
+        assert chunked[k].dtype == torch.float32 and chunked[k].shape == whole[k].shape
+        assert (chunked[k] - whole[k]).abs().max().item() <= 2e-2 * max(1.0, whole[k].abs().max().item()), k
+
+
 def test_backbone_channels_last_option(gpu_device):
     """cfg['model']['backbone_layout'] = 'nhwc': the backbone with channels-last activations and filters (MIOpen's NHWC kernels, the
     channels-last GroupNorm+SiLU kernel, no layout conversion in between). float32: the reference-generated fixture songunet.npz at the
