@@ -67,6 +67,9 @@ def parse():
                          "at 1e-4 / 99.9 %% / 80 dB), exact = the reference's float32/float64 operation order")
     ap.add_argument("--backbone", choices=["fp32", "bf16", "fp16"], default="fp32",
                     help="c4: precision of the SongUNet backbone (bf16 = the opt-in autocast option, SURVEY 8f-3)")
+    ap.add_argument("--backbone-chunk", type=int, default=-1,
+                    help="c4: images per backbone pass (cfg['model']['backbone_chunk']; -1 = the predictor's default: 8 for fp32 -- bounds MIOpen's "
+                         "first-use find at 43 s --, 0 = whole batches for the 16-bit options)")
     ap.add_argument("--backbone-layout", choices=["auto", "nchw", "nhwc"], default="auto",
                     help="c4: memory layout of the SongUNet backbone (auto, the default: channels-last for passes of two images or more; nhwc: "
                          "channels-last activations and filters -- MIOpen's NHWC kernels + the channels-last GroupNorm+SiLU / residual-join "
@@ -545,6 +548,8 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
     cfg = cameras.default_cfg(RES)
     cfg['model']['backbone_dtype'] = args.backbone
     cfg['model']['backbone_layout'] = args.backbone_layout
+    if args.backbone_chunk >= 0:
+        cfg['model']['backbone_chunk'] = args.backbone_chunk
     torch.backends.cudnn.benchmark = True               # MIOpen picks its convolution algorithms once per shape
     torch.manual_seed(0)
     model = f3d.Unet_GS_gtunet(cfg, renderer=f3d.render_predicted_more_v2_gof).to(device).eval()
@@ -593,7 +598,7 @@ def run_c4(args, rank, world, dist, device, comm_device, f3d, L):
         "config": {"workload": "C4 shape per rank (C3 at 1 GPU): %d images/GPU @%dx%d, predictor (SongUNet, random weights) + cycle "
                                "aggregation (8 views, 8 re-predictions, merged sets of 589,824 Gaussians) + 8 orbit views of every merged set "
                                "+ frame packing + gather" % (B, RES, RES),
-                   "images_per_gpu": B, "views_per_image": V, "resolution": RES, "backbone": args.backbone, "backbone_layout": args.backbone_layout,
+                   "images_per_gpu": B, "views_per_image": V, "resolution": RES, "backbone": args.backbone, "backbone_layout": args.backbone_layout, "backbone_chunk": args.backbone_chunk,
                    "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
         "breakdown_ms_per_step": {"predictor + cycle aggregation": t_cycle[0] / args.steps, "orbit render + frame packing": t_cycle[1] / args.steps,
                                   "rasterizer stages (HIP events)": {"preprocess": stage_ms[0] / args.steps, "binning": stage_ms[1] / args.steps,
