@@ -81,6 +81,9 @@ def parse():
                     help="c2: synthetic = the recipe of SURVEY 8d; real = the image of fixture F6 (tests/golden/real_image_256.npz: "
                          "images/1/n01644373_4548.jpg + its LeReS depth) through the build's own predictor and cycle aggregation "
                          "(formula weights, no checkpoint travels): the 589,824 merged Gaussians along the 128-view orbit")
+    ap.add_argument("--channels", choices=["all", "rgb_depth_alpha"], default="all",
+                    help="c2: output channels of the rasterizer calls; rgb_depth_alpha = what the reference's loops consume (visualize.py:304-306, "
+                         "400-402) and the build's cycle / orbit loops ask for (F3DG_FLAG_SKIP_NORMAL | _SKIP_DISTORTION); the headline stays 9-channel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the timed loops with frame packing + device-to-host copy: `value` is then the in-HBM rate")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra timed loop in the reference's arithmetic (value_exact / roofline_exact)")
@@ -169,7 +172,7 @@ def main():
         _lib.check(L.f3dg_set_option(b"render_round", int(os.environ["F3DG_RENDER_ROUND"])), "f3dg_set_option")
     if os.environ.get("F3DG_RENDER_KERNEL"):      # A/B of the compositing kernel generations (default: the library's)
         _lib.check(L.f3dg_set_option(b"render_kernel", int(os.environ["F3DG_RENDER_KERNEL"])), "f3dg_set_option")
-    for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad"), ("F3DG_BWD_OCC", b"bwd_occ"), ("F3DG_RENDER_SLIDE", b"render_slide"), ("F3DG_RENDER_LOWOCC", b"render_lowocc"), ("F3DG_RENDER_TAIL", b"render_tail"), ("F3DG_SMALL_DEBUG", b"small_debug"), ("F3DG_RENDER_PACK_TH", b"render_pack_th"), ("F3DG_RENDER_PACK", b"render_pack")):     # A/B switches of render3
+    for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad"), ("F3DG_BWD_OCC", b"bwd_occ"), ("F3DG_RENDER_SLIDE", b"render_slide"), ("F3DG_RENDER_LOWOCC", b"render_lowocc"), ("F3DG_RENDER_TAIL", b"render_tail"), ("F3DG_SMALL_DEBUG", b"small_debug"), ("F3DG_RENDER_PACK_TH", b"render_pack_th"), ("F3DG_RENDER_PACK", b"render_pack"), ("F3DG_PRE_HOIST", b"pre_hoist")):     # A/B switches of render3
         if os.environ.get(env):
             _lib.check(L.f3dg_set_option(opt, int(os.environ[env])), "f3dg_set_option")
     _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
@@ -207,7 +210,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     chunks = [(a, min(a + args.views_per_call, V)) for a in range(0, V, args.views_per_call)]
     workspaces = {}
 
-    call_opts = {"exact": None, "tile_cull": None}     # per-call settings (F3DG_FLAG_EXACT / _NO_TILE_CULL): None = the process default
+    call_opts = {"exact": None, "tile_cull": None, "channels": args.channels}     # per-call settings (F3DG_FLAG_EXACT / _NO_TILE_CULL): None = the process default
 
     def render_chunk(a, b, check, out=out):
         o, r, ws = f3d.rasterize_views(
@@ -504,7 +507,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                                    caveat),
                    "gaussians": P, "views": V, "resolution": RES, "sigma0": args.sigma0, "instances_per_step": R_total, "lists": list_stats,
                    "instances_processed_per_step": R_proc, "tile_cull": args.tile_cull,
-                   "views_per_call": args.views_per_call, "render_mode": args.render_mode,
+                   "views_per_call": args.views_per_call, "render_mode": args.render_mode, "channels": args.channels,
                    "kernel_launches_per_call": nlaunch / float(ncalls),
                    "parallelism": "image-sharded x%d + RCCL gather" % world if world > 1 else "single GPU"},
         "value_in_hbm": world * V * args.steps / elapsed_hbm, "ms_per_step_in_hbm": 1e3 * elapsed_hbm / args.steps,

@@ -130,6 +130,7 @@ int g_f3dg_bwd_occ = 5;
 int g_f3dg_render_round = 192;
 int g_f3dg_sort_wide_groups = 0;
 int g_f3dg_sort_fused_rects = 0;
+int g_f3dg_pre_hoist = 0;
 int g_f3dg_tile_cull = 1;            // instantiate a Gaussian only in the tiles its conservative ellipse reaches (0: the reference's tile lists)
 int g_f3dg_pre_order = 0;             // projection grid: 0 view-major (a view's chunks follow each other), 1 chunk-major (a chunk's views do)
 int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = +inf (measures the loop skeleton)
@@ -156,6 +157,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "pre_hoist") == 0) { g_f3dg_pre_hoist = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "sort_fused_rects") == 0) { g_f3dg_sort_fused_rects = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "pre_order") == 0) { g_f3dg_pre_order = value & 3; return F3DG_OK; }
@@ -337,6 +339,13 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                  const float* cam_pos, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                  int* radii_used, int save_aux, int need_box, int tile_cull, ProfCall* prof, F3dgHeaderInit init, int small = 0)
 {
+    // option pre_hoist: the per-Gaussian scratch (96 bytes each) borrows the backward's float64 accumulator plane, which nothing touches
+    // before f3dg_backward -- if it is large enough (80 bytes per (view, Gaussian): at least ~1.2 views per set) and a Gaussian serves
+    // enough views for the extra pass to pay
+    const int n_sets = views_per_set > 0 ? n_views / views_per_set : 1;
+    float4* hoist = nullptr;
+    if (g_f3dg_pre_hoist && n_views / n_sets >= 4 && (size_t)n_views * 80 >= (size_t)n_sets * 96)
+        hoist = reinterpret_cast<float4*>(ws + L.bwd_acc);
     int rc = f3dg_launch_preprocess(s, n_views, views_per_set, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, view2gaussian_precomp, viewmatrix, projmatrix,
                                     cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size,
@@ -347,7 +356,7 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     reinterpret_cast<float4*>(ws + L.cull),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
-                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux, tile_cull, init);
+                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux, tile_cull, init, hoist, n_sets);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_PREPROCESS, s);
     rc = small ? f3dg_launch_small_bin(s, n_views, P, W, H, L, ws) : f3dg_launch_binning(s, n_views, P, W, H, L, ws, save_aux);
@@ -742,6 +751,8 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
         if (rck != F3DG_OK) return rck;
     }
 #define CP(dst, off, bytes) if (dst && (bytes)) F3DG_HIP_CHECK(hipMemcpyAsync(dst, ws + (off), (bytes), hipMemcpyDeviceToDevice, s))
+    // (an inference call writes the record only for (view, Gaussian) pairs that are in a tile list: the other rows of `rec` hold whatever the
+    // workspace held -- documented in f3dg.h; mask with radii > 0, and with the culled lists also with "is in a list")
     CP(rec, L.rec, VP * sizeof(F3dgRec));
     CP(means2D, L.means2D, VP * 8);
     CP(conic, L.conic, VP * 16);

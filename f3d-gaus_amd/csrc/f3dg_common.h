@@ -199,7 +199,9 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox /* may be null */, float4* cull, float4* conic,
-                           int* radii, unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init);
+                           int* radii, unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init,
+                           float4* hoist = nullptr /* scratch of n_sets * P * 96 bytes: option pre_hoist */, int n_sets = 1);
+extern int g_f3dg_pre_hoist;            // 1: the view-independent part of the projection is computed once per Gaussian (preprocess_hoist_kernel)
 
 // Small-call path: entries per (view, tile) it can hold, and the shapes it serves (one or two views of at most 2^18 Gaussians on at
 // most 1024 tiles: the reference's one-view-per-call loops, visualize.py:293-314, 387-416)

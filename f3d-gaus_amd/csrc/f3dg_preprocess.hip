@@ -201,11 +201,42 @@ __device__ __forceinline__ void conservative_ellipse(const CullConic& q, float t
     ec = fc;
 }
 
+// View-independent part of the projection, once per Gaussian instead of once per (view, Gaussian) (option pre_hoist; VERDICT r04 item 6:
+// "hoist through memory, not registers"): the 3D covariance (computeCov3D, forward.cu:129-163), the rotation matrix of the
+// quaternion, and the float64 reciprocals of the squared scales that computeView2Gaussian forms (forward.cu:168-200) -- 24 floats = 96
+// bytes per Gaussian, [0..5] Sigma, [6..14] R (column-major m[c][r]), [15] unused, [16..21] Sx, Sy, Sz as float64 bit pairs. The same
+// operations in the same order as the per-view code, so every output of the projection stays bit-identical.
+__global__ void __launch_bounds__(256)
+preprocess_hoist_kernel(int n, const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations, float4* __restrict__ out)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const float3 scale = make_float3(scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]);
+    const float4 rot = reinterpret_cast<const float4*>(rotations)[g];
+    M3 S = {};
+    S.m[0][0] = scale_modifier * scale.x;
+    S.m[1][1] = scale_modifier * scale.y;
+    S.m[2][2] = scale_modifier * scale.z;
+    const M3 R = quat_to_R(rot);
+    const M3 Mm = mul(S, R);
+    const M3 Sigma = mul(transpose(Mm), Mm);
+    const double Sx = 1.0f / ((double)scale.x * scale.x + 1e-7);
+    const double Sy = 1.0f / ((double)scale.y * scale.y + 1e-7);
+    const double Sz = 1.0f / ((double)scale.z * scale.z + 1e-7);
+    float4* o = out + 6 * (size_t)g;
+    o[0] = make_float4(Sigma.m[0][0], Sigma.m[0][1], Sigma.m[0][2], Sigma.m[1][1]);
+    o[1] = make_float4(Sigma.m[1][2], Sigma.m[2][2], R.m[0][0], R.m[0][1]);
+    o[2] = make_float4(R.m[0][2], R.m[1][0], R.m[1][1], R.m[1][2]);
+    o[3] = make_float4(R.m[2][0], R.m[2][1], R.m[2][2], 0.0f);
+    o[4] = make_float4(__int_as_float(__double2loint(Sx)), __int_as_float(__double2hiint(Sx)), __int_as_float(__double2loint(Sy)), __int_as_float(__double2hiint(Sy)));
+    o[5] = make_float4(__int_as_float(__double2loint(Sz)), __int_as_float(__double2hiint(Sz)), 0.0f, 0.0f);
+}
+
 // SAVE_AUX = false (inference calls): the planes only the backward and the debug export read -- and the arithmetic only they need
 // (the 2D conic: one IEEE division) -- are not produced.
-template <bool SAVE_AUX>
+template <bool SAVE_AUX, bool HOIST>
 __global__ void __launch_bounds__(F3DG_BLOCK)
-preprocess_kernel(int P, int D, int M, int views_per_set,
+preprocess_kernel(int P, int D, int M, int views_per_set, const float4* __restrict__ hoist,
                   const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
                   const float* __restrict__ rotations, const float* __restrict__ opacities,
                   const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
@@ -270,12 +301,25 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
 
         float3 scale = make_float3(0, 0, 0);
         float4 rot = make_float4(1, 0, 0, 0);
-        if (scales) scale = make_float3(scales[3 * gs], scales[3 * gs + 1], scales[3 * gs + 2]);
-        if (rotations) rot = reinterpret_cast<const float4*>(rotations)[gs];
+        if (!HOIST) {
+            if (scales) scale = make_float3(scales[3 * gs], scales[3 * gs + 1], scales[3 * gs + 2]);
+            if (rotations) rot = reinterpret_cast<const float4*>(rotations)[gs];
+        }
 
         // ---- computeCov3D (forward.cu:129-163) or the precomputed one
         float c3[6];
-        if (cov3D_precomp) {
+        M3 Rh = {};                     // HOIST: the Gaussian's rotation matrix and scale reciprocals from preprocess_hoist_kernel
+        double Sxh = 0.0, Syh = 0.0, Szh = 0.0;
+        if (HOIST) {
+            const float4* h = hoist + 6 * gs;
+            const float4 h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5];
+            c3[0] = h0.x; c3[1] = h0.y; c3[2] = h0.z; c3[3] = h0.w; c3[4] = h1.x; c3[5] = h1.y;
+            Rh.m[0][0] = h1.z; Rh.m[0][1] = h1.w; Rh.m[0][2] = h2.x; Rh.m[1][0] = h2.y; Rh.m[1][1] = h2.z; Rh.m[1][2] = h2.w;
+            Rh.m[2][0] = h3.x; Rh.m[2][1] = h3.y; Rh.m[2][2] = h3.z;
+            Sxh = __hiloint2double(__float_as_int(h4.y), __float_as_int(h4.x));
+            Syh = __hiloint2double(__float_as_int(h4.w), __float_as_int(h4.z));
+            Szh = __hiloint2double(__float_as_int(h5.y), __float_as_int(h5.x));
+        } else if (cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * gs + i];
         } else {
@@ -402,7 +446,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
 #pragma unroll
                     for (int i = 0; i < 10; i++) vg[i] = v2g_precomp[idx * 10 + i];
                 } else {
-                    const M3 R = quat_to_R(rot);
+                    const M3 R = HOIST ? Rh : quat_to_R(rot);
                     // G2V = W2V * G2W (glm mat4 product, 4 terms left to right); G2W columns are the ROWS of R
                     // with the mean as 4th column; W2V[c][r] = view[4c + r].
                     float G2V[4][3];   // [col][row], rows 0..2 only (row 3 is never read)
@@ -428,9 +472,9 @@ preprocess_kernel(int P, int D, int M, int views_per_set,
                     const float t2y = (-Rt.m[0][1]) * t_x + (-Rt.m[1][1]) * t_y + (-Rt.m[2][1]) * t_z;
                     const float t2z = (-Rt.m[0][2]) * t_x + (-Rt.m[1][2]) * t_y + (-Rt.m[2][2]) * t_z;
 
-                    const double Sx = 1.0f / ((double)scale.x * scale.x + 1e-7);
-                    const double Sy = 1.0f / ((double)scale.y * scale.y + 1e-7);
-                    const double Sz = 1.0f / ((double)scale.z * scale.z + 1e-7);
+                    const double Sx = HOIST ? Sxh : 1.0f / ((double)scale.x * scale.x + 1e-7);
+                    const double Sy = HOIST ? Syh : 1.0f / ((double)scale.y * scale.y + 1e-7);
+                    const double Sz = HOIST ? Szh : 1.0f / ((double)scale.z * scale.z + 1e-7);
                     const double Cc = t2x * t2x * Sx + t2y * t2y * Sy + t2z * t2z * Sz;
 
                     M3 SR;
@@ -565,19 +609,25 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox, float4* cull, float4* conic, int* radii,
-                           unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init)
+                           unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init, float4* hoist, int n_sets)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    // option pre_hoist: the view-independent part once per Gaussian (only the common input form: scales + rotations, nothing precomputed)
+    if (hoist && !(scales && rotations && !cov3D_precomp && !v2g_precomp)) hoist = nullptr;
+    if (hoist)
+        F3DG_KLAUNCH(preprocess_hoist_kernel, dim3((unsigned)(((size_t)n_sets * P + 255) / 256)), dim3(256), 0, s, n_sets * P, scales, scale_modifier, rotations, hoist);
     const int chunks = (P + F3DG_BLOCK - 1) / F3DG_BLOCK;
     const int chunk_major = ((g_f3dg_pre_order & 1) && chunks <= 65535 ? 1 : 0) | (g_f3dg_pre_order & 2);
     dim3 grid((chunk_major & 1) ? V : chunks, (chunk_major & 1) ? chunks : V, 1);
-#define F3DG_LAUNCH_PRE(AUX) F3DG_KLAUNCH(preprocess_kernel<AUX>, grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, means3D, scales,     \
+#define F3DG_LAUNCH_PRE2(AUX, HST) F3DG_KLAUNCH((preprocess_kernel<AUX, HST>), grid, dim3(F3DG_BLOCK), 0, s, P, D, M, views_per_set > 0 ? views_per_set : V, hoist, means3D, scales,     \
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,                          \
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,                                          \
                        depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, g_f3dg_debug_skip_all, tile_cull,                                    \
                        1.0 / (double)focal_x, 1.0 / (double)focal_y, init, chunk_major)
+#define F3DG_LAUNCH_PRE(AUX) do { if (hoist) F3DG_LAUNCH_PRE2(AUX, true); else F3DG_LAUNCH_PRE2(AUX, false); } while (0)
     if (save_aux) F3DG_LAUNCH_PRE(true); else F3DG_LAUNCH_PRE(false);
 #undef F3DG_LAUNCH_PRE
+#undef F3DG_LAUNCH_PRE2
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

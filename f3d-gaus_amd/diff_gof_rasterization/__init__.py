@@ -261,7 +261,14 @@ _PENDING = {}       # (device index, stream) -> {"ticket": int, "ws": Workspace,
 
 
 def set_deferred_status(on=True):
-    """Opt in / out of the deferred status check of no-grad single-view calls (see the comment above). Turning it off flushes."""
+    """Opt in / out of the deferred status check of no-grad single-view calls (see the comment above). Turning it off flushes.
+
+    Caveats of the opt-in mode, both about what happens between a call and the moment its status is looked at (the next call on the
+    stream, or `flush()`): (1) consumers of the call's OUTPUTS enqueued in between read an incomplete frame if the call overflowed
+    (the repair re-renders into the same tensors and warns); (2) the repair re-renders from the caller's INPUT tensors as they are
+    THEN: a caller that refills those buffers in place between the call and the check (the cycle loop does: `splat_head(out=merged)`)
+    gets the repaired frame from the new Gaussians. Keep the inputs of a deferred call untouched until the next call / `flush()`, or
+    size the workspace so that the overflow cannot happen (the first call of a shape is always checked at once and sets the hint)."""
     if not on:
         flush()
     _DEFERRED["on"] = bool(on)
@@ -302,8 +309,8 @@ def flush(device=None):
 def add_redo(fn):
     """(wrapper-internal) work derived from the outputs of the call just issued on the current stream, to be repeated if that call
     turns out to have overflowed."""
-    dev = torch.cuda.current_device()
-    p = _PENDING.get((dev, torch.cuda.current_stream().cuda_stream))
+    stream = torch.cuda.current_stream()          # (the stream's own device, not the thread's current one)
+    p = _PENDING.get((stream.device.index, stream.cuda_stream))
     if p is not None:
         p["redo"].append(fn)
 

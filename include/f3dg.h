@@ -432,7 +432,8 @@ int f3dg_backward_pairs(void* stream, const void* workspace, long long* h_pairs)
 /* Test/inspection hook: device-to-device copies of the library's internal per-call state into caller buffers
  * (any pointer may be NULL). Used by the stage-wise parity tests to pin each kernel separately, the way the
  * oracle exposes GeometryState / BinningState / ImageState (rasterizer_impl.cu:188-243).
- *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], culling-ellipse c); depths [V*P], means2D [V*P*2], conic [V*P*4],
+ *   rec [V*P*16] (view2gaussian[10], opacity*coef, pre-test threshold, rgb[3], culling-ellipse c; after an INFERENCE call only the rows of
+ *   (view, Gaussian) pairs that are in a tile list are written -- the others are stale); depths [V*P], means2D [V*P*2], conic [V*P*4],
  *   tiles [V*P], offsets [V*P], clamped [V*P] (bit c = channel c clamped), keys_sorted [cap] u64 (all SAVE_AUX: an inference call does not write them),
  *   point_list [cap], ranges [V*T*2], final_T [V*4*H*W] and n_contrib [V*2*H*W] (SAVE_AUX).
  * Asking for a SAVE_AUX-only plane of a workspace whose last forward was an inference call returns F3DG_ERR_BAD_ARG (BLOCKING then:

@@ -138,6 +138,30 @@ def test_fused_rectangle_gather_is_invisible(gpu_device, kw):
     assert np.array_equal(a["out_color"].view(np.uint32), b["out_color"].view(np.uint32))
 
 
+@pytest.mark.parametrize("save_aux", [True, False])
+def test_projection_hoist_is_bit_identical(gpu_device, save_aux):
+    """Option pre_hoist (round 5): the view-independent part of the projection -- 3D covariance, rotation matrix, float64 scale
+    reciprocals -- computed once per Gaussian by preprocess_hoist_kernel and read by the per-(view, Gaussian) threads instead of being
+    recomputed per view. Same operations in the same order: records, radii, lists and images identical to the bit."""
+    from f3dgaus_amd import _lib
+    scene = make_scene(P=9000, res=(128, 96), s0=0.03, view=[0, 1, 3, 5, 6, 2], aniso=True, scale_modifier=0.8)
+    L = _lib.lib()
+    a = run_hip(scene, gpu_device, save_aux=save_aux)
+    try:
+        assert L.f3dg_set_option(b"pre_hoist", 1) == 0
+        L.f3dg_debug_launch_count(1)
+        b = run_hip(scene, gpu_device, save_aux=save_aux)
+    finally:
+        L.f3dg_set_option(b"pre_hoist", 0)
+    assert a["num_rendered"] == b["num_rendered"]
+    vis = a["radii"] > 0
+    for k in ("radii", "point_list", "ranges"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("view2gaussian", "opac", "rgb"):
+        assert np.array_equal(a[k][vis].view(np.uint32), b[k][vis].view(np.uint32)), k
+    assert np.array_equal(a["out_color"].view(np.uint32), b["out_color"].view(np.uint32))
+
+
 @pytest.mark.parametrize("which", ["cov3D+view2gaussian", "view2gaussian"])
 def test_precomputed_covariance_and_view2gaussian(which, gpu_device):
     """cov3D_precomp replaces scales / rotations in the 2D footprint (forward.cu:338-348), view2gaussian_precomp replaces the
