@@ -196,7 +196,7 @@ int launch_gn(void* stream, int N, int C, int HW, int groups, const T* x, const 
 // workgroup takes a run of pixels with ALL channels (whole lines), and the moments of a (sample, group) are summed across workgroups:
 //   gn_nhwc_moments_kernel: thread (row, col) owns the 16-byte packet `col` of the pixels row, row + rows, ...: float sums per channel
 //       over at most GN_NHWC_PIX / rows pixels, per-channel totals over the rows in LDS, per-group totals in float64 written to
-//       partial[n][block][g] = (sum, sum of squares); gn_nhwc_finish_kernel adds the blocks in order -> (mean, rstd) per (sample, group);
+//       partial[n][g][block] = (sum, sum of squares); gn_nhwc_finish_kernel adds the blocks in order -> (mean, rstd) per (sample, group);
 //   gn_nhwc_apply_kernel: the same mapping; scale / shift of the thread's PN channels once, then one pass: silu((x + pre_bias) * sc + sh).
 // Two reads (the second from L2 / MALL) and one write, as the NCHW kernel.
 constexpr int GN_NHWC_PIX = 512;      // pixels per workgroup
@@ -245,36 +245,46 @@ gn_nhwc_moments_kernel(int C, int HW, int groups, int rows, const T* __restrict_
         ca[c] = t1; cb[c] = t2;
     }
     __syncthreads();
-    // per-group totals in float64, one (sum, sum of squares) pair per WORKGROUP: partial[n][block][g]. No atomics -- the second stage
+    // per-group totals in float64, one (sum, sum of squares) pair per WORKGROUP: partial[n][g][block]. No atomics -- the second stage
     // (gn_nhwc_finish_kernel) adds a sample's blocks up in block order, so the statistics, and with them the whole backbone pass, are
     // bit-reproducible from run to run (until round 5 the blocks added into 8 atomic slots in arrival order)
     const int Cg = C / groups;
-    double* part = moments + 2 * ((size_t)n * gridDim.x + blockIdx.x) * groups;
     for (int g = threadIdx.x; g < groups; g += blockDim.x) {
         double s1 = 0.0, s2 = 0.0;
         for (int c = g * Cg; c < (g + 1) * Cg; c++) { s1 += (double)ca[c]; s2 += (double)cb[c]; }
-        part[2 * g] = s1;
-        part[2 * g + 1] = s2;
+        double* part = moments + 2 * (((size_t)n * groups + g) * gridDim.x + blockIdx.x);       // [n][g][block]: the second stage reads a (sample, group)'s blocks contiguously
+        part[0] = s1;
+        part[1] = s2;
     }
 }
 
-// second stage: thread (n, g) adds the nb partial pairs of its (sample, group) in block order and leaves mean and 1 / sqrt(var + eps) as
-// two floats behind the partials (stats[n][g]): the apply kernel's threads read them instead of each recomputing them in float64
+// second stage: ONE WAVE per (sample, group) adds its nb partial pairs -- lane l takes blocks l, l + 64, ... in order, then a fixed
+// butterfly over the lanes: the same association every run -- and leaves mean and 1 / sqrt(var + eps) as two floats behind the partials
+// (stats[n][g]): the apply kernel's threads read them instead of each recomputing them in float64. (One THREAD per pair, the first
+// version, walked 128 strided pairs serially: 12 us per launch, 78 launches per pass.)
 __global__ void __launch_bounds__(256)
 gn_nhwc_finish_kernel(int N, int groups, int nb, double cnt, float eps, const double* __restrict__ partial, float2* __restrict__ stats)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N * groups) return;
+    const int lane = threadIdx.x & 63;
     const int n = i / groups, g = i % groups;
     double m1 = 0.0, m2 = 0.0;
-    for (int b = 0; b < nb; b++) {
-        const double* p = partial + 2 * (((size_t)n * nb + b) * groups + g);
+    for (int b = lane; b < nb; b += 64) {
+        const double* p = partial + 2 * (((size_t)n * groups + g) * nb + b);
         m1 += p[0]; m2 += p[1];
     }
-    const double m = m1 / cnt;
-    double var = m2 / cnt - m * m;
-    if (var < 0.0) var = 0.0;
-    stats[i] = make_float2((float)m, (float)(1.0 / sqrt(var + (double)eps)));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        m1 += __shfl_xor(m1, m, 64);
+        m2 += __shfl_xor(m2, m, 64);
+    }
+    if (lane == 0) {
+        const double m = m1 / cnt;
+        double var = m2 / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        stats[i] = make_float2((float)m, (float)(1.0 / sqrt(var + (double)eps)));
+    }
 }
 
 template <typename T>
@@ -334,7 +344,7 @@ int launch_gn_nhwc(void* stream, int N, int C, int HW, int groups, const T* x, c
     float2* stats = reinterpret_cast<float2*>(moments + 2 * (size_t)N * nb * groups);
     const dim3 grid((unsigned)nb, (unsigned)N);
     F3DG_KLAUNCH(gn_nhwc_moments_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, pre_bias, moments);
-    F3DG_KLAUNCH(gn_nhwc_finish_kernel, dim3((unsigned)((N * groups + 255) / 256)), dim3(256), 0, s, N, groups, nb, (double)(C / groups) * (double)HW, eps,
+    F3DG_KLAUNCH(gn_nhwc_finish_kernel, dim3((unsigned)((N * groups + 3) / 4)), dim3(256), 0, s, N, groups, nb, (double)(C / groups) * (double)HW, eps,
                  moments, stats);
     F3DG_KLAUNCH(gn_nhwc_apply_kernel<T>, grid, dim3(256), 0, s, C, HW, groups, rows, x, pre_bias, stats, weight, bias, apply_silu, y);
     F3DG_HIP_CHECK(hipGetLastError());
