@@ -41,8 +41,18 @@ class GaussianRasterizationSettings_GOF(NamedTuple):
     debug: bool
 
 
+def _raw_stream(device_index=None):
+    """The current HIP stream of a device (default: the current device) as an integer handle. torch.cuda.current_stream() builds a Stream
+    object through two device-index resolutions (7 us a call, five calls per one-view render: a fifth of the drop-in loop's host time);
+    the raw getter is what it wraps."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if device_index is None else device_index)
+    except AttributeError:          # (a torch without the private getters)
+        return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
 
 
 def _dev_f32(t, device):
@@ -309,8 +319,8 @@ def flush(device=None):
 def add_redo(fn):
     """(wrapper-internal) work derived from the outputs of the call just issued on the current stream, to be repeated if that call
     turns out to have overflowed."""
-    stream = torch.cuda.current_stream()          # (the stream's own device, not the thread's current one)
-    p = _PENDING.get((stream.device.index, stream.cuda_stream))
+    dev = torch.cuda.current_device()
+    p = _PENDING.get((dev, _raw_stream(dev)))
     if p is not None:
         p["redo"].append(fn)
 
@@ -340,7 +350,7 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
     """One reference-shaped rasterizer call (one view): (color [1,9,H,W], radii [1,P], workspace). Shared by the autograd Function
     and by the wrapper's inference path (`rasterize_nograd`)."""
     device = means3D.device
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device.index, _raw_stream(device.index) if device.type == "cuda" else 0)
     ws = None if needs_grad else _WS_CACHE.get(key)
 
     shape_key = (means3D.size(0), int(rs.image_width), int(rs.image_height), 1)
@@ -482,7 +492,7 @@ def integrate_gaussians_to_points(points3D, means3D, sh, colors_precomp, opaciti
         cap = _initial_capacity(P, W, H, 1)
         key = (P, PN, W, H)
         while True:
-            ckey = (device.index, torch.cuda.current_stream(device).cuda_stream)
+            ckey = (device.index, _raw_stream(device.index))
             cached = _INTEG_WS.get(ckey)
             if cached is None or cached[0] != key or cached[1] < cap:
                 nbytes = L.f3dg_integrate_workspace_bytes(P, PN, W, H, cap)

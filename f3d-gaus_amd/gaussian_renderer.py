@@ -344,7 +344,7 @@ def cycle_inputs(raster, B, V):
     H, W = raster.shape[-2:]
     xin = torch.empty((V, B, 4, H, W), dtype=torch.float32, device=raster.device)
     depth = torch.empty((V, B, 1, H, W), dtype=torch.float32, device=raster.device)
-    rc = _lib.lib().f3dg_cycle_inputs(C.c_void_p(torch.cuda.current_stream().cuda_stream), int(B), int(V), int(H), int(W),
+    rc = _lib.lib().f3dg_cycle_inputs(_stream(), int(B), int(V), int(H), int(W),
                                       _lib.ptr(raster), _lib.ptr(xin), _lib.ptr(depth))
     _lib.check(rc, "f3dg_cycle_inputs")
     return xin, depth
