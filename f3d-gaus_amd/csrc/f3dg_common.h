@@ -256,7 +256,8 @@ extern int g_f3dg_render_pack;         // -1 (default): inference launches in th
 extern int g_f3dg_render_pack_th;      // trips of a slide with at most this many participating pixels are packed (default 32; 0: never)
 int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
-                        float* out_color, int fast, unsigned skip_channels, int count);
+                        float* out_color, int fast, unsigned skip_channels, int count, int save_aux = 0, float* final_T = nullptr,
+                        unsigned* n_contrib = nullptr);
 
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated);

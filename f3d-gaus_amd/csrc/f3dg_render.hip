@@ -1443,9 +1443,9 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
         // the rank-packed kernel of f3dg_render4.hip (option render_pack: 1 = every inference launch, -1 = the default: inference launches
         // in the reference's arithmetic, whose stateless part is 2.5 x as long -- measured -38 % on the real merged set, -6 % at C2; in
         // fast arithmetic the packed trips' hand-over costs what they save: 8.4-8.7 against 8.6 ms)
-        if (!save_aux && g_f3dg_render_slide && (g_f3dg_render_pack == 1 || (g_f3dg_render_pack < 0 && !g_f3dg_render_fast && g_f3dg_render_wpb == 1 && g_f3dg_render_tail == 0)))
+        if (g_f3dg_render_slide && (g_f3dg_render_pack == 1 || (g_f3dg_render_pack < 0 && !g_f3dg_render_fast && g_f3dg_render_wpb == 1 && g_f3dg_render_tail == 0)))
             return f3dg_launch_render4(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
-                                       g_f3dg_render_fast, skip_channels, g_f3dg_render_count);
+                                       g_f3dg_render_fast, skip_channels, g_f3dg_render_count, save_aux, final_T, n_contrib);
         if (g_f3dg_render_slide) {
 #define F3DG_R3S_ARGS s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib, tail_n
             // render_tail = N > 0 (one-wave workgroups only): the tail schedule once at most N pixels of a quadrant are unsaturated

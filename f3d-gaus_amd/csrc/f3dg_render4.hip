@@ -18,7 +18,7 @@
 //     trips in which the owning lanes pull their pair's six numbers by ds_bpermute and apply the recurrence.
 // Per pixel the sequence of blended entries and every operation on them is unchanged, so the images are bit-identical to render3s in
 // either arithmetic mode (tests/test_raster_forward_gpu.py). LDS per wave: 4 KB of records + 512 B of id ring + 128 B of pair queue;
-// 8 waves per SIMD as before. Inference launches only (a SAVE_AUX forward stays on render3s).
+// Inference launches and (round 5, SAVE_AUX variant) forwards that a backward follows.
 #include "f3dg_blend.h"
 #include "f3dg_ellipse.h"
 
@@ -66,13 +66,15 @@ __device__ __forceinline__ float pull(int addr, float v)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
 }
 
-template <bool FAST, bool NORMAL, bool DIST, bool COUNT>
+// SAVE_AUX (a forward that f3dg_backward follows): also final_T [V][4][HW] and n_contrib [V][2][HW]; last_contributor / max_contributor are
+// 1-based positions in the tile's list, kept per staged slot (sP) and translated when a half of the window retires, as in render3s.
+template <bool FAST, bool NORMAL, bool DIST, bool COUNT, bool SAVE_AUX = false>
 __global__ void __launch_bounds__(64, 8)
 render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
-                   float* __restrict__ out_color, int pack_th)
+                   float* __restrict__ out_color, int pack_th, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
 {
     unsigned view, unit;
     f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
@@ -92,6 +94,8 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 
     __shared__ float4 sR[4][F3DG_R4_WIN];          // records, [16-byte chunk][slot]; slots 0..31 and 32..63 are the two halves of the window
     __shared__ unsigned sQ[F3DG_R4_RING];          // ids of kept entries not staged yet, ring
+    __shared__ unsigned sQpos[SAVE_AUX ? F3DG_R4_RING : 1];     // ... and their positions in the tile's list
+    __shared__ unsigned sP[SAVE_AUX ? F3DG_R4_WIN : 1];         // list position of every staged slot (the reference's `contributor`)
 #if F3DG_R4_PARK
     // the parking area of a packed batch: what the dense trip hands to the blend trips, [position in the queue]. The queue itself
     // (sK: 64 x u16, (owning lane << 6) | physical slot) is read by the dense trip before it parks its results and aliases the first
@@ -114,6 +118,13 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     F3dgPixel st;
     f3dg_pixel_init(st);
 
+    auto translate = [&](unsigned half_or_all) {      // slots -> 1-based list positions for the slots of one physical half (2: both)
+        if (SAVE_AUX) {
+            const unsigned a = st.last_contributor - F3DG_R4_FLAG, b = st.max_contributor - F3DG_R4_FLAG;
+            if (a < (unsigned)F3DG_R4_WIN && (half_or_all == 2u || (a >> 5) == half_or_all)) st.last_contributor = sP[a] + 1u;
+            if (b < (unsigned)F3DG_R4_WIN && (half_or_all == 2u || (b >> 5) == half_or_all)) st.max_contributor = sP[b] + 1u;
+        }
+    };
     unsigned n_staged = 0, n_fused = 0, n_slides = 0, n_lane_fused = 0, n_batches = 0, n_blend_trips = 0, n_dense_pairs = 0, n_blend_pairs = 0;
     unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
     unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
@@ -128,10 +139,16 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             idn = cursor + lane < n ? point_list[range.x + cursor + lane] : 0u;
             const bool keep = pos < n && (idm & qbit) != 0u;
             const unsigned long long kb = __ballot(keep);
-            if (keep) sQ[(qhead + qpend + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u))) & (F3DG_R4_RING - 1)] = idm & F3DG_ID_MASK;
+            if (keep) {
+                const unsigned slot = (qhead + qpend + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u))) & (F3DG_R4_RING - 1);
+                sQ[slot] = idm & F3DG_ID_MASK;
+                if (SAVE_AUX) sQpos[slot] = pos;
+            }
             qpend += (unsigned)__popcll(kb);
         }
         const unsigned m = qpend < 32u ? qpend : 32u;
+        // every live pixel has finished the older half (bits 0..31 of `pass` are clear): retire it
+        translate(flip);
         if (m == 0u && __ballot(pass != 0ull) == 0ull)
             break;                                // nothing left to stage, nothing left in the newer half
         wave_lds_fence();
@@ -148,6 +165,7 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                 for (int c = 0; c < 4; c++)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
                                                      (__attribute__((address_space(3))) void*)&sR[c][base], 16, 0, 0);
+                if (SAVE_AUX) sP[base + lane] = sQpos[(qhead + hl) & (F3DG_R4_RING - 1)];
             }
             e4 = vcull[id];
         }
@@ -325,6 +343,7 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
         if (__ballot(!done) == 0ull)
             break;
     }
+    translate(2u);
     if (COUNT) {
         unsigned a = n_lane_fused, b = n_blend_pairs;
 #pragma unroll
@@ -361,6 +380,16 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
         const float* bg = background + (bg_per_view ? 3 * view : 0);
         const float Tr = st.Tr;
         const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = st.distortion;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
         float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
         out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
         out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
@@ -382,22 +411,23 @@ thread_local char g_kernel_name4[160] = "";
 
 int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
-                        float* out_color, int fast, unsigned skip_channels, int count)
+                        float* out_color, int fast, unsigned skip_channels, int count, int save_aux, float* final_T, unsigned* n_contrib)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
     const dim3 grid((unsigned)V * (unsigned)T * 4u);
-    const bool lean = (skip_channels & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION)) == (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION);
+    const bool lean = !save_aux && (skip_channels & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION)) == (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION);
     const int th = g_f3dg_render_pack_th;
-#define F3DG_R4_ARGS s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, th
-#define F3DG_LAUNCH4(FST, NRM, DST, CNT) F3DG_KLAUNCH((render4_fwd_kernel<FST, NRM, DST, CNT>), grid, dim3(64), 0, F3DG_R4_ARGS)
-    if (count && !lean) { if (fast) F3DG_LAUNCH4(true, true, true, true); else F3DG_LAUNCH4(false, true, true, true); }
-    else if (lean) { if (fast) F3DG_LAUNCH4(true, false, false, false); else F3DG_LAUNCH4(false, false, false, false); }
-    else { if (fast) F3DG_LAUNCH4(true, true, true, false); else F3DG_LAUNCH4(false, true, true, false); }
+#define F3DG_R4_ARGS s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, th, final_T, n_contrib
+#define F3DG_LAUNCH4(FST, NRM, DST, CNT, AUX) F3DG_KLAUNCH((render4_fwd_kernel<FST, NRM, DST, CNT, AUX>), grid, dim3(64), 0, F3DG_R4_ARGS)
+    if (save_aux) { if (fast) F3DG_LAUNCH4(true, true, true, false, true); else F3DG_LAUNCH4(false, true, true, false, true); }
+    else if (count && !lean) { if (fast) F3DG_LAUNCH4(true, true, true, true, false); else F3DG_LAUNCH4(false, true, true, true, false); }
+    else if (lean) { if (fast) F3DG_LAUNCH4(true, false, false, false, false); else F3DG_LAUNCH4(false, false, false, false, false); }
+    else { if (fast) F3DG_LAUNCH4(true, true, true, false, false); else F3DG_LAUNCH4(false, true, true, false, false); }
 #undef F3DG_LAUNCH4
 #undef F3DG_R4_ARGS
-    snprintf(g_kernel_name4, sizeof g_kernel_name4, "render4_fwd_kernel<FAST=%s, NORMAL=%s, DIST=%s%s, pack_th=%d>", fast ? "true" : "false",
-             lean ? "false" : "true", lean ? "false" : "true", count && !lean ? ", COUNT=true" : "", th);
+    snprintf(g_kernel_name4, sizeof g_kernel_name4, "render4_fwd_kernel<FAST=%s, NORMAL=%s, DIST=%s%s%s, pack_th=%d>", fast ? "true" : "false",
+             lean ? "false" : "true", lean ? "false" : "true", count && !lean && !save_aux ? ", COUNT=true" : "", save_aux ? ", SAVE_AUX=true" : "", th);
     g_f3dg_last_render_kernel = g_kernel_name4;
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

@@ -362,6 +362,26 @@ def test_packed_schedule_bit_identical(name, gpu_device):
     for v in range(scene["viewmatrix"].shape[0]):
         o = run_oracle(scene, view=v)
         assert_render_parity(variants[1]["out_color"][v], o["out_color"], "packed %s view %d" % (name, v))
+    # the SAVE_AUX variant (a forward that a backward follows): also the auxiliary planes -- final transmittance, the distortion sums,
+    # the last and the median contributor as 1-based list positions -- identical to render3s's
+    try:
+        L.f3dg_set_option(b"render_lowocc", 0)
+        L.f3dg_set_option(b"render_pack", 0)
+        a = run_hip(scene, gpu_device, save_aux=True)
+        assert b"render3s" in L.f3dg_debug_last_render_kernel()
+        aux = []
+        for th in (64, 32, 5):
+            L.f3dg_set_option(b"render_pack", 1)
+            L.f3dg_set_option(b"render_pack_th", th)
+            aux.append(run_hip(scene, gpu_device, save_aux=True))
+            assert b"render4" in L.f3dg_debug_last_render_kernel() and b"SAVE_AUX=true" in L.f3dg_debug_last_render_kernel()
+    finally:
+        L.f3dg_set_option(b"render_pack", -1)
+        L.f3dg_set_option(b"render_pack_th", 32)
+        L.f3dg_set_option(b"render_lowocc", 1)
+    for b in aux:
+        for k in ("out_color", "final_T", "n_contrib"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
 
 
 @pytest.mark.parametrize("tail", [64, 16, 3])
