@@ -14,11 +14,15 @@
 //   * then PACKED batches. A batch takes the next R pending entries of every pixel (R ranks: as many as fit 64 pairs, at most what the
 //     pixels that hold the window back still need), writes the (pixel, slot) pairs to a 64-entry LDS queue in pixel-major order
 //     (offset of pixel p = sum over ranks of mbcnt of the rank's ballot), evaluates the stateless part ONE PAIR PER LANE (the ray of
-//     the pair's pixel comes by ds_bpermute from the lane that owns it, the record from the staged window), and then runs R short
-//     trips in which the owning lanes pull their pair's six numbers by ds_bpermute and apply the recurrence.
-// Per pixel the sequence of blended entries and every operation on them is unchanged, so the images are bit-identical to render3s in
-// either arithmetic mode (tests/test_raster_forward_gpu.py). LDS per wave: 4 KB of records + 512 B of id ring + 128 B of pair queue;
-// Inference launches and (round 5, SAVE_AUX variant) forwards that a backward follows.
+//     the pair's pixel comes by ds_bpermute from the lane that owns it, the record from the staged window), parks the six numbers of
+//     every pair in LDS, and then runs R short blend trips -- a divergent loop -- in which the owning lanes read their pairs' numbers
+//     and apply the recurrence (branch-free in fast arithmetic: a rejected or saturating pair runs with weight 0).
+// Per pixel the sequence of blended entries and every operation on them is unchanged, so the images -- and, in the SAVE_AUX variant, the
+// auxiliary planes the backward reads -- are bit-identical to render3s in either arithmetic mode (tests/test_raster_forward_gpu.py).
+// LDS per wave: 4 KB of records + 512 B of id ring + 1.5 KB of parking area (the queue aliases its first 128 bytes): 6,144 B (5,120 B
+// without normals and distortion, 6,912 B with SAVE_AUX). Measured (profiles/r05_final/compositing_packed.md): in the reference's
+// arithmetic, whose stateless part is 2.5 x as long, -38 % on the real merged set and -7 % at C2; in fast arithmetic equal to render3s
+// (the hand-over and its scalar bookkeeping cost what the packing saves) -- hence the default of f3dg_launch_render: render_pack -1.
 #include "f3dg_blend.h"
 #include "f3dg_ellipse.h"
 
@@ -68,8 +72,11 @@ __device__ __forceinline__ float pull(int addr, float v)
 
 // SAVE_AUX (a forward that f3dg_backward follows): also final_T [V][4][HW] and n_contrib [V][2][HW]; last_contributor / max_contributor are
 // 1-based positions in the tile's list, kept per staged slot (sP) and translated when a half of the window retires, as in render3s.
+#ifndef F3DG_R4_OCC
+#define F3DG_R4_OCC 8               // waves per SIMD the register allocation aims at (the full variants' 6 KB of LDS allow 6.5)
+#endif
 template <bool FAST, bool NORMAL, bool DIST, bool COUNT, bool SAVE_AUX = false>
-__global__ void __launch_bounds__(64, 8)
+__global__ void __launch_bounds__(64, F3DG_R4_OCC)
 render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
