@@ -175,6 +175,8 @@ def main():
     for env, opt in (("F3DG_RENDER_DMA", b"render_dma"), ("F3DG_RENDER_LDS_PAD", b"render_lds_pad"), ("F3DG_BWD_OCC", b"bwd_occ"), ("F3DG_RENDER_SLIDE", b"render_slide"), ("F3DG_RENDER_LOWOCC", b"render_lowocc"), ("F3DG_RENDER_TAIL", b"render_tail"), ("F3DG_SMALL_DEBUG", b"small_debug"), ("F3DG_RENDER_PACK_TH", b"render_pack_th"), ("F3DG_RENDER_PACK", b"render_pack"), ("F3DG_PRE_HOIST", b"pre_hoist"), ("F3DG_RENDER_WPB", b"render_wpb")):     # A/B switches of render3
         if os.environ.get(env):
             _lib.check(L.f3dg_set_option(opt, int(os.environ[env])), "f3dg_set_option")
+    for item in filter(None, os.environ.get("F3DG_OPTIONS", "").split(",")):     # "name=value,...": any library option, for A/B runs
+        _lib.check(L.f3dg_set_option(item.split("=")[0].strip().encode(), int(item.split("=")[1])), "f3dg_set_option")
     _lib.check(L.f3dg_set_option(b"tile_cull", args.tile_cull), "f3dg_set_option")
     result = {"c2": run_c2, "c4": run_c4, "c5": run_c5, "dropin": run_dropin}[args.workload](args, rank, world, dist, device, comm_device, f3d, L)
     if rank == 0:

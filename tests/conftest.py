@@ -18,9 +18,22 @@ def f3d():
     return f3dgaus_amd
 
 
+def _apply_env_options():
+    """F3DG_OPTIONS="bwd_walk=16,render_pack=0": library options for an A/B run of the whole suite (tools/ab_*.sh)."""
+    spec = os.environ.get("F3DG_OPTIONS", "")
+    if not spec:
+        return
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    for item in spec.split(","):
+        name, value = item.split("=")
+        _lib.check(L.f3dg_set_option(name.strip().encode(), int(value)), "f3dg_set_option")
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
+    _apply_env_options()
     return torch.device("cuda:0")

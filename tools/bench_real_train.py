@@ -28,7 +28,9 @@ dpix[:, 7] = 0
 kw = dict(image_height=256, image_width=256, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"], rotations=g["rotation"],
           sh_degree=1, save_aux=True)
 L = _lib.lib()
-for pack in (0, -1):
+for item in filter(None, os.environ.get("F3DG_OPTIONS", "").split(",")):
+    _lib.check(L.f3dg_set_option(item.split("=")[0].strip().encode(), int(item.split("=")[1])), "f3dg_set_option")
+for pack in ((-1,) if os.environ.get("F3DG_OPTIONS") else (0, -1)):
     L.f3dg_set_option(b"render_pack", pack)
     out, radii, ws = f3d.rasterize_views(g["xyz"], g["opacity"], vm, pm, cp, bg, **kw)
 
