@@ -81,6 +81,7 @@ SIGNATURES = {
     "f3dg_debug_last_render_kernel": (C.c_char_p, []),
     "f3dg_debug_render_counts": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "f3dg_debug_render4_counts": (_i, [C.POINTER(C.c_ulonglong), _i]),
+    "f3dg_debug_render3q_clocks": (_i, [C.POINTER(C.c_ulonglong)]),
     "f3dg_debug_pass1_occupancy": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "f3dg_backward_pairs": (_i, [_p, _p, C.POINTER(_ll)]),
     "f3dg_debug_timing": (_i, [C.POINTER(C.c_ulonglong), _i]),

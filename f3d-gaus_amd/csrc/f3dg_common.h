@@ -233,6 +233,11 @@ extern int g_f3dg_small_debug;         // timing experiments of small_bin_kernel
 extern int g_f3dg_small_path;          // 1 (default): inference calls of a small shape (f3dg_small_shape) take the three-launch path
 extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is compiled for: 5 (default: 10.0 ms at C5), 2..4 (10.2-10.4: the kernel is VALU-bound at any of them) or 6 (spills, 12.0)
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
+extern int g_f3dg_render_unroll;       // small launches (render_lowocc): entries per phase-2 trip (render3u / render3p: 2..4; 1: render3l); -1 = by launch size and arithmetic
+int f3dg_launch_render3u(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
+                         float* out_color, int fast, int save_aux, float* final_T, unsigned* n_contrib, int unroll, int split, int count);
+extern int g_f3dg_render_split;        // small launches: 1 = two waves per quadrant (render3p_fwd_kernel: a producer wave scans, gathers and runs phase 1 for the window after the one the consumer wave composites)
 extern int g_f3dg_render_lowocc;       // 1 (default): launches of at most 2048 quadrant waves take render3l_fwd_kernel (next window's gathers in flight)
 extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding half-window (render3s_fwd_kernel); 0: fixed 64-entry windows
 extern int g_f3dg_render_tail;         // N > 0: render3s switches a quadrant to the tail schedule once at most N of its pixels are unsaturated (0: never)

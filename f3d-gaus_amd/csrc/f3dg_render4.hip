@@ -414,7 +414,726 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 
 thread_local char g_kernel_name4[160] = "";
 
+
+// ---- SMALL launches (one or two 256^2 views: at most two waves per SIMD): U entries per phase-2 trip ------------------------------
+// A one-view call (the reference's own loop, visualize.py:293-314, 387-416) is 1,024 quadrant waves on 1,024 SIMDs: every wave is alone
+// and its time is the LENGTH of its instruction chain times the latency of a dependent instruction -- measured ~9 cycles per
+// instruction at 65,536 pixel-ordered Gaussians (8.7 slides x ~1,870 instructions in 77 us), where the SIMD could issue one every two.
+// render3l_fwd_kernel (f3dg_render.hip) hides the memory part of that chain (next window's gathers behind phase 2); this variant
+// shortens the arithmetic part: a phase-2 trip pops the next U passing entries of every pixel, evaluates their stateless parts
+// (f3dg_pair_eval) as U INDEPENDENT instruction streams the scheduler interleaves -- the record reads of all U leave LDS together --
+// and then applies the recurrence to the U results in list order (f3dg_pair_apply / _flat; a pair behind the pixel's saturation or
+// beyond its last passing entry runs with alpha 0). Registers are free at this occupancy. Per pixel the sequence of blended entries
+// and every operation on them is render3l's: same images and auxiliary planes to the bit.
+#define F3DG_R3U_RING 256
+template <bool SAVE_AUX, bool FAST, int U>
+__global__ void __launch_bounds__(64, 2)
+render3u_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x;
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const unsigned n = range.y - range.x;
+
+    __shared__ float4 sR[2][4][F3DG_R4_WIN];  // two windows of records, [window][16-byte chunk][entry]
+    __shared__ uint2 sQ[F3DG_R3U_RING];       // (list position, Gaussian id) of the kept entries: the current window, the next one, the backlog
+
+    const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vcull = cull + (size_t)view * P;
+    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    bool done = !inside;
+    F3dgPixel st;
+    f3dg_pixel_init(st);
+
+    unsigned cursor = 0, qhead = 0, qcount = 0;
+    unsigned id0 = lane < n ? point_list[range.x + lane] : 0u;
+    unsigned id1 = 64u + lane < n ? point_list[range.x + 64u + lane] : 0u;
+    auto scan_until = [&](unsigned want) {
+        while (qcount < want && cursor < n) {
+            const unsigned idm = id0, pos = cursor + lane;
+            cursor += 64u;
+            id0 = id1;
+            id1 = cursor + 64u + lane < n ? point_list[range.x + cursor + 64u + lane] : 0u;
+            const bool keep = pos < n && (idm & qbit) != 0u;
+            const unsigned long long kb = __ballot(keep);
+            if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R3U_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+            qcount += (unsigned)__popcll(kb);
+        }
+        wave_lds_fence();
+    };
+    auto request = [&](unsigned buf, unsigned first, unsigned m, float4& e4) {
+        e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (lane < m) {
+            const unsigned id = sQ[(first + lane) & (F3DG_R3U_RING - 1)].y;
+            const float4* src = reinterpret_cast<const float4*>(vrec + id);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                 (__attribute__((address_space(3))) void*)&sR[buf][c][0], 16, 0, 0);
+            e4 = vcull[id];
+        }
+    };
+
+    if (__ballot(!done) != 0ull) {
+        scan_until(F3DG_R4_WIN);
+        unsigned m = qcount < F3DG_R4_WIN ? qcount : F3DG_R4_WIN, buf = 0;
+        float4 e4;
+        request(0, qhead, m, e4);
+        while (m != 0u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            const float ec = lane < m ? sR[buf][3][lane].w : 0.0f;
+            // ---- phase 1 of the current window
+            int pass_lo = 0, pass_hi = 0;
+            {
+                const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
+                const float v0 = (float)qy0 - e4.y;
+                float dxx[8], adx[8], dyy[8], cdy[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    dxx[q] = u0 + (float)q;
+                    adx[q] = e4.z * dxx[q];
+                    dyy[q] = v0 + (float)q;
+                    cdy[q] = ec * dyy[q] * dyy[q];
+                }
+                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+            }
+            // ---- the next window: scan for it and request its records; they land during phase 2
+            scan_until(m + F3DG_R4_WIN);
+            const unsigned m_next = qcount - m < F3DG_R4_WIN ? qcount - m : F3DG_R4_WIN;
+            float4 e4n;
+            request(buf ^ 1u, qhead + m, m_next, e4n);
+
+            // ---- phase 2 of the current window, U entries per trip
+            unsigned long long pass = done ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+            while (pass != 0 && !done) {
+                int j[U];
+                bool have[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    have[u] = pass != 0ull;
+                    j[u] = have[u] ? __builtin_ctzll(pass) : j[0];
+                    pass &= pass - 1ull;
+                }
+                F3dgPair pr[U];
+                float cr[U], cg[U], cb[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float4 q0 = sR[buf][0][j[u]], q1 = sR[buf][1][j[u]], q2 = sR[buf][2][j[u]], q3 = sR[buf][3][j[u]];
+                    pr[u] = f3dg_pair_eval<FAST, true, true, FAST>(ray_x, ray_y, q0, q1, q2);
+                    if (!have[u]) pr[u].alpha = 0.0f;
+                    cr[u] = q3.x; cg[u] = q3.y; cb[u] = q3.z;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (FAST) {
+                        F3dgPair p = pr[u];
+                        p.alpha = done ? 0.0f : p.alpha;
+                        done |= f3dg_pair_apply_flat<true, true>(st, F3DG_R4_FLAG | (unsigned)j[u], p, cr[u], cg[u], cb[u]);
+                    } else if (!done && pr[u].alpha != 0.0f) {
+                        done = f3dg_pair_apply<false, true, true>(st, F3DG_R4_FLAG | (unsigned)j[u], pr[u], cr[u], cg[u], cb[u]);
+                    }
+                }
+            }
+            if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
+                if (st.last_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
+                    st.last_contributor = sQ[(qhead + (st.last_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+                if (st.max_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
+                    st.max_contributor = sQ[(qhead + (st.max_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+            }
+            qhead += m;
+            qcount -= m;
+            m = m_next;
+            e4 = e4n;
+            buf ^= 1u;
+            if (__ballot(!done) == 0ull)
+                break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write of this wave may still be in flight when it ends
+    }
+
+    if (inside) {
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = distortion_before_normalized;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        out[8 * HW + pix_id] = distortion;
+    }
+}
+
+// ---- SMALL launches, two waves per quadrant: a PRODUCER wave prepares window k + 1 while the CONSUMER wave composites window k ------
+// What is left of a lone wave's chain once phase 2 is shortened is everything else: with no entry passing the ellipse test at all
+// (option debug_skip_all) the one-view kernel still takes 36 of its 66 us -- list chunks, the id-dependent record gathers, the 64
+// ellipse ballots of phase 1, each a latency nobody fills. That part does not depend on any pixel's state, so here it runs on its own
+// wave: workgroup = 2 waves on 2 SIMDs of a CU; wave 1 scans the list, requests the records of the next window into the other half
+// of the double buffer (global_load_lds), waits for them, runs phase 1 and leaves the 64 pass masks in LDS; wave 0 owns the pixels and
+// only runs phase 2 (U entries per trip, as render3u). One s_barrier per window. The time of a window is the longer of the two parts
+// instead of their sum. Per pixel nothing changes: bit-identical outputs and auxiliary planes.
+template <bool SAVE_AUX, bool FAST, int U>
+__global__ void __launch_bounds__(128, 1)
+render3p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x & 63u;
+    const bool producer = threadIdx.x >= 64u;             // (wave-uniform)
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+
+    __shared__ float4 sR[2][4][F3DG_R4_WIN];              // two windows of records, [window][16-byte chunk][entry]
+    __shared__ uint2 sQ[F3DG_R3U_RING];                   // (list position, Gaussian id) of the kept entries (the producer's ring)
+    __shared__ unsigned long long sPass[2][64];           // per window: the pass mask of every pixel
+    __shared__ unsigned sM[2], sHead[2];                  // per window: its number of entries (0: the list has ended), its first ring slot
+    __shared__ unsigned sStop[2];                         // [b]: set by the consumer when every pixel was done after the window in buffer b
+
+    if (threadIdx.x < 2u) sStop[threadIdx.x] = 0u;
+
+    if (producer) {
+        // ================================================ wave 1: scan, gather, phase 1 ================================================
+        uint2 range = ranges[(size_t)view * T + tile];
+        if (hdr->overflow) range = make_uint2(0, 0);
+        const unsigned n = range.y - range.x;
+        const F3dgRec* vrec = rec + (size_t)view * P;
+        const float4* vcull = cull + (size_t)view * P;
+        const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        unsigned cursor = 0, qhead = 0, qcount = 0;
+        unsigned id0 = lane < n ? point_list[range.x + lane] : 0u;
+        unsigned id1 = 64u + lane < n ? point_list[range.x + 64u + lane] : 0u;
+        unsigned id2 = 128u + lane < n ? point_list[range.x + 128u + lane] : 0u;      // three 64-id chunks of the list in flight
+        unsigned buf = 0;
+        for (;;) {
+            // the next window: entries [qhead, qhead + m) of the ring
+            while (qcount < F3DG_R4_WIN && cursor < n) {
+                const unsigned idm = id0, pos = cursor + lane;
+                cursor += 64u;
+                id0 = id1;
+                id1 = id2;
+                id2 = cursor + 128u + lane < n ? point_list[range.x + cursor + 128u + lane] : 0u;
+                const bool keep = pos < n && (idm & qbit) != 0u;
+                const unsigned long long kb = __ballot(keep);
+                if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R3U_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+                qcount += (unsigned)__popcll(kb);
+            }
+            wave_lds_fence();
+            const unsigned m = qcount < F3DG_R4_WIN ? qcount : F3DG_R4_WIN;
+            float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (lane < m) {
+                const unsigned id = sQ[(qhead + lane) & (F3DG_R3U_RING - 1)].y;
+                const float4* src = reinterpret_cast<const float4*>(vrec + id);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                     (__attribute__((address_space(3))) void*)&sR[buf][c][0], 16, 0, 0);
+                e4 = vcull[id];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            if (m != 0u) {
+                const float ec = lane < m ? sR[buf][3][lane].w : 0.0f;
+                int pass_lo = 0, pass_hi = 0;
+                const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
+                const float v0 = (float)qy0 - e4.y;
+                float dxx[8], adx[8], dyy[8], cdy[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    dxx[q] = u0 + (float)q;
+                    adx[q] = e4.z * dxx[q];
+                    dyy[q] = v0 + (float)q;
+                    cdy[q] = ec * dyy[q] * dyy[q];
+                }
+                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+                sPass[buf][lane] = ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+            }
+            if (lane == 0) { sM[buf] = m; sHead[buf] = qhead; }
+            __syncthreads();                                  // window `buf` is ready; the consumer has finished the window before it
+            if (m == 0u || sStop[buf ^ 1u] != 0u)           // (the flag of the window composited before this barrier: the consumer's next write goes to the other one)
+                break;
+            qhead += m;
+            qcount -= m;
+            buf ^= 1u;
+        }
+        return;
+    }
+
+    // ==================================================== wave 0: the pixels, phase 2 ====================================================
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+    bool done = !inside;
+    F3dgPixel st;
+    f3dg_pixel_init(st);
+    {
+        unsigned buf = 0;
+        for (;;) {
+            __syncthreads();                                  // window `buf` is ready
+            const unsigned m = sM[buf];
+            if (m == 0u || sStop[buf ^ 1u] != 0u)
+                break;
+            unsigned long long pass = done ? 0ull : sPass[buf][lane];
+            while (pass != 0 && !done) {
+                int j[U];
+                bool have[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    have[u] = pass != 0ull;
+                    j[u] = have[u] ? __builtin_ctzll(pass) : j[0];
+                    pass &= pass - 1ull;
+                }
+                F3dgPair pr[U];
+                float cr[U], cg[U], cb[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float4 q0 = sR[buf][0][j[u]], q1 = sR[buf][1][j[u]], q2 = sR[buf][2][j[u]], q3 = sR[buf][3][j[u]];
+                    pr[u] = f3dg_pair_eval<FAST, true, true, FAST>(ray_x, ray_y, q0, q1, q2);
+                    if (!have[u]) pr[u].alpha = 0.0f;
+                    cr[u] = q3.x; cg[u] = q3.y; cb[u] = q3.z;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (FAST) {
+                        F3dgPair p = pr[u];
+                        p.alpha = done ? 0.0f : p.alpha;
+                        done |= f3dg_pair_apply_flat<true, true>(st, F3DG_R4_FLAG | (unsigned)j[u], p, cr[u], cg[u], cb[u]);
+                    } else if (!done && pr[u].alpha != 0.0f) {
+                        done = f3dg_pair_apply<false, true, true>(st, F3DG_R4_FLAG | (unsigned)j[u], pr[u], cr[u], cg[u], cb[u]);
+                    }
+                }
+            }
+            if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
+                const unsigned head = sHead[buf];
+                if (st.last_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
+                    st.last_contributor = sQ[(head + (st.last_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+                if (st.max_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
+                    st.max_contributor = sQ[(head + (st.max_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+            }
+            if (__ballot(!done) == 0ull && lane == 0) sStop[buf] = 1u;  // (read by both waves after the next barrier)
+            buf ^= 1u;
+        }
+    }
+
+    if (inside) {
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = distortion_before_normalized;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        out[8 * HW + pix_id] = distortion;
+    }
+}
+
+// ---- SMALL launches, a PIPELINE of waves per quadrant (option render_split = 2 / 3) -------------------------------------------------
+// render3p above takes the window preparation off the pixels' wave; what remains on it is phase 2 -- ~48 of 58 us at 65,536
+// Gaussians -- and two thirds of a phase-2 trip are the stateless part of the pair (f3dg_pair_eval). Here that part moves to E more
+// waves: the workgroup of a quadrant is
+//     wave 0          the CONSUMER: owns the 64 pixels' running state; per round it reads E parked pair results per pixel from LDS and
+//                     applies the recurrence to them in list order (f3dg_pair_apply / _flat), nothing else;
+//     waves 1 .. E    the EVALUATORS: every lane walks ITS pixel's pass mask of the current window; in round r evaluator e takes the
+//                     pixel's entry of rank r E + e, reads its record, evaluates the stateless part and parks the result (six numbers,
+//                     the colour, the slot) in a ring of K rounds;
+//     wave E + 1      the PRODUCER of render3p: list scan, record gathers, phase 1 and the number of rounds of a window.
+// No barrier after the first: the waves meet through monotonic LDS counters (release stores, acquire loads at workgroup scope) --
+// windows published by the producer, windows finished by every evaluator and by the consumer (the producer reuses a record buffer
+// when the window two before is finished), rounds published by every evaluator and rounds consumed (an evaluator runs at most K rounds
+// ahead). An evaluator knows nothing of saturation: it evaluates every passing entry, the consumer ignores what lies behind a pixel's
+// stop and raises a stop flag once all 64 pixels are done; every wait of the other waves watches that flag. Per pixel the sequence of
+// blended entries and every operation on them is render3l's: bit-identical images and auxiliary planes.
+struct R3qPark { float4 a[64]; float4 b[64]; float2 c[64]; };      // (alpha t m nn0) (nn1 nn2 r g) (b slot)
+
+__device__ __forceinline__ void r3q_wait_ge(unsigned* flag, unsigned v)
+{
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - v) < 0)
+        __builtin_amdgcn_s_sleep(0);
+}
+// the same for the waves that must not outwait the consumer's stop: false = stopped
+__device__ __forceinline__ bool r3q_wait_ge_or_stop(unsigned* flag, unsigned v, unsigned* stop)
+{
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - v) < 0) {
+        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u)
+            return false;
+        __builtin_amdgcn_s_sleep(0);
+    }
+    return true;
+}
+
+template <bool SAVE_AUX, bool FAST, int E>
+__global__ void __launch_bounds__(64 * (E + 2), 1)
+render3q_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
+                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
+                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib, int prof)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // option render_count: shader clocks of every role (f3dg_debug_render3q_clocks) -- g_f3dg_counts4 rows 32 + role: [0] total, [1] waiting
+    // for a window (to be published / to be finished), [2] waiting for a round counter, [3] windows, [4] rounds, [5] waves; row 40: the
+    // longest wave of every role
+    const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_win = 0ull, t_spin = 0ull, n_win = 0ull, n_rounds = 0ull;
+#define R3Q_TIMED(acc, expr) do { const unsigned long long t0_ = prof ? __builtin_readcyclecounter() : 0ull; expr; if (prof) acc += __builtin_readcyclecounter() - t0_; } while (0)
+#define R3Q_REPORT(role) do { if (prof && lane == 0) { const unsigned long long tt_ = __builtin_readcyclecounter() - t_start;                          \
+        atomicAdd(&g_f3dg_counts4[32 + (role)][0], tt_); atomicAdd(&g_f3dg_counts4[32 + (role)][1], t_win); atomicAdd(&g_f3dg_counts4[32 + (role)][2], t_spin); \
+        atomicAdd(&g_f3dg_counts4[32 + (role)][3], n_win); atomicAdd(&g_f3dg_counts4[32 + (role)][4], n_rounds); atomicAdd(&g_f3dg_counts4[32 + (role)][5], 1ull); \
+        atomicMax(&g_f3dg_counts4[40][role], tt_); } } while (0)
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+
+    constexpr int K = E == 2 ? 4 : 2;                     // rounds of parking (power of two): 20 KB (E = 2) / 15 KB (E = 3); four workgroups share a CU's 160 KB
+    __shared__ float4 sR[2][4][F3DG_R4_WIN];              // two windows of records, [window][16-byte chunk][entry]
+    __shared__ uint2 sQ[F3DG_R3U_RING];                   // (list position, Gaussian id) of the kept entries (the producer's ring)
+    __shared__ unsigned long long sPass[2][64];           // per window: the pass mask of every pixel
+    __shared__ unsigned sM[2], sHead[2], sRounds[2];      // per window: entries (0: the list has ended), first ring slot, rounds of E ranks
+    __shared__ R3qPark sPark[K][E];
+    __shared__ unsigned sProd;                            // windows published by the producer
+    __shared__ unsigned sEvalWin[E], sConsWin;            // windows finished by evaluator e / by the consumer
+    __shared__ unsigned sEvalDone[E], sConsumed;          // rounds published by evaluator e / consumed (over all windows)
+    __shared__ unsigned sStop;                            // the consumer: every pixel of the quadrant is done
+
+    if (threadIdx.x < (unsigned)E) { sEvalDone[threadIdx.x] = 0u; sEvalWin[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0) { sConsumed = 0u; sConsWin = 0u; sProd = 0u; sStop = 0u; }
+    __syncthreads();
+
+    if (wave == (unsigned)E + 1u) {
+        // ================================================ the producer: scan, gather, phase 1 ================================================
+        uint2 range = ranges[(size_t)view * T + tile];
+        if (hdr->overflow) range = make_uint2(0, 0);
+        const unsigned n = range.y - range.x;
+        const F3dgRec* vrec = rec + (size_t)view * P;
+        const float4* vcull = cull + (size_t)view * P;
+        const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        unsigned cursor = 0, qhead = 0, qcount = 0;
+        unsigned id0 = lane < n ? point_list[range.x + lane] : 0u;
+        unsigned id1 = 64u + lane < n ? point_list[range.x + 64u + lane] : 0u;
+        unsigned id2 = 128u + lane < n ? point_list[range.x + 128u + lane] : 0u;      // three 64-id chunks of the list in flight
+        for (unsigned w = 0;; w++) {
+            const unsigned buf = w & 1u;
+            while (qcount < F3DG_R4_WIN && cursor < n) {
+                const unsigned idm = id0, pos = cursor + lane;
+                cursor += 64u;
+                id0 = id1;
+                id1 = id2;
+                id2 = cursor + 128u + lane < n ? point_list[range.x + cursor + 128u + lane] : 0u;
+                const bool keep = pos < n && (idm & qbit) != 0u;
+                const unsigned long long kb = __ballot(keep);
+                if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R3U_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+                qcount += (unsigned)__popcll(kb);
+            }
+            wave_lds_fence();
+            const unsigned m = qcount < F3DG_R4_WIN ? qcount : F3DG_R4_WIN;
+            // buffer `buf` held window w - 2: every reader of its records, pass masks and ring slots must have finished it
+            if (w >= 2u) {
+                bool go = true;
+                const unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
+                for (int e = 0; e < E; e++) go = go && r3q_wait_ge_or_stop(&sEvalWin[e], w - 1u, &sStop);
+                go = go && r3q_wait_ge_or_stop(&sConsWin, w - 1u, &sStop);
+                if (prof) t_win += __builtin_readcyclecounter() - t0;
+                if (!go) break;
+            }
+            float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (lane < m) {
+                const unsigned id = sQ[(qhead + lane) & (F3DG_R3U_RING - 1)].y;
+                const float4* src = reinterpret_cast<const float4*>(vrec + id);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                     (__attribute__((address_space(3))) void*)&sR[buf][c][0], 16, 0, 0);
+                e4 = vcull[id];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            unsigned rounds = 0;
+            if (m != 0u) {
+                const float ec = lane < m ? sR[buf][3][lane].w : 0.0f;
+                int pass_lo = 0, pass_hi = 0;
+                const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
+                const float v0 = (float)qy0 - e4.y;
+                float dxx[8], adx[8], dyy[8], cdy[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    dxx[q] = u0 + (float)q;
+                    adx[q] = e4.z * dxx[q];
+                    dyy[q] = v0 + (float)q;
+                    cdy[q] = ec * dyy[q] * dyy[q];
+                }
+                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+                sPass[buf][lane] = ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
+                const unsigned most = (unsigned)__builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, (int)(__popc((unsigned)pass_lo) + __popc((unsigned)pass_hi))));
+                rounds = (most + (unsigned)E - 1u) / (unsigned)E;
+            }
+            if (lane == 0) { sM[buf] = m; sHead[buf] = qhead; sRounds[buf] = rounds; }
+            wave_lds_fence();
+            if (lane == 0) __hip_atomic_store(&sProd, w + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (m == 0u)
+                break;
+            n_win++;
+            qhead += m;
+            qcount -= m;
+        }
+        R3Q_REPORT(2);
+        return;
+    }
+
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
+    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
+    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
+
+    if (wave != 0u) {
+        // ================================================ evaluator e: the stateless part of rank r E + e ================================================
+        const unsigned e = wave - 1u;
+        unsigned rr = 0;                                      // rounds since the start (all windows)
+        for (unsigned w = 0;; w++) {
+            const unsigned buf = w & 1u;
+            bool go;
+            R3Q_TIMED(t_win, go = r3q_wait_ge_or_stop(&sProd, w + 1u, &sStop));
+            if (!go) break;
+            const unsigned m = sM[buf];
+            if (m == 0u)
+                break;
+            const unsigned R = sRounds[buf];
+            n_win++; n_rounds += R;
+            unsigned long long pass = sPass[buf][lane];
+            for (unsigned r = 0; r < R && go; r++, rr++) {
+#pragma unroll
+                for (int k = 0; k < E; k++)                   // (wave-uniform count: e ranks belong to the evaluators before this one)
+                    if ((unsigned)k < e) pass &= pass - 1ull;
+                const bool have = pass != 0ull;
+                const int j = have ? __builtin_ctzll(pass) : 0;
+                pass &= pass - 1ull;
+#pragma unroll
+                for (int k = 0; k < E - 1; k++)
+                    if ((unsigned)k + e < (unsigned)E - 1u) pass &= pass - 1ull;
+                const float4 q0 = sR[buf][0][j], q1 = sR[buf][1][j], q2 = sR[buf][2][j], q3 = sR[buf][3][j];
+                F3dgPair pr = f3dg_pair_eval<FAST, true, true, FAST>(ray_x, ray_y, q0, q1, q2);
+                if (!have) pr.alpha = 0.0f;
+                R3Q_TIMED(t_spin, go = r3q_wait_ge_or_stop(&sConsumed, rr + 1u - (unsigned)K, &sStop));      // the ring slot of round rr - K has been read
+                if (!go) break;
+                R3qPark& pk = sPark[rr & (K - 1)][e];
+                pk.a[lane] = make_float4(pr.alpha, pr.t, pr.m, pr.nn0);
+                pk.b[lane] = make_float4(pr.nn1, pr.nn2, q3.x, q3.y);
+                pk.c[lane] = make_float2(q3.z, __uint_as_float((unsigned)j));
+                wave_lds_fence();
+                if (lane == 0) __hip_atomic_store(&sEvalDone[e], rr + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (!go) break;
+            if (lane == 0) __hip_atomic_store(&sEvalWin[e], w + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        R3Q_REPORT(1);
+        return;
+    }
+
+    // ==================================================== the consumer: the pixels' recurrence ====================================================
+    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * pix_y + pix_x;
+    bool done = !inside;
+    F3dgPixel st;
+    f3dg_pixel_init(st);
+    {
+        unsigned rr = 0;
+        bool stop = false;
+        for (unsigned w = 0; !stop; w++) {
+            const unsigned buf = w & 1u;
+            R3Q_TIMED(t_win, r3q_wait_ge(&sProd, w + 1u));
+            const unsigned m = sM[buf];
+            if (m == 0u)
+                break;
+            const unsigned R = sRounds[buf];
+            n_win++; n_rounds += R;
+            const unsigned rr_end = rr + R;
+            for (; rr != rr_end; rr++) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    R3Q_TIMED(t_spin, r3q_wait_ge(&sEvalDone[e], rr + 1u));
+                    const R3qPark& pk = sPark[rr & (K - 1)][e];
+                    const float4 a = pk.a[lane], b = pk.b[lane];
+                    const float2 c = pk.c[lane];
+                    F3dgPair p;
+                    p.alpha = a.x; p.t = a.y; p.m = a.z; p.nn0 = a.w; p.nn1 = b.x; p.nn2 = b.y;
+                    const unsigned contributor = F3DG_R4_FLAG | __float_as_uint(c.y);
+                    if (FAST) {
+                        p.alpha = done ? 0.0f : p.alpha;
+                        done |= f3dg_pair_apply_flat<true, true>(st, contributor, p, b.z, b.w, c.x);
+                    } else if (!done && p.alpha != 0.0f) {
+                        done = f3dg_pair_apply<false, true, true>(st, contributor, p, b.z, b.w, c.x);
+                    }
+                }
+                wave_lds_fence();
+                if (lane == 0) __hip_atomic_store(&sConsumed, rr + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__ballot(!done) == 0ull) {                 // nobody needs the rest of the list
+                    stop = true;
+                    break;
+                }
+            }
+            if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
+                const unsigned head = sHead[buf];
+                if (st.last_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
+                    st.last_contributor = sQ[(head + (st.last_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+                if (st.max_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
+                    st.max_contributor = sQ[(head + (st.max_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+            }
+            wave_lds_fence();
+            if (lane == 0) {
+                if (stop) __hip_atomic_store(&sStop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(&sConsWin, w + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    R3Q_REPORT(0);
+#undef R3Q_TIMED
+#undef R3Q_REPORT
+
+    if (inside) {
+        const float* bg = background + (bg_per_view ? 3 * view : 0);
+        const float Tr = st.Tr;
+        const float distortion_before_normalized = st.distortion;
+        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
+
+        if (SAVE_AUX) {
+            float* fT = final_T + (size_t)view * 4 * HW;
+            fT[pix_id] = Tr;
+            fT[pix_id + HW] = st.dist1;
+            fT[pix_id + 2 * HW] = st.dist2;
+            fT[pix_id + 3 * HW] = distortion_before_normalized;
+            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
+            nc[pix_id] = st.last_contributor;
+            nc[pix_id + HW] = st.max_contributor;
+        }
+        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
+        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
+        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
+        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
+        out[3 * HW + pix_id] = st.C3;
+        out[4 * HW + pix_id] = st.C4;
+        out[5 * HW + pix_id] = st.C5;
+        out[6 * HW + pix_id] = st.C6;
+        out[7 * HW + pix_id] = st.C7;
+        out[8 * HW + pix_id] = distortion;
+    }
+}
+
 } // namespace
+
+int f3dg_launch_render3u(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
+                         float* out_color, int fast, int save_aux, float* final_T, unsigned* n_contrib, int unroll, int split, int count)
+{
+    const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    const int T = tiles_x * tiles_y;
+    const dim3 grid((unsigned)V * (unsigned)T * 4u);
+    if (split >= 2) {       // the pipeline of waves: consumer + E evaluators + producer
+        const int E = split >= 3 ? 3 : 2;
+#define F3DG_LAUNCH3Q(AUX, FST, EE) F3DG_KLAUNCH((render3q_fwd_kernel<AUX, FST, EE>), grid, dim3(64 * (EE + 2)), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, \
+                                                 point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib, count)
+#define F3DG_LAUNCH3Q_E(AUX, FST) do { if (E == 3) F3DG_LAUNCH3Q(AUX, FST, 3); else F3DG_LAUNCH3Q(AUX, FST, 2); } while (0)
+        if (save_aux) { if (fast) F3DG_LAUNCH3Q_E(true, true); else F3DG_LAUNCH3Q_E(true, false); }
+        else { if (fast) F3DG_LAUNCH3Q_E(false, true); else F3DG_LAUNCH3Q_E(false, false); }
+#undef F3DG_LAUNCH3Q_E
+#undef F3DG_LAUNCH3Q
+        snprintf(g_kernel_name4, sizeof g_kernel_name4, "render3q_fwd_kernel<SAVE_AUX=%s, FAST=%s, E=%d>", save_aux ? "true" : "false", fast ? "true" : "false", E);
+        g_f3dg_last_render_kernel = g_kernel_name4;
+        F3DG_HIP_CHECK(hipGetLastError());
+        return F3DG_OK;
+    }
+    if (split) {
+        const int U = unroll >= 2 ? 2 : 1;
+#define F3DG_LAUNCH3P(AUX, FST, UU) F3DG_KLAUNCH((render3p_fwd_kernel<AUX, FST, UU>), grid, dim3(128), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, \
+                                                 point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib)
+#define F3DG_LAUNCH3P_U(AUX, FST) do { if (U == 2) F3DG_LAUNCH3P(AUX, FST, 2); else F3DG_LAUNCH3P(AUX, FST, 1); } while (0)
+        if (save_aux) { if (fast) F3DG_LAUNCH3P_U(true, true); else F3DG_LAUNCH3P_U(true, false); }
+        else { if (fast) F3DG_LAUNCH3P_U(false, true); else F3DG_LAUNCH3P_U(false, false); }
+#undef F3DG_LAUNCH3P_U
+#undef F3DG_LAUNCH3P
+        snprintf(g_kernel_name4, sizeof g_kernel_name4, "render3p_fwd_kernel<SAVE_AUX=%s, FAST=%s, U=%d>", save_aux ? "true" : "false", fast ? "true" : "false", U);
+        g_f3dg_last_render_kernel = g_kernel_name4;
+        F3DG_HIP_CHECK(hipGetLastError());
+        return F3DG_OK;
+    }
+    const int U = unroll >= 4 ? 4 : unroll == 3 ? 3 : 2;
+#define F3DG_LAUNCH3U(AUX, FST, UU) F3DG_KLAUNCH((render3u_fwd_kernel<AUX, FST, UU>), grid, dim3(64), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, \
+                                                 point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib)
+#define F3DG_LAUNCH3U_U(AUX, FST) do { if (U == 4) F3DG_LAUNCH3U(AUX, FST, 4); else if (U == 3) F3DG_LAUNCH3U(AUX, FST, 3); else F3DG_LAUNCH3U(AUX, FST, 2); } while (0)
+    if (save_aux) { if (fast) F3DG_LAUNCH3U_U(true, true); else F3DG_LAUNCH3U_U(true, false); }
+    else { if (fast) F3DG_LAUNCH3U_U(false, true); else F3DG_LAUNCH3U_U(false, false); }
+#undef F3DG_LAUNCH3U_U
+#undef F3DG_LAUNCH3U
+    snprintf(g_kernel_name4, sizeof g_kernel_name4, "render3u_fwd_kernel<SAVE_AUX=%s, FAST=%s, U=%d>", save_aux ? "true" : "false", fast ? "true" : "false", U);
+    g_f3dg_last_render_kernel = g_kernel_name4;
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
 
 int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
@@ -450,11 +1169,25 @@ extern "C" int f3dg_debug_render4_counts(unsigned long long* h_out, int reset)
     if (h_out)
         for (int k = 0; k < 16; k++) {
             h_out[k] = 0;
-            for (int r = 0; r < 64; r++) h_out[k] += rows[r][k];
+            for (int r = 0; r < 32; r++) h_out[k] += rows[r][k];      // (rows 32..: render3q's role clocks)
         }
     if (reset) {
         memset(rows, 0, sizeof rows);
         F3DG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_f3dg_counts4), rows, sizeof rows));
     }
+    return F3DG_OK;
+}
+
+// debug: the role clocks of render3q_fwd_kernel (option render_count = 1), summed over the launches since the last reset of
+// f3dg_debug_render4_counts: h_out[4][16] = rows { consumer, evaluators, producer } x { shader clocks in total, at the window barrier,
+// waiting for a counter, windows, rounds, waves }, row 3 = the longest { consumer, evaluator, producer } wave of any workgroup
+extern "C" int f3dg_debug_render3q_clocks(unsigned long long* h_out)
+{
+    static unsigned long long rows[64][16];
+    if (!h_out) return F3DG_ERR_BAD_ARG;
+    F3DG_HIP_CHECK(hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_f3dg_counts4), sizeof rows));
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 16; k++) h_out[16 * r + k] = rows[32 + r][k];
+    for (int k = 0; k < 16; k++) h_out[48 + k] = rows[40][k];
     return F3DG_OK;
 }

@@ -361,7 +361,12 @@ int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const u
  * with per-4x4-block lists; 1 = the round-1 pixel-lane kernel (its plain variant is the transcription-order baseline of the tests).
  * "render_slide" (default 1): render3 with sliding half-windows (render3s_fwd_kernel) or fixed 64-entry windows (0).
  * "render_lowocc" (default 1): launches of at most 2,048 quadrant waves (one or two 256^2 views) take render3l_fwd_kernel, which
- * keeps the next window's gathers in flight behind phase 2; 0 = the general kernel for every launch.
+ * keeps the next window's gathers in flight behind phase 2; 0 = the general kernel for every launch. Launches of at most 1,024 waves
+ * (ONE 256^2 view: every wave alone on its SIMD, its time a chain of latencies) use several waves per quadrant, bit-identical:
+ * "render_split" (default -1: 1 in fast arithmetic, 3 in the reference's): 1 = render3p_fwd_kernel, a producer wave scans the list,
+ * gathers the records and runs phase 1 of the next window while the consumer wave composites; 2 / 3 = render3q_fwd_kernel, consumer +
+ * 2 / 3 evaluator waves (the stateless part of every pair, parked in LDS) + producer; 0 = one wave. "render_unroll" (default -1: 2
+ * in fast arithmetic on one-view launches, else 1): entries per phase-2 trip of the one- and two-wave kernels (2..4).
  * "render_dma" (default 1): render3 stages records by global_load_lds_dwordx4 (1) or through registers (0); "render_lds_pad"
  * (default 0): extra dynamic LDS bytes per render3 workgroup (occupancy experiments).
  * "bwd_occ" (default 5): waves per SIMD the compositing backward (render3_bwd_kernel) is compiled for (2..6).
@@ -422,6 +427,11 @@ int f3dg_debug_render_counts(unsigned long long* h_out8, int reset);
  * staged, scanned, fused trips, slides, lane-trips of fused trips, waves, packed batches (= dense trips), blend trips of the batches,
  * pairs evaluated in dense trips, pairs that reached a blend trip, 0 ... }. */
 int f3dg_debug_render4_counts(unsigned long long* h_out, int reset);
+/* Debug: shader clocks of the roles of the small-launch pipeline kernel (render3q_fwd_kernel, options render_split = 2 / 3 and
+ * render_count = 1), summed over the launches since the last reset of f3dg_debug_render4_counts. h_out[4][16]: rows { consumer,
+ * evaluators, producer } x { total, waiting at the window barrier, waiting for a round counter, windows, rounds, waves }; row 3 =
+ * the longest { consumer, evaluator, producer } wave of any workgroup. */
+int f3dg_debug_render3q_clocks(unsigned long long* h_out);
 /* Diagnostic (tools/pmc_pass1.sh): resident workgroups per CU of the two pass-1 kernels of f3dg_integrate as the runtime computes it. */
 int f3dg_debug_pass1_occupancy(int* rays_blocks, int* cull_blocks);
 

@@ -384,6 +384,67 @@ def test_packed_schedule_bit_identical(name, gpu_device):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
 
 
+@pytest.mark.parametrize("name", ["F2_oblique_aniso", "F5_odd_size", "F6_small_splats", "F9_long_tile_lists", "C1", "thin"])
+def test_small_launch_unrolled_trips_bit_identical(name, gpu_device):
+    """Launches of at most 2,048 quadrant waves (one or two 256^2 views: the reference's per-view loop) take the latency-chain
+    kernels. render3u_fwd_kernel (option render_unroll = U, csrc/f3dg_render4.hip) pops U passing entries per phase-2 trip, evaluates
+    their stateless parts as independent instruction streams and applies the recurrence in list order: images and auxiliary planes
+    must be render3l's (U = 1) to the bit, for every U, and meet the oracle."""
+    from f3dgaus_amd import _lib
+    extra = {"C1": dict(P=65536, res=(256, 256), s0=0.01, view="oblique"),
+             "thin": dict(P=40000, res=(120, 88), s0=0.03, view="oblique", n_views=2, seed=7)}
+    scene = make_scene(**(SCENES[name] if name in SCENES else extra[name]))
+    if name == "thin":
+        scene["opacities"] = scene["opacities"] * 0.04        # nothing saturates: every quadrant walks its whole list
+    V = scene["viewmatrix"].shape[0]
+    assert V * ((scene["W"] + 15) // 16) * ((scene["H"] + 15) // 16) * 4 <= 2048
+    L = _lib.lib()
+    res = {}
+    try:
+        L.f3dg_set_option(b"render_split", 0)
+        for U in (1, 2, 3, 4):
+            assert L.f3dg_set_option(b"render_unroll", U) == 0
+            for aux in (False, True):
+                res[U, aux] = run_hip(scene, gpu_device, save_aux=aux)
+                assert (b"render3l" if U == 1 else b"render3u") in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
+        # two waves per quadrant (option render_split): the producer wave prepares the next window while the consumer composites
+        L.f3dg_set_option(b"render_split", 1)
+        for U in (1, 2):
+            L.f3dg_set_option(b"render_unroll", U)
+            for aux in (False, True):
+                res["split", U, aux] = run_hip(scene, gpu_device, save_aux=aux)
+                assert b"render3p" in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
+        # the pipeline of waves (render_split = 2 / 3: a consumer wave, 2 / 3 evaluator waves, the producer wave)
+        for sp in (2, 3):
+            L.f3dg_set_option(b"render_split", sp)
+            for aux in (False, True):
+                res["split", 10 * sp, aux] = run_hip(scene, gpu_device, save_aux=aux)
+                assert b"render3q" in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
+        # the defaults: by launch size and arithmetic (one view: render3p in fast arithmetic, render3q in the reference's)
+        L.f3dg_set_option(b"render_unroll", -1)
+        L.f3dg_set_option(b"render_split", -1)
+        res["split", 0, False] = run_hip(scene, gpu_device, save_aux=False)
+        if V * ((scene["W"] + 15) // 16) * ((scene["H"] + 15) // 16) * 4 <= 1024:
+            import helpers
+            want = b"render3q" if helpers.RENDER_MODE == "exact" else b"render3p" if helpers.RENDER_MODE == "fast" else b"render3"
+            assert want in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
+        res["split", 0, True] = run_hip(scene, gpu_device, save_aux=True)
+    finally:
+        L.f3dg_set_option(b"render_unroll", -1)
+        L.f3dg_set_option(b"render_split", -1)
+    for U in (0, 1, 2, 20, 30):
+        assert np.array_equal(res[1, False]["out_color"].view(np.uint32), res["split", U, False]["out_color"].view(np.uint32)), ("split", U)
+        for k in ("out_color", "final_T", "n_contrib"):
+            assert np.array_equal(res[1, True][k].view(np.uint32), res["split", U, True][k].view(np.uint32)), ("split", U, k)
+    for U in (2, 3, 4):
+        assert np.array_equal(res[1, False]["out_color"].view(np.uint32), res[U, False]["out_color"].view(np.uint32)), U
+        for k in ("out_color", "final_T", "n_contrib"):
+            assert np.array_equal(res[1, True][k].view(np.uint32), res[U, True][k].view(np.uint32)), (U, k)
+    for v in range(V):
+        o = run_oracle(scene, view=v)
+        assert_render_parity(res[4, False]["out_color"][v], o["out_color"], "unrolled %s view %d" % (name, v))
+
+
 @pytest.mark.parametrize("tail", [64, 16, 3])
 def test_tail_schedule_thin_coverage(tail, gpu_device):
     """The tail schedule of the one-wave kernel (option render_tail) on the case it exists for: long tile lists of faint

@@ -31,6 +31,16 @@ if os.environ.get("REAL"):
               tanfovy=cams["tanfovy"], bg=torch.zeros(3), viewmatrix=cams["viewmatrix"][vi:vi + 1], projmatrix=cams["projmatrix"][vi:vi + 1],
               campos=cams["campos"][vi:vi + 1], means3D=g["xyz"], opacities=g["opacity"], scales=g["scaling"], rotations=g["rotation"],
               shs=torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous(), colors_precomp=None)
+elif os.environ.get("PIXEL"):        # the drop-in loop's one-view scene: 65,536 pixel-ordered Gaussians (bench.py --workload dropin)
+    import torch
+    from f3dgaus_amd import synthetic
+    g = synthetic.make_pixel_gaussians(256, s0=S0, seed=0, device="cpu")
+    cams = synthetic.orbit_cameras(60, resolution=256)
+    vi = int(os.environ.get("VIEW", "7"))
+    sc = dict(P=g["xyz"].shape[0], W=256, H=256, sh_degree=1, kernel_size=0.0, scale_modifier=1.0, tanfovx=cams["tanfovx"],
+              tanfovy=cams["tanfovy"], bg=torch.zeros(3), viewmatrix=cams["viewmatrix"][vi:vi + 1], projmatrix=cams["projmatrix"][vi:vi + 1],
+              campos=cams["campos"][vi:vi + 1], means3D=g["xyz"], opacities=g["opacity"], scales=g["scaling"], rotations=g["rotation"],
+              shs=torch.cat([g["features_dc"], g["features_rest"]], 1).contiguous(), colors_precomp=None)
 else:
     sc = make_scene(P=196608, res=(256, 256), s0=S0, view="oblique")
 o = run_oracle(sc)
@@ -46,6 +56,7 @@ tiles = rng.choice(256, NT, replace=False)
 
 slides = []          # per slide: list of active-lane counts per trip
 n_slides = 0
+n_waves = 0
 for tile in tiles:
     r0, r1 = ranges[tile]
     ids = pl[r0:r1]
@@ -95,6 +106,7 @@ for tile in tiles:
         if len(lst) == 0:
             continue
         dq = doneidx[lanes].max()
+        n_waves += 1
         pm = proc[np.ix_(lanes, lst)]
         nq = pm.shape[1]
         nxt = [np.nonzero(pm[l])[0] for l in range(64)]
@@ -115,6 +127,7 @@ for tile in tiles:
             slides.append(trips)
             s += STEP
 
+print("quadrant waves %d: slides per wave %.1f" % (n_waves, len(slides) / max(n_waves, 1)))
 slides_n = len(slides)
 all_trips = np.array([t for s in slides for t in s])
 print("slides %d, trips %d (%.2f per slide), lane-trips %d, utilisation %.3f" %
