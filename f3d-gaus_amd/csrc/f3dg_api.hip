@@ -308,6 +308,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.n_contrib = take((size_t)V * 2 * HW * sizeof(unsigned));
     L.bwd_acc = take(VP * 10 * sizeof(double));
     L.small_cap = f3dg_small_shape(P, W, H, V) ? (unsigned)F3DG_SMALL_CAP : 0u;
+    L.small_boxes = take(L.small_cap ? (size_t)V * ((P + 63) / 64) * sizeof(uint2) : 0);
     L.small_cnt = take((size_t)V * T * sizeof(unsigned));
     L.small_list = take((size_t)V * T * L.small_cap * sizeof(unsigned));
     L.total = off;
@@ -362,7 +363,8 @@ int run_geometry(hipStream_t s, char* ws, const F3dgLayout& L, int n_views, int 
                                     reinterpret_cast<float4*>(ws + L.cull),
                                     reinterpret_cast<float4*>(ws + L.conic), radii_used,
                                     reinterpret_cast<unsigned*>(ws + L.tiles),
-                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux, tile_cull, init, hoist, n_sets);
+                                    reinterpret_cast<unsigned char*>(ws + L.clamped), save_aux, tile_cull, init, hoist, n_sets,
+                                    small ? reinterpret_cast<uint2*>(ws + L.small_boxes) : nullptr);
     if (rc != F3DG_OK) return rc;
     prof_mark(prof, ST_PREPROCESS, s);
     rc = small ? f3dg_launch_small_bin(s, n_views, P, W, H, L, ws) : f3dg_launch_binning(s, n_views, P, W, H, L, ws, save_aux);

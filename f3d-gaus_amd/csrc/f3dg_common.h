@@ -136,6 +136,7 @@ struct F3dgLayout {
     size_t n_contrib;      // [V][2][H*W] u32
     size_t bwd_acc;        // [V*P][10] double: float64 accumulator of dL/dview2gaussian (backward only)
     // small-call path (f3dg_small.hip; carved only for the shapes it serves, small_cap = 0 otherwise)
+    size_t small_boxes;    // [V][ceil(P/64)] uint2: union of the tile rectangles of every 64 consecutive Gaussians (small path only)
     size_t small_cnt;      // [V*T] u32: length of every (view, tile) list
     size_t small_list;     // [V*T][small_cap] u32: the sorted lists (the compositing kernel's point list on this path)
     unsigned int small_cap;
@@ -200,7 +201,8 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox /* may be null */, float4* cull, float4* conic,
                            int* radii, unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init,
-                           float4* hoist = nullptr /* scratch of n_sets * P * 96 bytes: option pre_hoist */, int n_sets = 1);
+                           float4* hoist = nullptr /* scratch of n_sets * P * 96 bytes: option pre_hoist */, int n_sets = 1,
+                           uint2* chunk_boxes = nullptr /* small path: [V][ceil(P/64)] unions of 64 rectangles */);
 extern int g_f3dg_pre_hoist;            // 1: the view-independent part of the projection is computed once per Gaussian (preprocess_hoist_kernel)
 
 // Small-call path: entries per (view, tile) it can hold, and the shapes it serves (one or two views of at most 2^18 Gaussians on at

@@ -250,7 +250,7 @@ preprocess_kernel(int P, int D, int M, int views_per_set, const float4* __restri
                   float4* __restrict__ conic_out,
                   int* __restrict__ radii, unsigned* __restrict__ tiles_touched,
                   unsigned char* __restrict__ clamped, int debug_skip_all, int tile_cull,
-                  double inv_focal_x, double inv_focal_y, F3dgHeaderInit init, int chunk_major)
+                  double inv_focal_x, double inv_focal_y, F3dgHeaderInit init, int chunk_major, uint2* __restrict__ chunk_boxes)
 {
     if (init.hdr != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
         // the workspace header (read by every later kernel of the call, by nothing in this one): zeroed, then its constants
@@ -562,6 +562,21 @@ preprocess_kernel(int P, int D, int M, int views_per_set, const float4* __restri
 
     radii[idx] = my_radii;
     rects[idx] = rect;
+    if (chunk_boxes) {
+        // small-call path (f3dg_small.hip): the union of the tile rectangles of this wave's 64 consecutive Gaussians, so that a tile's
+        // workgroup tests 64 Gaussians with one comparison before it reads their rectangles. (The view's last, partial wave -- the
+        // lanes beyond P have left -- publishes "everything".)
+        uint2 bx = make_uint2(F3DG_RECT_COORD << 16, F3DG_RECT_COORD << 16);
+        if (__ballot(true) == ~0ull) {
+            const bool vis = ((rect.x >> 16) & F3DG_RECT_COORD) > (rect.x & F3DG_RECT_COORD) && ((rect.y >> 16) & F3DG_RECT_COORD) > (rect.y & F3DG_RECT_COORD);
+            const unsigned mnx = __reduce_min_sync(~0ull, vis ? rect.x & F3DG_RECT_COORD : F3DG_RECT_COORD);
+            const unsigned mxx = __reduce_max_sync(~0ull, vis ? (rect.x >> 16) & F3DG_RECT_COORD : 0u);
+            const unsigned mny = __reduce_min_sync(~0ull, vis ? rect.y & F3DG_RECT_COORD : F3DG_RECT_COORD);
+            const unsigned mxy = __reduce_max_sync(~0ull, vis ? (rect.y >> 16) & F3DG_RECT_COORD : 0u);
+            bx = make_uint2(mnx | (mxx << 16), mny | (mxy << 16));
+        }
+        if ((threadIdx.x & 63u) == 0u) chunk_boxes[(size_t)v * ((P + 63) / 64) + (g >> 6)] = bx;
+    }
     sort_keys[idx] = my_tiles ? __float_as_uint(depth) : 0xFFFFFFFFu;      // key of the per-view depth sort (f3dg_binning.hip)
     if (bbox_out) bbox_out[idx] = box;
     // The 64-byte record and the 16-byte ellipse are read through the tile lists only: a (view, Gaussian) pair that is in no list
@@ -609,7 +624,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, int W, int H,
                            float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                            F3dgRec* rec, float2* means2D, float* depths, unsigned* sort_keys, uint2* rects, float4* bbox, float4* cull, float4* conic, int* radii,
-                           unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init, float4* hoist, int n_sets)
+                           unsigned* tiles, unsigned char* clamped, int save_aux, int tile_cull, F3dgHeaderInit init, float4* hoist, int n_sets, uint2* chunk_boxes)
 {
     const int grid_x = (W + F3DG_TILE - 1) / F3DG_TILE, grid_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     // option pre_hoist: the view-independent part once per Gaussian (only the common input form: scales + rotations, nothing precomputed)
@@ -623,7 +638,7 @@ int f3dg_launch_preprocess(hipStream_t s, int V, int views_per_set, int P, int D
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, v2g_precomp, viewmatrix, projmatrix,                          \
                        cam_pos, W, H, grid_x, grid_y, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, rec, means2D,                                          \
                        depths, sort_keys, rects, bbox, cull, conic, radii, tiles, clamped, g_f3dg_debug_skip_all, tile_cull,                                    \
-                       1.0 / (double)focal_x, 1.0 / (double)focal_y, init, chunk_major)
+                       1.0 / (double)focal_x, 1.0 / (double)focal_y, init, chunk_major, chunk_boxes)
 #define F3DG_LAUNCH_PRE(AUX) do { if (hoist) F3DG_LAUNCH_PRE2(AUX, true); else F3DG_LAUNCH_PRE2(AUX, false); } while (0)
     if (save_aux) F3DG_LAUNCH_PRE(true); else F3DG_LAUNCH_PRE(false);
 #undef F3DG_LAUNCH_PRE

@@ -4,9 +4,12 @@
 // 589,824 Gaussians each). For such a call the general binning stage (f3dg_binning.hip: per-view depth sort, instance generation, tile
 // pass; 26 dependent launches built for hundreds of views per call) is all launch latency: ~4.5 us per kernel whatever it does,
 // ~150 us per call at 65,536 Gaussians. Here ONE kernel does the binning, one workgroup per (view, tile):
-//   1. its sixteen waves each scan a sixteenth of the view's Gaussians (tile rectangle, 8 B each, from L2) and note as one ballot per
-//      64 Gaussians which rectangles hold the tile; the ballots are expanded into the hits' ids in id order (a prefix over the waves'
-//      counts gives every wave its place), their depth keys gathered densely -- no atomics, no lists in global memory;
+//   1. its sixteen waves find the Gaussians whose tile rectangle holds the tile, in two levels (round 5): the projection leaves the
+//      union of the rectangles of every 64 consecutive Gaussians, a wave tests those unions first (one lane per 64 Gaussians) and only
+//      the hit chunks have their rectangles read (8 B each, from L2), shared round-robin among the waves; a point cloud in no particular
+//      id order hits most unions and is scanned flat, a sixteenth per wave. One ballot per 64 Gaussians notes which rectangles hold the
+//      tile; the ballots are expanded into the hits' ids in id order (a prefix over the waves' counts gives every wave its place),
+//      their depth keys gathered densely -- no atomics, no lists in global memory;
 //   2. a stable LSD radix sort of the (depth bits, id) pairs in LDS (wave-ballot ranking, four 8-bit passes, passes whose digit is the
 //      same for every entry are skipped) -- exactly the order of the reference's stable sort of (tile | depth) keys
 //      (rasterizer_impl.cu:70-111, 358-363);
@@ -35,6 +38,7 @@ struct SmallShared {
     u32 hist[SMALL_WAVES][256];                // per-wave digit counts, then the waves' write offsets
     u32 wave_n[SMALL_WAVES];
     u32 wave_min[SMALL_WAVES], wave_max[SMALL_WAVES];
+    u64 chit[SMALL_WAVES][SMALL_STEPS / 64];    // which chunks of every wave's share hold the tile
     u32 wsum[4];
     u32 skip;
 };
@@ -43,7 +47,7 @@ static_assert(sizeof(u64) * SMALL_STEPS * SMALL_WAVES <= 2 * sizeof(u32) * F3DG_
 // One workgroup of 16 waves per (view, tile): a single 256^2 view is 256 workgroups, one per CU, and the scan of the view's
 // Gaussians is a latency chain per wave -- the sixteen waves of a CU each take a sixteenth of it.
 __global__ void __launch_bounds__(SMALL_THREADS)
-small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const uint2* __restrict__ rects,
+small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const uint2* __restrict__ rects, const uint2* __restrict__ boxes,
                  const u32* __restrict__ sort_keys, u32* __restrict__ list, u32* __restrict__ cnt, uint2* __restrict__ ranges, int debug_stop)
 {
     __shared__ SmallShared sh;
@@ -55,38 +59,102 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
     const uint2* vrect = rects + (size_t)view * P;
     const u32* vkey = sort_keys + (size_t)view * P;
 
-    // ---- 1. collect: wave w scans Gaussians [w Pq, (w + 1) Pq), 32 steps of 64 in flight. A step only tests the packed tile
-    // rectangle (rmin <= t < rmax in both halves of a word with one packed 16-bit subtraction); its ballot -- which of the step's 64
-    // Gaussians hit the tile -- is parked in lane `step % 32` and leaves for LDS 32 steps at a time. The limit of a tile is its TOTAL
-    // (F3DG_SMALL_CAP entries), however the hits are spread over the waves: predicted Gaussians are pixel-ordered (id = y * 256 + x), a
-    // wave's share is sixteen image rows = one tile row, and ALL hits of a tile come from one or two waves.
+    // ---- 1. collect. Two levels: the projection left, for every CHUNK of 64 consecutive Gaussians, the union of their tile rectangles
+    // (boxes); a wave first tests the boxes of its share of the Gaussians (wave w owns [w Pq, (w + 1) Pq): one lane per chunk), and only
+    // the chunks whose box holds the tile have their 64 rectangles read -- by whichever wave comes next in a round-robin over ALL the
+    // workgroup's hit chunks: predicted Gaussians are pixel-ordered (id = y * 256 + x), a wave's share is sixteen image rows = one tile
+    // row, and all hits of a tile lie in the shares of one or two waves. A chunk's ballot -- which of its 64 Gaussians hit the tile --
+    // goes to the OWNER's row of hit masks (buffer 0, one 64-bit word per chunk), so everything after this step is unchanged. A test only
+    // looks at the packed tile rectangle (rmin <= t < rmax in both halves of a word with one packed 16-bit subtraction). The limit of a
+    // tile is its TOTAL (F3DG_SMALL_CAP entries), however the hits are spread over the waves.
     const u32 Pq = ((P + 64u * SMALL_WAVES - 1u) / (64u * SMALL_WAVES)) * 64u;
-    const u32 g0 = min(P, wave * Pq), g1 = min(P, g0 + Pq);
-    u32 nw = 0;                                 // hits of this wave (wave-uniform)
-    u64* wbal = reinterpret_cast<u64*>(&sh.buf[0][0]) + wave * SMALL_STEPS;
+    const u32 g0 = min(P, wave * Pq);
+    const u32 CW = Pq / 64u;                     // chunks per wave: <= SMALL_STEPS
+    const u32 nchunks = (P + 63u) / 64u;
+    const uint2* vbox = boxes + (size_t)view * nchunks;
+    u64* const wbal_all = reinterpret_cast<u64*>(&sh.buf[0][0]);
+    u64* wbal = wbal_all + wave * SMALL_STEPS;
     typedef short pk16 __attribute__((ext_vector_type(2)));
     const u32 cxw = (tx + 1u) | ((tx + 1u) << 16), cyw = (ty + 1u) | ((ty + 1u) << 16);
     const pk16 cx = __builtin_bit_cast(pk16, cxw), cy = __builtin_bit_cast(pk16, cyw);
-    constexpr int UN = 32;                       // steps of 64 rectangles in flight per lane (the scan is a chain of memory round trips)
-    u32 nsteps = 0;
-    for (u32 base = g0; base < g1; base += 64u * UN, nsteps += UN) {
-        uint2 r[UN];
-#pragma unroll
-        for (int u = 0; u < UN; u++)        // (unconditional loads from a clamped index: a guarded load is a branch + a full wait each)
-            r[u] = vrect[min(base + 64u * u + lane, P - 1u)];
-        u32 keep_lo = 0, keep_hi = 0;
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            // low half: rmin - (t + 1) < 0  <=>  rmin <= t;  high half: rmax - (t + 1) >= 0  <=>  t < rmax  (an empty rectangle fails the second)
-            const u32 dx = __builtin_bit_cast(u32, __builtin_bit_cast(pk16, r[u].x & 0x7FFF7FFFu) - cx);
-            const u32 dy = __builtin_bit_cast(u32, __builtin_bit_cast(pk16, r[u].y & 0x7FFF7FFFu) - cy);
-            const bool in = (((dx ^ 0x8000u) | (dy ^ 0x8000u)) & 0x80008000u) == 0u && base + 64u * u + lane < g1;
-            const u64 bal = __ballot(in);
-            if (lane == (u32)u) { keep_lo = (u32)bal; keep_hi = (u32)(bal >> 32); }
-            nw += (u32)__popcll(bal);
-        }
-        if (lane < (u32)UN) wbal[nsteps + lane] = ((u64)keep_hi << 32) | keep_lo;
+    // low half: rmin - (t + 1) < 0  <=>  rmin <= t;  high half: rmax - (t + 1) >= 0  <=>  t < rmax  (an empty rectangle fails the second)
+    auto holds_tile = [&](const uint2 r) {
+        const u32 dx = __builtin_bit_cast(u32, __builtin_bit_cast(pk16, r.x & 0x7FFF7FFFu) - cx);
+        const u32 dy = __builtin_bit_cast(u32, __builtin_bit_cast(pk16, r.y & 0x7FFF7FFFu) - cy);
+        return (((dx ^ 0x8000u) | (dy ^ 0x8000u)) & 0x80008000u) == 0u;
+    };
+    const u32 nsteps = CW;
+    for (u32 s0 = 0; s0 < CW; s0 += 64u) {
+        const u32 c = wave * CW + s0 + lane;
+        const bool in = s0 + lane < CW && c < nchunks && holds_tile(vbox[min(c, nchunks - 1u)]);
+        const u64 hb = __ballot(in);
+        if (lane == 0) sh.chit[wave][s0 >> 6] = hb;
+        if (s0 + lane < CW) wbal[s0 + lane] = 0ull;
     }
+    __syncthreads();
+    // how many chunks hold the tile (the same number in every wave): Gaussians in no particular id order -- a caller's own point
+    // cloud -- put the tile into most boxes, and then every wave simply reads its own share, 32 chunks in flight
+    u32 total_hits = lane < SMALL_WAVES * (SMALL_STEPS / 64u) && (lane % (SMALL_STEPS / 64u)) * 64u < CW ? (u32)__popcll(sh.chit[lane / (SMALL_STEPS / 64u)][lane % (SMALL_STEPS / 64u)]) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total_hits += (u32)__shfl_xor((int)total_hits, o, 64);
+    if (total_hits * 4u > nchunks) {
+        constexpr int UN = 32;
+        const u32 g1 = min(P, g0 + Pq);
+        u32 st = 0;
+        for (u32 base = g0; base < g1; base += 64u * UN, st += UN) {
+            uint2 r[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++)        // (unconditional loads from a clamped index: a guarded load is a branch + a full wait each)
+                r[u] = vrect[min(base + 64u * u + lane, P - 1u)];
+            u32 keep_lo = 0, keep_hi = 0;
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const u64 bal = __ballot(holds_tile(r[u]) && base + 64u * u + lane < g1);
+                if (lane == (u32)u) { keep_lo = (u32)bal; keep_hi = (u32)(bal >> 32); }
+            }
+            if (lane < (u32)UN) wbal[st + lane] = ((u64)keep_hi << 32) | keep_lo;
+        }
+    } else {
+        // hit chunk number k (in id order) is read by wave k % SMALL_WAVES, UNB chunks in flight
+        constexpr int UNB = 16;
+        u32 pend[UNB];
+        int np = 0;
+        u32 k = 0;
+        auto flush = [&]() {
+            uint2 r[UNB];
+#pragma unroll
+            for (int u = 0; u < UNB; u++)
+                if (u < np) r[u] = vrect[min(pend[u] * 64u + lane, P - 1u)];
+#pragma unroll
+            for (int u = 0; u < UNB; u++)
+                if (u < np) {
+                    const bool in = holds_tile(r[u]) && pend[u] * 64u + lane < P;
+                    const u64 bal = __ballot(in);
+                    if (lane == 0) wbal_all[(pend[u] / CW) * SMALL_STEPS + pend[u] % CW] = bal;
+                }
+            np = 0;
+        };
+        const u32 words = (CW + 63u) / 64u;
+        for (u32 ww = 0; ww < SMALL_WAVES; ww++)
+            for (u32 wd = 0; wd < words; wd++) {
+                u64 hb = sh.chit[ww][wd];
+                while (hb != 0ull) {
+                    const u32 bit = (u32)__builtin_ctzll(hb);
+                    hb &= hb - 1ull;
+                    if ((k++ & (SMALL_WAVES - 1u)) == wave) {
+                        pend[np++] = ww * CW + wd * 64u + bit;
+                        if (np == UNB) flush();
+                    }
+                }
+            }
+        if (np != 0) flush();
+    }
+    __syncthreads();
+    u32 nw = 0;                                 // hits of this wave's share (wave-uniform)
+    for (u32 s0 = 0; s0 < CW; s0 += 64u)
+        nw += s0 + lane < CW ? (u32)__popcll(wbal[s0 + lane]) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nw += (u32)__shfl_xor((int)nw, o, 64);
     if (lane == 0) sh.wave_n[wave] = nw;
     __syncthreads();
     u32 n = 0, off = 0;
@@ -132,6 +200,7 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
         }
     }
     __syncthreads();
+    if (debug_stop == 4) return;
     // depth key and quadrant mask of every hit (dense: at most four per thread), the key range of the list
     u32 kmin = 0xFFFFFFFFu, kmax = 0u;
     u32 mykey[F3DG_SMALL_CAP / SMALL_THREADS];
@@ -177,6 +246,7 @@ small_bin_kernel(u32 P, u32 T, u32 grid_x, F3dgHeader* __restrict__ hdr, const u
         if (i < n) k1[i] = mykey[j] - kmin;
     }
     __syncthreads();
+    if (debug_stop == 5) return;
     const u32 span = kmax - kmin;
     const int key_bits = debug_stop == 3 ? 0 : span == 0u ? 0 : 32 - __builtin_clz(span);
 
@@ -283,7 +353,7 @@ int f3dg_launch_small_bin(hipStream_t s, int V, int P, int W, int H, const F3dgL
     const u32 grid_x = (u32)((W + F3DG_TILE - 1) / F3DG_TILE);
     const u32 T = grid_x * (u32)((H + F3DG_TILE - 1) / F3DG_TILE);
     F3DG_KLAUNCH(small_bin_kernel, dim3((u32)V * T), dim3(SMALL_THREADS), 0, s, (u32)P, T, grid_x, reinterpret_cast<F3dgHeader*>(ws + L.header),
-                 reinterpret_cast<const uint2*>(ws + L.rects), reinterpret_cast<const u32*>(ws + L.gsort),
+                 reinterpret_cast<const uint2*>(ws + L.rects), reinterpret_cast<const uint2*>(ws + L.small_boxes), reinterpret_cast<const u32*>(ws + L.gsort),
                  reinterpret_cast<u32*>(ws + L.small_list), reinterpret_cast<u32*>(ws + L.small_cnt), reinterpret_cast<uint2*>(ws + L.ranges),
                  g_f3dg_small_debug);
     F3DG_HIP_CHECK(hipGetLastError());
