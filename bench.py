@@ -674,6 +674,8 @@ def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
         f3d.flush()
         torch.cuda.synchronize()
     e_def = timed(step_device, sync_flush, args.warmup, args.steps)
+    f3d.set_deferred_status(True, depth=2)      # call k checked when call k + 2 arrives: the host runs a whole call ahead of the device
+    e_def2 = timed(step_device, sync_flush, args.warmup, args.steps)
     f3d.set_deferred_status(False)
     timed(step_device, sync, args.warmup, 0)
     L.f3dg_profile_enable(1)
@@ -694,6 +696,7 @@ def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * e_dev / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "value_deferred_status": n / e_def,
+        "value_deferred_status_depth2": n / e_def2,
         "gaussian_order": "pixel-ordered (id = y * res + x, as the predictor emits them)" if pixel else "random ids",
         "config": {"workload": "drop-in: render_predicted_more_v2_gof one view per call (the reference's loop, visualize.py:387-416), %d Gaussians "
                                "(sigma0=%g), %d calls per step @%dx%d, frames left on the device" % (P, args.sigma0, V, RES, RES),

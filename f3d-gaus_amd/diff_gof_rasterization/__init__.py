@@ -266,12 +266,17 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
 # call it belongs to with a grown workspace INTO THE SAME output tensors (and re-runs whatever the wrapper derived from them), and
 # warns: anything the caller enqueued on those outputs in between read an incomplete frame. The first call of a shape -- no capacity
 # is known for it yet -- is always checked at once. Default: off (the reference's blocking contract).
-_DEFERRED = {"on": False}
-_PENDING = {}       # (device index, stream) -> {"ticket": int, "ws": Workspace, "redo": [callables], "shape": key of _CAP_HINT}
+_DEFERRED = {"on": False, "depth": 1}
+_PENDING = {}       # (device index, stream) -> [oldest .. newest] of {"ticket": int, "ws": Workspace, "redo": [callables], "shape": key of _CAP_HINT}
 
 
-def set_deferred_status(on=True):
+def set_deferred_status(on=True, depth=1):
     """Opt in / out of the deferred status check of no-grad single-view calls (see the comment above). Turning it off flushes.
+
+    ``depth``: how many calls may be unchecked on a stream. 1 (default): call k is checked when call k + 1 arrives -- the host then waits
+    for call k's kernels before it issues the next call's, and the device idles for the ~25 us that takes. 2: call k is checked when
+    call k + 2 arrives; the host runs a whole call ahead and the device never waits for it (one-view loop at 65,536 Gaussians: 7.4 k -> 8.9 k
+    views/s, `profiles/r05_final/one_view.md`). The caveats below then hold for two calls instead of one.
 
     Caveats of the opt-in mode, both about what happens between a call and the moment its status is looked at (the next call on the
     stream, or `flush()`): (1) consumers of the call's OUTPUTS enqueued in between read an incomplete frame if the call overflowed
@@ -282,16 +287,23 @@ def set_deferred_status(on=True):
     if not on:
         flush()
     _DEFERRED["on"] = bool(on)
+    _DEFERRED["depth"] = max(1, int(depth))
 
 
 def deferred_status():
     return _DEFERRED["on"]
 
 
-def _resolve(key):
-    p = _PENDING.pop(key, None)
-    if p is None:
-        return
+def _resolve(key, keep=0):
+    """Checks the oldest unchecked calls of the stream until at most ``keep`` are left."""
+    q = _PENDING.get(key)
+    while q and len(q) > keep:
+        _resolve_one(q.pop(0))
+    if q is not None and not q:
+        del _PENDING[key]
+
+
+def _resolve_one(p):
     n = C.c_longlong(0)
     rc = _lib.lib().f3dg_status_poll(p["ticket"], 1, C.byref(n))
     if rc == _lib.ERR_OVERFLOW:
@@ -320,9 +332,9 @@ def add_redo(fn):
     """(wrapper-internal) work derived from the outputs of the call just issued on the current stream, to be repeated if that call
     turns out to have overflowed."""
     dev = torch.cuda.current_device()
-    p = _PENDING.get((dev, _raw_stream(dev)))
-    if p is not None:
-        p["redo"].append(fn)
+    q = _PENDING.get((dev, _raw_stream(dev)))
+    if q:
+        q[-1]["redo"].append(fn)
 
 
 def read_status(workspace):
@@ -356,7 +368,7 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
     shape_key = (means3D.size(0), int(rs.image_width), int(rs.image_height), 1)
     deferred = _DEFERRED["on"] and not needs_grad and not rs.debug and device.type == "cuda"
     if deferred:
-        _resolve(key)                                  # the previous call on this stream: its status has landed long ago
+        _resolve(key, keep=_DEFERRED["depth"] - 1)      # the call `depth` calls back on this stream: its status has landed long ago
         deferred = shape_key in _CAP_HINT             # no capacity known yet: check this one at once
 
     def call(check=True, out=None, radii=None, workspace=ws, max_rendered=None):
@@ -391,7 +403,7 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
         def redo(color=color, radii=radii):
             _, _, ws2 = call(check=True, out=color, radii=radii, workspace=None)
             _WS_CACHE[key] = ws2
-        _PENDING[key] = {"ticket": ticket, "ws": ws, "redo": [redo], "shape": shape_key}
+        _PENDING.setdefault(key, []).append({"ticket": ticket, "ws": ws, "redo": [redo], "shape": shape_key})
     else:
         color, radii, ws = call()
     if not needs_grad:

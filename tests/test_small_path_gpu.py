@@ -107,11 +107,13 @@ def _pc(scene, device):
             "features_dc": shs[None, :, :1].contiguous(), "features_rest": shs[None, :, 1:].contiguous()}
 
 
-def test_deferred_status_same_frames_and_late_overflow_is_repaired(gpu_device):
+@pytest.mark.parametrize("depth", [1, 2])
+def test_deferred_status_same_frames_and_late_overflow_is_repaired(depth, gpu_device):
     """`set_deferred_status(True)`: the status of a drop-in call is checked when the next call arrives on the stream (or at `flush()`)
     instead of blocking. Same frames as the blocking contract; an overflow found late -- here a call that needs 6x the instances of
     the one that sized the workspace, on the small-call path AND beyond a tile's slot -- re-issues the call into the same output
-    tensors (and the derived normal maps), with a warning."""
+    tensors (and the derived normal maps), with a warning. depth = 2: a call is checked when the second call after it arrives; two
+    overflowing calls in flight are both repaired."""
     import warnings
     from f3dgaus_amd import cameras
     from f3dgaus_amd import diff_gof_rasterization as dgr
@@ -129,17 +131,22 @@ def test_deferred_status_same_frames_and_late_overflow_is_repaired(gpu_device):
         dgr._CAP_HINT.clear()
         dgr._WS_CACHE.clear()
         L.f3dg_set_option(b"small_path", 2)
-        f3d.set_deferred_status(True)
+        f3d.set_deferred_status(True, depth=depth)
+        b2 = None
         try:
             a0 = f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small))      # first call of the shape: checked at once
             a1 = f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small))      # deferred
-            assert len(dgr._PENDING) == 1
+            assert len(dgr._PENDING) == 1 and sum(len(q) for q in dgr._PENDING.values()) == 1
             with warnings.catch_warnings(record=True) as w:
                 warnings.simplefilter("always")
-                b = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))       # resolves a1 (fine), overflows itself -- unnoticed so far
+                b = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))       # resolves a1 (depth 1; fine), overflows itself -- unnoticed so far
                 assert not w
+                if depth == 2:
+                    assert sum(len(q) for q in dgr._PENDING.values()) == 2
+                    b2 = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))  # resolves a1; a second overflowing call behind the first
+                    assert not w
                 f3d.flush()                                                             # ... until here: re-issued in place
-                assert len(w) == 1 and "re-issued" in str(w[0].message)
+                assert len(w) == (2 if depth == 2 else 1) and all("re-issued" in str(m.message) for m in w)
             assert not dgr._PENDING
             c = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))           # the grown hint: no overflow any more
             with warnings.catch_warnings(record=True) as w:
@@ -149,6 +156,6 @@ def test_deferred_status_same_frames_and_late_overflow_is_repaired(gpu_device):
         finally:
             f3d.set_deferred_status(False)
             L.f3dg_set_option(b"small_path", 2)
-    for got, want in ((a0, want_small), (a1, want_small), (b, want_big), (c, want_big)):
+    for got, want in ((a0, want_small), (a1, want_small), (b, want_big), (c, want_big)) + (((b2, want_big),) if b2 is not None else ()):
         for k in keys:
             assert torch.equal(got[k], want[k]), k
