@@ -628,9 +628,14 @@ def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
     cfg = cameras.default_cfg(RES)
     # the predictor's Gaussians are PIXEL-ORDERED (id = y * res + x on the input image's depth map): that is what these loops feed
     # the rasterizer, and the id order matters to the small-call path (a wave's share of the ids is a band of image rows)
-    pixel = P == RES * RES and not os.environ.get("F3DG_DROPIN_RANDOM_IDS")
-    g = synthetic.make_pixel_gaussians(RES, s0=args.sigma0, seed=rank, device=device) if pixel else \
-        synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)
+    # (a multiple of res^2: a MERGED set -- visualize.py:387-416 renders the orbit from the nine predicted sets of the cycle, 589,824
+    # Gaussians --: that many pixel-ordered blocks one after the other)
+    pixel = P % (RES * RES) == 0 and not os.environ.get("F3DG_DROPIN_RANDOM_IDS")
+    if pixel:
+        blocks = [synthetic.make_pixel_gaussians(RES, s0=args.sigma0, seed=rank + 17 * b, device=device) for b in range(P // (RES * RES))]
+        g = {k: torch.cat([b[k] for b in blocks], 0).contiguous() for k in blocks[0]}
+    else:
+        g = synthetic.make_gaussians(P, s0=args.sigma0, seed=rank, device=device)
     pc = {"xyz": g["xyz"][None], "opacity": g["opacity"][None], "scaling": g["scaling"][None], "rotation": g["rotation"][None],
           "features_dc": g["features_dc"][None], "features_rest": g["features_rest"][None]}
     cams = synthetic.orbit_cameras(V, resolution=RES, device=device)
@@ -697,7 +702,7 @@ def run_dropin(args, rank, world, dist, device, comm_device, f3d, L):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "value_deferred_status": n / e_def,
         "value_deferred_status_depth2": n / e_def2,
-        "gaussian_order": "pixel-ordered (id = y * res + x, as the predictor emits them)" if pixel else "random ids",
+        "gaussian_order": ("pixel-ordered (id = y * res + x, as the predictor emits them)" + (", %d blocks (a merged set)" % (P // (RES * RES)) if P > RES * RES else "")) if pixel else "random ids",
         "config": {"workload": "drop-in: render_predicted_more_v2_gof one view per call (the reference's loop, visualize.py:387-416), %d Gaussians "
                                "(sigma0=%g), %d calls per step @%dx%d, frames left on the device" % (P, args.sigma0, V, RES, RES),
                    "gaussians": P, "views": V, "resolution": RES, "kernel_launches_per_call": launches / float(calls)},

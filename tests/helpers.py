@@ -17,8 +17,9 @@ def make_scene(P, res=(64, 64), s0=0.05, seed=0, view="canonical", n_views=1, sh
                kernel_size=0.0, scale_modifier=1.0, behind_fraction=0.0, bg=(0.0, 0.0, 0.0), aniso=False, depth_range=None, pixel_ordered=False):
     W, H = res
     if pixel_ordered:       # one Gaussian per pixel of a res x res input image, id = y * res + x (what the predictor hands the rasterizer)
-        assert P == W * H and W == H
-        g = synthetic.make_pixel_gaussians(W, s0=s0, seed=seed, sh_rest=max(3, (sh_degree + 1) ** 2 - 1))
+        assert P % (W * H) == 0 and W == H          # (a multiple: that many blocks one after the other, as a merged set of several images)
+        blocks = [synthetic.make_pixel_gaussians(W, s0=s0, seed=seed + 17 * b, sh_rest=max(3, (sh_degree + 1) ** 2 - 1)) for b in range(P // (W * H))]
+        g = {k: torch.cat([b[k] for b in blocks], 0).contiguous() for k in blocks[0]}
     else:
         g = synthetic.make_gaussians(P, s0=s0, seed=seed, behind_fraction=behind_fraction, sh_rest=max(3, (sh_degree + 1) ** 2 - 1))
     if depth_range is not None:   # spread the Gaussians over view-space depths z0..z1 (log-uniform), keeping their image positions:
