@@ -49,7 +49,15 @@ for label, f in rows:
         st["compositing"], rf["frac"], ("%.2f; `%s`" % (rx["ms_per_launch"], rx["kernel"].split("<")[0])) if rx else ""))
 j = lj(os.path.join(src, "bench_dropin.log"))
 if j:
-    out += ["", "Drop-in loop (one view per call, 65,536 pixel-ordered Gaussians): %.0f views/s, %.0f with `set_deferred_status`." % (j["value"], j.get("value_deferred_status", 0))]
+    u = j.get("us_per_call", {})
+    st = [v for k, v in u.items() if isinstance(v, dict)]
+    out += ["", "Drop-in loop (one view per call, 65,536 pixel-ordered Gaussians): %.0f views/s, %.0f with `set_deferred_status(True)`, %.0f with `depth=2`; kernels per call %s us." % (
+        j["value"], j.get("value_deferred_status", 0), j.get("value_deferred_status_depth2", 0), json.dumps({k: round(v, 1) for k, v in st[0].items()}) if st else "?")]
+    jx = lj(os.path.join(src, "bench_dropin_exact.log"))
+    if jx:
+        stx = [v for k, v in jx.get("us_per_call", {}).items() if isinstance(v, dict)]
+        out += ["The same in the reference's arithmetic: %.0f / %.0f / %.0f views/s; kernels per call %s us." % (
+            jx["value"], jx.get("value_deferred_status", 0), jx.get("value_deferred_status_depth2", 0), json.dumps({k: round(v, 1) for k, v in stx[0].items()}) if stx else "?")]
 j = lj(os.path.join(src, "bench_c5.log"))
 if j:
     out += ["", "C5 (1 M Gaussians, 32 views @512^2, forward + backward): %.0f views/s, %.2f ms/step; stages %s." % (j["value"], j["ms_per_step"], json.dumps({k: round(v, 2) for k, v in j.get("stage_ms_per_step", {}).items()}))]
@@ -67,7 +75,7 @@ if os.path.exists(log):
 open(os.path.join(dst, "summary.md"), "w").write("\n".join(out) + "\n")
 for f in glob.glob(os.path.join(src, "stats", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "bench_kernel_stats.csv"))
-for f in ("parity_report.md", "unet_determinism.log", "unet_first_use.log"):
+for f in ("parity_report.md", "unet_determinism.log", "unet_first_use.log", "issue_rate.log", "r3q_clocks.log"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f.replace(".log", ".md")))
 

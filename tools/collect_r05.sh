@@ -15,6 +15,9 @@ F3DG_RENDER_PACK=0 $T python bench.py --data real --no-cpu-baseline > $O/bench_r
 $T python bench.py --sigma0 0.05 --no-cpu-baseline > $O/bench_sigma005.log 2>&1
 $T python bench.py --gaussians 589824 --views 128 --no-cpu-baseline > $O/bench_589k.log 2>&1
 $T python bench.py --workload dropin --views 60 > $O/bench_dropin.log 2>&1
+$T python bench.py --workload dropin --views 60 --render-mode exact > $O/bench_dropin_exact.log 2>&1
+[ -x tools/micro/issue_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/issue_rate.hip -o tools/micro/issue_rate > /dev/null 2>&1; timeout 60 tools/micro/issue_rate > $O/issue_rate.log 2>&1
+( for a in "2" "3" "2 exact" "3 exact"; do echo "== render_split $a"; timeout 120 python tools/r3q_clocks.py $a 2>&1 | grep -v amdgpu.ids; done ) > $O/r3q_clocks.log 2>&1
 $T python bench.py --workload c5 --steps 3 --warmup 1 > $O/bench_c5.log 2>&1
 $T python bench.py --workload c4 --images 16 --steps 2 --warmup 1 > $O/bench_c4_fp32.log 2>&1
 $T python bench.py --workload c4 --images 16 --steps 2 --warmup 1 --backbone-chunk 0 > $O/bench_c4_fp32_chunk0.log 2>&1

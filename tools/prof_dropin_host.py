@@ -25,7 +25,7 @@ wv, fp, cc = (cams[k].unsqueeze(1) for k in ("viewmatrix", "projmatrix", "campos
 wvs, fps, ccs = ([t[i:i + 1].contiguous() for i in range(V)] for t in (wv, fp, cc))
 bg = torch.zeros(1, 3, device=dev)
 frames = torch.empty((V, 3, RES, RES), dtype=torch.float32, device=dev)
-f3d.set_deferred_status(True)
+f3d.set_deferred_status(True, depth=2)
 
 
 def loop(n):

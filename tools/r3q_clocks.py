@@ -35,6 +35,6 @@ print(L.f3dg_debug_last_render_kernel().decode())
 for r, name in enumerate(("consumer", "evaluators", "producer")):
     tot, bar, spin, win, rnd, waves = (h[16 * r + k] for k in range(6))
     if waves:
-        print("%-10s per wave: %8.0f clocks, %5.1f %% at the window barrier, %5.1f %% waiting for a counter; %.1f windows, %.1f rounds" % (
+        print("%-10s per wave: %8.0f clocks, %5.1f %% waiting for a window, %5.1f %% waiting for a counter; %.1f windows, %.1f rounds" % (
             name, tot / waves, 100.0 * bar / tot, 100.0 * spin / tot, win / waves, rnd / waves))
 print("longest wave of any workgroup: consumer %d, evaluator %d, producer %d clocks" % (h[48], h[49], h[50]))
