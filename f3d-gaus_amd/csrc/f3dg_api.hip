@@ -89,6 +89,7 @@ void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s)
 }
 
 int g_f3dg_small_path = 1;
+int g_f3dg_small_path_aux = 1;       // forwards that keep the auxiliary planes (a backward follows) may take the small-call path too
 int g_f3dg_small_debug = 0;
 namespace {
 // shapes (P, n_views, W, H) whose small-call path overflowed a tile list: they take the general path from then on
@@ -147,6 +148,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) { std::lock_guard<std::mutex> lock(g_small_mutex); g_small_disabled.clear(); } return F3DG_OK; }
+    if (name && strcmp(name, "small_path_aux") == 0) { g_f3dg_small_path_aux = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "small_debug") == 0) { g_f3dg_small_debug = value; return F3DG_OK; }
     if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = (value >= 2 && value <= 6) ? value : 5; return F3DG_OK; }
@@ -423,7 +425,7 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
     // what this call runs with: the process-wide defaults of f3dg_set_option, overridden by the call's own flags
     const int fast = (flags & F3DG_FLAG_EXACT) ? 0 : (flags & F3DG_FLAG_FAST) ? 1 : f3dg_render_uses_fast(save_aux);
     const int tile_cull = (flags & F3DG_FLAG_NO_TILE_CULL) ? 0 : g_f3dg_tile_cull;
-    const int small = g_f3dg_small_path && !(flags & F3DG_FLAG_NO_SMALL_PATH) && !save_aux && n_sets == 1 && P > 0 && L.small_cap != 0 &&
+    const int small = g_f3dg_small_path && !(flags & F3DG_FLAG_NO_SMALL_PATH) && (!save_aux || g_f3dg_small_path_aux) && n_sets == 1 && P > 0 && L.small_cap != 0 &&
                       g_f3dg_render_kernel == 3 && !small_disabled((unsigned)P, (unsigned)n_views, (unsigned)W, (unsigned)H);
     // (the header is initialised by the first workgroup of the projection kernel; without Gaussians there is no such launch)
     const F3dgHeaderInit hinit = { hdr, (unsigned)max_rendered, (unsigned)fast, (unsigned)save_aux, (unsigned)small,
@@ -747,6 +749,8 @@ extern "C" int f3dg_debug_export(void* stream, const void* workspace, int P, int
     if (h.small_path) {
         // the small-call path keeps its lists in per-tile slots: hand them out in the general path's layout (gap-free, (view, tile) order)
         if (h.overflow) return F3DG_ERR_OVERFLOW;
+        // (no instance offsets and no 64-bit keys on that path: a caller that inspects them renders with F3DG_FLAG_NO_SMALL_PATH)
+        if (offsets || keys_sorted) return F3DG_ERR_STATE;
         const int rcs = f3dg_launch_small_export(s, n_views, W, H, L, ws, point_list, ranges);
         if (rcs != F3DG_OK) return rcs;
         point_list = nullptr;

@@ -134,7 +134,7 @@ __device__ __forceinline__ double row_total(double v)
 __global__ void __launch_bounds__(F3DG_BLOCK)
 render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
-                  const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                  const unsigned* __restrict__ point_list_general, const unsigned* __restrict__ small_list, const F3dgRec* __restrict__ rec,
                   const float2* __restrict__ means2D, const float4* __restrict__ conic,
                   const float* __restrict__ background, int bg_per_view,
                   const float* __restrict__ final_T, const unsigned* __restrict__ n_contrib,
@@ -157,8 +157,10 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
 
     uint2 range = ranges[(size_t)view * T + tile];
     // no lists to walk after an overflow -- and none that belong to this call when the workspace's last forward kept no auxiliary
-    // planes (an inference call) or took the small-call path (its lists are elsewhere): all gradients stay zero, the header says why
-    if (hdr->overflow || hdr->save_aux == 0u || hdr->small_path != 0u) {
+    // planes (an inference call): all gradients stay zero, the header says why
+    // (a one-view forward with auxiliary planes may have taken the small-call path: its lists live in the per-tile slots)
+    const unsigned* __restrict__ point_list = hdr->small_path != 0u ? small_list : point_list_general;
+    if (hdr->overflow || hdr->save_aux == 0u) {
         range = make_uint2(0, 0);
         if (!hdr->overflow && blockIdx.x == 0 && threadIdx.x == 0) const_cast<F3dgHeader*>(hdr)->bwd_stale = 1u;
     }
@@ -393,7 +395,7 @@ render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float
 __global__ void __launch_bounds__(F3DG_BLOCK, F3DG_BWD_OCC)
 render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
-                  const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                  const unsigned* __restrict__ point_list_general, const unsigned* __restrict__ small_list, const F3dgRec* __restrict__ rec,
                   const float4* __restrict__ bbox,
                   const float2* __restrict__ means2D, const float4* __restrict__ conic,
                   const float* __restrict__ background, int bg_per_view,
@@ -418,8 +420,10 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 
     uint2 range = ranges[(size_t)view * T + tile];
     // no lists to walk after an overflow -- and none that belong to this call when the workspace's last forward kept no auxiliary
-    // planes (an inference call) or took the small-call path (its lists are elsewhere): all gradients stay zero, the header says why
-    if (hdr->overflow || hdr->save_aux == 0u || hdr->small_path != 0u) {
+    // planes (an inference call): all gradients stay zero, the header says why
+    // (a one-view forward with auxiliary planes may have taken the small-call path: its lists live in the per-tile slots)
+    const unsigned* __restrict__ point_list = hdr->small_path != 0u ? small_list : point_list_general;
+    if (hdr->overflow || hdr->save_aux == 0u) {
         range = make_uint2(0, 0);
         if (!hdr->overflow && blockIdx.x == 0 && threadIdx.x == 0) const_cast<F3dgHeader*>(hdr)->bwd_stale = 1u;
     }
@@ -711,7 +715,7 @@ template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                    F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
-                   const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
+                   const unsigned* __restrict__ point_list_general, const unsigned* __restrict__ small_list, const F3dgRec* __restrict__ rec,
                    const float4* __restrict__ cull,
                    const float2* __restrict__ means2D, const float4* __restrict__ conic,
                    const float* __restrict__ background, int bg_per_view,
@@ -736,8 +740,10 @@ render3_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 
     uint2 range = ranges[(size_t)view * T + tile];
     // no lists to walk after an overflow -- and none that belong to this call when the workspace's last forward kept no auxiliary
-    // planes (an inference call) or took the small-call path (its lists are elsewhere): all gradients stay zero, the header says why
-    if (hdr->overflow || hdr->save_aux == 0u || hdr->small_path != 0u) {
+    // planes (an inference call): all gradients stay zero, the header says why
+    // (a one-view forward with auxiliary planes may have taken the small-call path: its lists live in the per-tile slots)
+    const unsigned* __restrict__ point_list = hdr->small_path != 0u ? small_list : point_list_general;
+    if (hdr->overflow || hdr->save_aux == 0u) {
         range = make_uint2(0, 0);
         if (!hdr->overflow && blockIdx.x == 0 && threadIdx.x == 0) const_cast<F3dgHeader*>(hdr)->bwd_stale = 1u;
     }
@@ -1369,7 +1375,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     if (g_f3dg_render_cull && g_f3dg_render_kernel == 3) {
 #define F3DG_LAUNCH_BWD3(OCC) F3DG_KLAUNCH((render3_bwd_kernel<OCC>), dim3((unsigned)n_views * (unsigned)T * 4u), dim3(64), 0, s, n_views, P, W, H,  \
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),                                        \
-                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),                        \
+                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const unsigned*>(ws + L.small_list), reinterpret_cast<const F3dgRec*>(ws + L.rec),                        \
                            reinterpret_cast<const float4*>(ws + L.cull),                                                                            \
                            reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),                         \
                            background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),                    \
@@ -1380,7 +1386,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     } else if (g_f3dg_render_cull)
         F3DG_KLAUNCH(render_bwd_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
-                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
+                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const unsigned*>(ws + L.small_list), reinterpret_cast<const F3dgRec*>(ws + L.rec),
                            reinterpret_cast<const float4*>(ws + L.bbox),
                            reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
                            background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
@@ -1389,7 +1395,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     else     // option render_cull = 0: the lock-step kernel (every lane visits every entry, wave butterflies), kept for A/B
         F3DG_KLAUNCH(render_bwd_lockstep_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
-                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const F3dgRec*>(ws + L.rec),
+                           reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const unsigned*>(ws + L.small_list), reinterpret_cast<const F3dgRec*>(ws + L.rec),
                            reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic),
                            background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
                            reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,

@@ -18,7 +18,8 @@
 //
 // A slot holds F3DG_SMALL_CAP entries -- the limit is the tile's total, however its hits are spread over the waves (round 3 gave each
 // wave a sixteenth of the slot, which pixel-ordered predicted Gaussians overflow: all hits of a tile come from the one or two waves
-// that scan its image rows); a longer list sets the overflow flags and the caller re-runs the call on the general path (f3dg_read_status remembers the shape). Inference calls only (no auxiliary planes).
+// that scan its image rows); a longer list sets the overflow flags and the caller re-runs the call on the general path (f3dg_read_status remembers the shape).
+// Forwards with auxiliary planes take it too (round 5, option small_path_aux): f3dg_backward reads the header and walks the slots.
 #include "f3dg_common.h"
 
 namespace {

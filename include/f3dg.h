@@ -370,8 +370,10 @@ int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const u
  * "render_dma" (default 1): render3 stages records by global_load_lds_dwordx4 (1) or through registers (0); "render_lds_pad"
  * (default 0): extra dynamic LDS bytes per render3 workgroup (occupancy experiments).
  * "bwd_occ" (default 5): waves per SIMD the compositing backward (render3_bwd_kernel) is compiled for (2..6).
- * "small_path" (default 1): inference calls of one or two views of at most 2^18 Gaussians on at most 1,024 tiles take the three-launch
- * path of f3dg_small.hip (2 = on, and forget the shapes an earlier overflow disabled); "small_debug", "time_launches": diagnostics.
+ * "small_path" (default 1): calls of one or two views of at most 2^18 Gaussians on at most 1,024 tiles take the three-launch
+ * path of f3dg_small.hip (2 = on, and forget the shapes an earlier overflow disabled); "small_path_aux" (default 1): forwards with
+ * F3DG_FLAG_SAVE_AUX too -- f3dg_backward then walks the per-tile slots (0: only inference calls, as in round 4);
+ * "small_debug", "time_launches": diagnostics.
  * The render_kernel value also selects the per-pixel pass of f3dg_integrate: 3 = shared rays (integrate_pass1_rays_kernel), 2 = one
  * pixel per lane with the culled lists, 1 = round 1's per-ray pre-test; all bit-identical.
  * "render_round" (default 192): list entries a workgroup of render2 stages per round (192 at 7 waves/SIMD or 256 at 6).

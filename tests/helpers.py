@@ -102,7 +102,7 @@ def _run_hip_reference_lists(scene, device, save_aux, max_rendered, culled):
         tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], sh=dev(scene["shs"]),
         colors_precomp=dev(scene["colors_precomp"]), scales=dev(scene["scales"]), rotations=dev(scene["rotations"]),
         sh_degree=scene["sh_degree"], scale_modifier=scene["scale_modifier"], kernel_size=scene["kernel_size"],
-        save_aux=save_aux, max_rendered=max_rendered, tile_cull=False, exact=_exact_flag())
+        save_aux=save_aux, max_rendered=max_rendered, tile_cull=False, small_path=False, exact=_exact_flag())      # (the general path's internals are exported below)
     V, P, W, H = scene["viewmatrix"].shape[0], scene["P"], scene["W"], scene["H"]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     cap = ws.max_rendered
