@@ -402,7 +402,7 @@ def test_small_launch_unrolled_trips_bit_identical(name, gpu_device):
     res = {}
     try:
         L.f3dg_set_option(b"render_split", 0)
-        for U in (1, 2, 3, 4):
+        for U in (1, 2):
             assert L.f3dg_set_option(b"render_unroll", U) == 0
             for aux in (False, True):
                 res[U, aux] = run_hip(scene, gpu_device, save_aux=aux)
@@ -436,13 +436,13 @@ def test_small_launch_unrolled_trips_bit_identical(name, gpu_device):
         assert np.array_equal(res[1, False]["out_color"].view(np.uint32), res["split", U, False]["out_color"].view(np.uint32)), ("split", U)
         for k in ("out_color", "final_T", "n_contrib"):
             assert np.array_equal(res[1, True][k].view(np.uint32), res["split", U, True][k].view(np.uint32)), ("split", U, k)
-    for U in (2, 3, 4):
+    for U in (2,):
         assert np.array_equal(res[1, False]["out_color"].view(np.uint32), res[U, False]["out_color"].view(np.uint32)), U
         for k in ("out_color", "final_T", "n_contrib"):
             assert np.array_equal(res[1, True][k].view(np.uint32), res[U, True][k].view(np.uint32)), (U, k)
     for v in range(V):
         o = run_oracle(scene, view=v)
-        assert_render_parity(res[4, False]["out_color"][v], o["out_color"], "unrolled %s view %d" % (name, v))
+        assert_render_parity(res[2, False]["out_color"][v], o["out_color"], "unrolled %s view %d" % (name, v))
 
 
 @pytest.mark.parametrize("tail", [64, 16, 3])

@@ -1,5 +1,6 @@
 #!/bin/bash
-# forwards with auxiliary planes on the small-call path: gradient tests, the one-view forward + backward step
-cd /root/repo; export TMPDIR=/tmp; ulimit -c 0; O=gpurun_out/r05p; mkdir -p $O; rm -rf $O/*
-timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-timeout 200 python tools/bench_one_view_train.py 2>&1 | grep -v amdgpu.ids > $O/train1.log; cat $O/train1.log
+# final check of the round: build from scratch, smoke, the whole GPU suite, the default bench line
+cd /root/repo; export TMPDIR=/tmp; ulimit -c 0; O=gpurun_out/r05_last; mkdir -p $O; rm -rf $O/*
+timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+( time timeout 1200 python -m pytest tests -m gpu -q --durations=5 ) > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
+timeout 400 python bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log | tail -1 | cut -c1-400
