@@ -25,6 +25,8 @@ dpix[:, 7] = 0
 kw = dict(image_height=RES, image_width=RES, tanfovx=cams["tanfovx"], tanfovy=cams["tanfovy"], sh=shs, scales=g["scaling"], rotations=g["rotation"],
           sh_degree=1, save_aux=True)
 L = _lib.lib()
+for item in filter(None, os.environ.get("F3DG_OPTIONS", "").split(",")):
+    _lib.check(L.f3dg_set_option(item.split("=")[0].strip().encode(), int(item.split("=")[1])), "f3dg_set_option")
 for aux_small in (0, 1):
     L.f3dg_set_option(b"small_path", 2)
     L.f3dg_set_option(b"small_path_aux", aux_small)
