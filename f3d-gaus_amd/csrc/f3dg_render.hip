@@ -1433,9 +1433,10 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
             // one view (at most one quadrant per SIMD): the multi-wave kernels of f3dg_render4.hip. Defaults by measurement at 65,536 pixel-ordered
             // Gaussians (profiles/r05_final/one_view.md): fast arithmetic -- producer + consumer waves, two entries per trip (render3p, 76.6 ->
             // 57.9 us); the reference's arithmetic -- consumer + three evaluator waves + producer (render3q, 134 -> 100 us)
+            // (two views, 2,048 quadrants: render3p as well in fast arithmetic -- 79.7 -> 63.6 us per call; render3q's LDS would not fit)
             const bool one_view = (long long)V * T * 4 <= 1024ll;
-            const int split = g_f3dg_render_split >= 0 ? g_f3dg_render_split : !one_view ? 0 : g_f3dg_render_fast ? 1 : 3;
-            const int unroll = g_f3dg_render_unroll >= 1 ? g_f3dg_render_unroll : (one_view && g_f3dg_render_fast) ? 2 : 1;
+            const int split = g_f3dg_render_split >= 0 ? g_f3dg_render_split : g_f3dg_render_fast ? 1 : one_view ? 3 : 0;
+            const int unroll = g_f3dg_render_unroll >= 1 ? g_f3dg_render_unroll : g_f3dg_render_fast ? 2 : 1;
             if (unroll > 1 || split)
                 return f3dg_launch_render3u(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
                                             g_f3dg_render_fast, save_aux, final_T, n_contrib, unroll, split, g_f3dg_render_count);

@@ -363,7 +363,7 @@ int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const u
  * "render_lowocc" (default 1): launches of at most 2,048 quadrant waves (one or two 256^2 views) take render3l_fwd_kernel, which
  * keeps the next window's gathers in flight behind phase 2; 0 = the general kernel for every launch. Launches of at most 1,024 waves
  * (ONE 256^2 view: every wave alone on its SIMD, its time a chain of latencies) use several waves per quadrant, bit-identical:
- * "render_split" (default -1: 1 in fast arithmetic, 3 in the reference's): 1 = render3p_fwd_kernel, a producer wave scans the list,
+ * "render_split" (default -1: 1 in fast arithmetic -- also for two views --, 3 in the reference's): 1 = render3p_fwd_kernel, a producer wave scans the list,
  * gathers the records and runs phase 1 of the next window while the consumer wave composites; 2 / 3 = render3q_fwd_kernel, consumer +
  * 2 / 3 evaluator waves (the stateless part of every pair, parked in LDS) + producer; 0 = one wave. "render_unroll" (default -1: 2
  * in fast arithmetic on one-view launches, else 1): entries per phase-2 trip of the one- and two-wave kernels (1 or 2; 3 and 4 measured equal to 2).

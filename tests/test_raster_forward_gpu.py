@@ -384,7 +384,7 @@ def test_packed_schedule_bit_identical(name, gpu_device):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
 
 
-@pytest.mark.parametrize("name", ["F2_oblique_aniso", "F5_odd_size", "F6_small_splats", "F9_long_tile_lists", "C1", "thin"])
+@pytest.mark.parametrize("name", ["F2_oblique_aniso", "F5_odd_size", "F6_small_splats", "F9_long_tile_lists", "C1", "thin", "two_views"])
 def test_small_launch_unrolled_trips_bit_identical(name, gpu_device):
     """Launches of at most 2,048 quadrant waves (one or two 256^2 views: the reference's per-view loop) take the latency-chain
     kernels. render3u_fwd_kernel (option render_unroll = U, csrc/f3dg_render4.hip) pops U passing entries per phase-2 trip, evaluates
@@ -392,7 +392,8 @@ def test_small_launch_unrolled_trips_bit_identical(name, gpu_device):
     must be render3l's (U = 1) to the bit, for every U, and meet the oracle."""
     from f3dgaus_amd import _lib
     extra = {"C1": dict(P=65536, res=(256, 256), s0=0.01, view="oblique"),
-             "thin": dict(P=40000, res=(120, 88), s0=0.03, view="oblique", n_views=2, seed=7)}
+             "thin": dict(P=40000, res=(120, 88), s0=0.03, view="oblique", n_views=2, seed=7),
+             "two_views": dict(P=65536, res=(256, 256), s0=0.01, view="oblique", n_views=2, seed=5)}      # 2,048 quadrants
     scene = make_scene(**(SCENES[name] if name in SCENES else extra[name]))
     if name == "thin":
         scene["opacities"] = scene["opacities"] * 0.04        # nothing saturates: every quadrant walks its whole list
@@ -424,10 +425,10 @@ def test_small_launch_unrolled_trips_bit_identical(name, gpu_device):
         L.f3dg_set_option(b"render_unroll", -1)
         L.f3dg_set_option(b"render_split", -1)
         res["split", 0, False] = run_hip(scene, gpu_device, save_aux=False)
-        if V * ((scene["W"] + 15) // 16) * ((scene["H"] + 15) // 16) * 4 <= 1024:
-            import helpers
-            want = b"render3q" if helpers.RENDER_MODE == "exact" else b"render3p" if helpers.RENDER_MODE == "fast" else b"render3"
-            assert want in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
+        import helpers
+        one_view = V * ((scene["W"] + 15) // 16) * ((scene["H"] + 15) // 16) * 4 <= 1024
+        want = b"render3p" if helpers.RENDER_MODE == "fast" else (b"render3q" if one_view else b"render3l") if helpers.RENDER_MODE == "exact" else b"render3"
+        assert want in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
         res["split", 0, True] = run_hip(scene, gpu_device, save_aux=True)
     finally:
         L.f3dg_set_option(b"render_unroll", -1)
