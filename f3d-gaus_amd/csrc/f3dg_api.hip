@@ -155,7 +155,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_split") == 0) { g_f3dg_render_split = value < 0 ? F3DG_RENDER_SPLIT_DEFAULT : value > 3 ? 3 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_unroll") == 0) { g_f3dg_render_unroll = value < 0 ? F3DG_RENDER_UNROLL_DEFAULT : value < 1 ? 1 : value > 2 ? 2 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value < 0 ? 1 : value > 64 ? 64 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_count") == 0) { g_f3dg_render_count = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_tail") == 0) { g_f3dg_render_tail = value < 0 ? F3DG_RENDER_TAIL_DEFAULT : value > 64 ? 64 : value; return F3DG_OK; }

@@ -1429,7 +1429,7 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
 #define F3DG_LAUNCH3(AUX, FST, OCC) do { if (g_f3dg_render_dma) F3DG_LAUNCH3D(AUX, FST, true, OCC); else F3DG_LAUNCH3D(AUX, FST, false, OCC); } while (0)
         // every variant fits 64 VGPRs without spills: 8 waves per SIMD, 32 x 5 KB = the CU's 160 KB of LDS
         // small launches (at most two waves per SIMD: one or two 256^2 views) are latency chains: the prefetching variant
-        if (g_f3dg_render_lowocc && (long long)V * T * 4 <= 2048ll) {
+        if (g_f3dg_render_lowocc && (long long)V * T * 4 <= (g_f3dg_render_lowocc > 1 ? 1024ll * g_f3dg_render_lowocc : 2048ll)) {
             // one view (at most one quadrant per SIMD): the multi-wave kernels of f3dg_render4.hip. Defaults by measurement at 65,536 pixel-ordered
             // Gaussians (profiles/r05_final/one_view.md): fast arithmetic -- producer + consumer waves, two entries per trip (render3p, 76.6 ->
             // 57.9 us); the reference's arithmetic -- consumer + three evaluator waves + producer (render3q, 134 -> 100 us)

@@ -360,7 +360,8 @@ int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const u
  * them with the Gaussians across the lanes and blends with the pixels across the lanes; 2 = render2, four coupled waves per tile
  * with per-4x4-block lists; 1 = the round-1 pixel-lane kernel (its plain variant is the transcription-order baseline of the tests).
  * "render_slide" (default 1): render3 with sliding half-windows (render3s_fwd_kernel) or fixed 64-entry windows (0).
- * "render_lowocc" (default 1): launches of at most 2,048 quadrant waves (one or two 256^2 views) take render3l_fwd_kernel, which
+ * "render_lowocc" (default 1; n > 1: up to n x 1,024 quadrants -- measured: from four views per call on the general kernel wins):
+ * launches of at most 2,048 quadrant waves (one or two 256^2 views) take render3l_fwd_kernel, which
  * keeps the next window's gathers in flight behind phase 2; 0 = the general kernel for every launch. Launches of at most 1,024 waves
  * (ONE 256^2 view: every wave alone on its SIMD, its time a chain of latencies) use several waves per quadrant, bit-identical:
  * "render_split" (default -1: 1 in fast arithmetic -- also for two views --, 3 in the reference's): 1 = render3p_fwd_kernel, a producer wave scans the list,
