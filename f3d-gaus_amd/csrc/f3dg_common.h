@@ -235,8 +235,8 @@ extern int g_f3dg_small_debug;         // timing experiments of small_bin_kernel
 extern int g_f3dg_small_path;          // 1 (default): inference calls of a small shape (f3dg_small_shape) take the three-launch path
 extern int g_f3dg_bwd_occ;             // waves per SIMD render3_bwd_kernel is compiled for: 5 (default: 10.0 ms at C5), 2..4 (10.2-10.4: the kernel is VALU-bound at any of them) or 6 (spills, 12.0)
 extern int g_f3dg_render_lds_pad;      // experiment: extra dynamic LDS bytes per render3 workgroup (lowers the occupancy)
-extern int g_f3dg_render_unroll;       // small launches (render_lowocc): entries per phase-2 trip (render3u / render3p: 2; 1: render3l); -1 = by launch size and arithmetic
-int f3dg_launch_render3u(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+extern int g_f3dg_render_unroll;       // small launches (render_lowocc): entries per phase-2 trip of render3p (1 or 2); -1 = by launch size and arithmetic
+int f3dg_launch_render_small(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
                          const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
                          float* out_color, int fast, int save_aux, float* final_T, unsigned* n_contrib, int unroll, int split, int count);
 extern int g_f3dg_render_split;        // small launches: 1 = two waves per quadrant (render3p_fwd_kernel: a producer wave scans, gathers and runs phase 1 for the window after the one the consumer wave composites)

@@ -1437,8 +1437,8 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
             const bool one_view = (long long)V * T * 4 <= 1024ll;
             const int split = g_f3dg_render_split >= 0 ? g_f3dg_render_split : g_f3dg_render_fast ? 1 : one_view ? 3 : 0;
             const int unroll = g_f3dg_render_unroll >= 1 ? g_f3dg_render_unroll : g_f3dg_render_fast ? 2 : 1;
-            if (unroll > 1 || split)
-                return f3dg_launch_render3u(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
+            if (split)
+                return f3dg_launch_render_small(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
                                             g_f3dg_render_fast, save_aux, final_T, n_contrib, unroll, split, g_f3dg_render_count);
 #define F3DG_LAUNCH3L(AUX, FST) F3DG_KLAUNCH((render3l_fwd_kernel<AUX, FST>), grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T,  \
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \

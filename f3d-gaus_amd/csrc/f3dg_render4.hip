@@ -415,198 +415,17 @@ render4_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 thread_local char g_kernel_name4[160] = "";
 
 
-// ---- SMALL launches (one or two 256^2 views: at most two waves per SIMD): U entries per phase-2 trip ------------------------------
-// A one-view call (the reference's own loop, visualize.py:293-314, 387-416) is 1,024 quadrant waves on 1,024 SIMDs: every wave is alone
-// and its time is the LENGTH of its instruction chain times the latency of a dependent instruction -- measured ~9 cycles per
-// instruction at 65,536 pixel-ordered Gaussians (8.7 slides x ~1,870 instructions in 77 us), where the SIMD could issue one every two.
-// render3l_fwd_kernel (f3dg_render.hip) hides the memory part of that chain (next window's gathers behind phase 2); this variant
-// shortens the arithmetic part: a phase-2 trip pops the next U passing entries of every pixel, evaluates their stateless parts
-// (f3dg_pair_eval) as U INDEPENDENT instruction streams the scheduler interleaves -- the record reads of all U leave LDS together --
-// and then applies the recurrence to the U results in list order (f3dg_pair_apply / _flat; a pair behind the pixel's saturation or
-// beyond its last passing entry runs with alpha 0). Registers are free at this occupancy. Per pixel the sequence of blended entries
-// and every operation on them is render3l's: same images and auxiliary planes to the bit.
 #define F3DG_R3U_RING 256
-template <bool SAVE_AUX, bool FAST, int U>
-__global__ void __launch_bounds__(64, 2)
-render3u_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
-                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
-                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
-                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
-                    float* __restrict__ out_color, float* __restrict__ final_T, unsigned* __restrict__ n_contrib)
-{
-    unsigned view, unit;
-    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
-    const unsigned tile = unit >> 2, quad = unit & 3u;
-    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
-    const unsigned lane = threadIdx.x;
-    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
-    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
-    const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
-    const size_t HW = (size_t)H * W;
-    const size_t pix_id = (size_t)W * pix_y + pix_x;
-    const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
-    const float ray_x = (float)((pixf_x - W / 2.) / focal_x);
-    const float ray_y = (float)((pixf_y - H / 2.) / focal_y);
-
-    uint2 range = ranges[(size_t)view * T + tile];
-    if (hdr->overflow) range = make_uint2(0, 0);
-    const unsigned n = range.y - range.x;
-
-    __shared__ float4 sR[2][4][F3DG_R4_WIN];  // two windows of records, [window][16-byte chunk][entry]
-    __shared__ uint2 sQ[F3DG_R3U_RING];       // (list position, Gaussian id) of the kept entries: the current window, the next one, the backlog
-
-    const F3dgRec* vrec = rec + (size_t)view * P;
-    const float4* vcull = cull + (size_t)view * P;
-    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-
-    bool done = !inside;
-    F3dgPixel st;
-    f3dg_pixel_init(st);
-
-    unsigned cursor = 0, qhead = 0, qcount = 0;
-    unsigned id0 = lane < n ? point_list[range.x + lane] : 0u;
-    unsigned id1 = 64u + lane < n ? point_list[range.x + 64u + lane] : 0u;
-    auto scan_until = [&](unsigned want) {
-        while (qcount < want && cursor < n) {
-            const unsigned idm = id0, pos = cursor + lane;
-            cursor += 64u;
-            id0 = id1;
-            id1 = cursor + 64u + lane < n ? point_list[range.x + cursor + 64u + lane] : 0u;
-            const bool keep = pos < n && (idm & qbit) != 0u;
-            const unsigned long long kb = __ballot(keep);
-            if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R3U_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
-            qcount += (unsigned)__popcll(kb);
-        }
-        wave_lds_fence();
-    };
-    auto request = [&](unsigned buf, unsigned first, unsigned m, float4& e4) {
-        e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (lane < m) {
-            const unsigned id = sQ[(first + lane) & (F3DG_R3U_RING - 1)].y;
-            const float4* src = reinterpret_cast<const float4*>(vrec + id);
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
-                                                 (__attribute__((address_space(3))) void*)&sR[buf][c][0], 16, 0, 0);
-            e4 = vcull[id];
-        }
-    };
-
-    if (__ballot(!done) != 0ull) {
-        scan_until(F3DG_R4_WIN);
-        unsigned m = qcount < F3DG_R4_WIN ? qcount : F3DG_R4_WIN, buf = 0;
-        float4 e4;
-        request(0, qhead, m, e4);
-        while (m != 0u) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_lds_fence();
-            const float ec = lane < m ? sR[buf][3][lane].w : 0.0f;
-            // ---- phase 1 of the current window
-            int pass_lo = 0, pass_hi = 0;
-            {
-                const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
-                const float v0 = (float)qy0 - e4.y;
-                float dxx[8], adx[8], dyy[8], cdy[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    dxx[q] = u0 + (float)q;
-                    adx[q] = e4.z * dxx[q];
-                    dyy[q] = v0 + (float)q;
-                    cdy[q] = ec * dyy[q] * dyy[q];
-                }
-                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
-            }
-            // ---- the next window: scan for it and request its records; they land during phase 2
-            scan_until(m + F3DG_R4_WIN);
-            const unsigned m_next = qcount - m < F3DG_R4_WIN ? qcount - m : F3DG_R4_WIN;
-            float4 e4n;
-            request(buf ^ 1u, qhead + m, m_next, e4n);
-
-            // ---- phase 2 of the current window, U entries per trip
-            unsigned long long pass = done ? 0ull : ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
-            while (pass != 0 && !done) {
-                int j[U];
-                bool have[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    have[u] = pass != 0ull;
-                    j[u] = have[u] ? __builtin_ctzll(pass) : j[0];
-                    pass &= pass - 1ull;
-                }
-                F3dgPair pr[U];
-                float cr[U], cg[U], cb[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const float4 q0 = sR[buf][0][j[u]], q1 = sR[buf][1][j[u]], q2 = sR[buf][2][j[u]], q3 = sR[buf][3][j[u]];
-                    pr[u] = f3dg_pair_eval<FAST, true, true, FAST>(ray_x, ray_y, q0, q1, q2);
-                    if (!have[u]) pr[u].alpha = 0.0f;
-                    cr[u] = q3.x; cg[u] = q3.y; cb[u] = q3.z;
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (FAST) {
-                        F3dgPair p = pr[u];
-                        p.alpha = done ? 0.0f : p.alpha;
-                        done |= f3dg_pair_apply_flat<true, true>(st, F3DG_R4_FLAG | (unsigned)j[u], p, cr[u], cg[u], cb[u]);
-                    } else if (!done && pr[u].alpha != 0.0f) {
-                        done = f3dg_pair_apply<false, true, true>(st, F3DG_R4_FLAG | (unsigned)j[u], pr[u], cr[u], cg[u], cb[u]);
-                    }
-                }
-            }
-            if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
-                if (st.last_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
-                    st.last_contributor = sQ[(qhead + (st.last_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
-                if (st.max_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
-                    st.max_contributor = sQ[(qhead + (st.max_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
-            }
-            qhead += m;
-            qcount -= m;
-            m = m_next;
-            e4 = e4n;
-            buf ^= 1u;
-            if (__ballot(!done) == 0ull)
-                break;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS write of this wave may still be in flight when it ends
-    }
-
-    if (inside) {
-        const float* bg = background + (bg_per_view ? 3 * view : 0);
-        const float Tr = st.Tr;
-        const float distortion_before_normalized = st.distortion;
-        const float distortion = (float)(st.distortion / ((1 - Tr) * (1 - Tr) + 1e-7));
-
-        if (SAVE_AUX) {
-            float* fT = final_T + (size_t)view * 4 * HW;
-            fT[pix_id] = Tr;
-            fT[pix_id + HW] = st.dist1;
-            fT[pix_id + 2 * HW] = st.dist2;
-            fT[pix_id + 3 * HW] = distortion_before_normalized;
-            unsigned* nc = n_contrib + (size_t)view * 2 * HW;
-            nc[pix_id] = st.last_contributor;
-            nc[pix_id + HW] = st.max_contributor;
-        }
-        float* out = out_color + (size_t)view * F3DG_OUT_CHANNELS * HW;
-        out[0 * HW + pix_id] = st.C0 + Tr * bg[0];
-        out[1 * HW + pix_id] = st.C1 + Tr * bg[1];
-        out[2 * HW + pix_id] = st.C2 + Tr * bg[2];
-        out[3 * HW + pix_id] = st.C3;
-        out[4 * HW + pix_id] = st.C4;
-        out[5 * HW + pix_id] = st.C5;
-        out[6 * HW + pix_id] = st.C6;
-        out[7 * HW + pix_id] = st.C7;
-        out[8 * HW + pix_id] = distortion;
-    }
-}
-
 // ---- SMALL launches, two waves per quadrant: a PRODUCER wave prepares window k + 1 while the CONSUMER wave composites window k ------
 // What is left of a lone wave's chain once phase 2 is shortened is everything else: with no entry passing the ellipse test at all
 // (option debug_skip_all) the one-view kernel still takes 36 of its 66 us -- list chunks, the id-dependent record gathers, the 64
 // ellipse ballots of phase 1, each a latency nobody fills. That part does not depend on any pixel's state, so here it runs on its own
 // wave: workgroup = 2 waves on 2 SIMDs of a CU; wave 1 scans the list, requests the records of the next window into the other half
 // of the double buffer (global_load_lds), waits for them, runs phase 1 and leaves the 64 pass masks in LDS; wave 0 owns the pixels and
-// only runs phase 2 (U entries per trip, as render3u). One s_barrier per window. The time of a window is the longer of the two parts
+// only runs phase 2 -- U entries per trip: the next U passing entries of every pixel are popped together, their stateless parts
+// (f3dg_pair_eval) evaluated as U independent instruction streams the scheduler interleaves (the record reads of all U leave LDS together;
+// a lone wave issues a dependent instruction every ~5 clocks, independent ones every 2.5), the recurrence applied in list order. One
+// s_barrier per window. The time of a window is the longer of the two parts
 // instead of their sum. Per pixel nothing changes: bit-identical outputs and auxiliary planes.
 template <bool SAVE_AUX, bool FAST, int U>
 __global__ void __launch_bounds__(128, 1)
@@ -1086,7 +905,7 @@ render3q_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
 
 } // namespace
 
-int f3dg_launch_render3u(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+int f3dg_launch_render_small(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
                          const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
                          float* out_color, int fast, int save_aux, float* final_T, unsigned* n_contrib, int unroll, int split, int count)
 {
@@ -1121,18 +940,8 @@ int f3dg_launch_render3u(hipStream_t s, int V, int P, int W, int H, float focal_
         F3DG_HIP_CHECK(hipGetLastError());
         return F3DG_OK;
     }
-    const int U = 2;        // (3 and 4 entries per trip measured equal to 2: 67.3 / 65.9 / 65.7 us; not compiled in)
-#define F3DG_LAUNCH3U(AUX, FST, UU) F3DG_KLAUNCH((render3u_fwd_kernel<AUX, FST, UU>), grid, dim3(64), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, \
-                                                 point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib)
-#define F3DG_LAUNCH3U_U(AUX, FST) F3DG_LAUNCH3U(AUX, FST, 2)
-    if (save_aux) { if (fast) F3DG_LAUNCH3U_U(true, true); else F3DG_LAUNCH3U_U(true, false); }
-    else { if (fast) F3DG_LAUNCH3U_U(false, true); else F3DG_LAUNCH3U_U(false, false); }
-#undef F3DG_LAUNCH3U_U
-#undef F3DG_LAUNCH3U
-    snprintf(g_kernel_name4, sizeof g_kernel_name4, "render3u_fwd_kernel<SAVE_AUX=%s, FAST=%s, U=%d>", save_aux ? "true" : "false", fast ? "true" : "false", U);
-    g_f3dg_last_render_kernel = g_kernel_name4;
-    F3DG_HIP_CHECK(hipGetLastError());
-    return F3DG_OK;
+    (void)unroll;
+    return F3DG_ERR_BAD_ARG;      // (split == 0 is render3l_fwd_kernel's: f3dg_launch_render does not come here)
 }
 
 int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,

@@ -367,7 +367,7 @@ int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const u
  * "render_split" (default -1: 1 in fast arithmetic -- also for two views --, 3 in the reference's): 1 = render3p_fwd_kernel, a producer wave scans the list,
  * gathers the records and runs phase 1 of the next window while the consumer wave composites; 2 / 3 = render3q_fwd_kernel, consumer +
  * 2 / 3 evaluator waves (the stateless part of every pair, parked in LDS) + producer; 0 = one wave. "render_unroll" (default -1: 2
- * in fast arithmetic on one-view launches, else 1): entries per phase-2 trip of the one- and two-wave kernels (1 or 2; 3 and 4 measured equal to 2).
+ * in fast arithmetic on one-view launches, else 1): entries per phase-2 trip of render3p (1 or 2; 3 and 4 measured equal to 2).
  * "render_dma" (default 1): render3 stages records by global_load_lds_dwordx4 (1) or through registers (0); "render_lds_pad"
  * (default 0): extra dynamic LDS bytes per render3 workgroup (occupancy experiments).
  * "bwd_occ" (default 5): waves per SIMD the compositing backward (render3_bwd_kernel) is compiled for (2..6).
