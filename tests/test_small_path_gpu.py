@@ -159,3 +159,39 @@ def test_deferred_status_same_frames_and_late_overflow_is_repaired(depth, gpu_de
     for got, want in ((a0, want_small), (a1, want_small), (b, want_big), (c, want_big)) + (((b2, want_big),) if b2 is not None else ()):
         for k in keys:
             assert torch.equal(got[k], want[k]), k
+
+def test_blocking_status_repairs_overflow_before_returning(gpu_device):
+    """Without `set_deferred_status` the wrapper keeps the reference's contract: a call returns checked frames. A call that overflows
+    the workspace an earlier call of the shape sized is re-issued with a grown one before it returns: same frames as a fresh process,
+    no warning, and the capacity hint of the shape grows."""
+    import warnings
+    from f3dgaus_amd import cameras
+    from f3dgaus_amd import diff_gof_rasterization as dgr
+    cfg = cameras.default_cfg(128)
+    small = make_scene(P=30000, res=(128, 128), s0=0.008, view="oblique")
+    big = make_scene(P=30000, res=(128, 128), s0=0.05, view="oblique")
+    dev = gpu_device
+    cam = lambda sc: (sc["viewmatrix"][:1].to(dev), sc["projmatrix"][:1].to(dev), sc["campos"][:1].to(dev), torch.zeros(1, 3, device=dev), cfg)
+    keys = ("render", "rendered_normal", "rendered_depth", "depth_normal", "rendered_alpha", "distortion_map", "radii")
+    L = _lib.lib()
+    L.f3dg_set_option(b"small_path", 2)
+    with torch.no_grad():
+        want_small = {k: v.clone() for k, v in f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small)).items() if k in keys}
+        want_big = {k: v.clone() for k, v in f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big)).items() if k in keys}
+        dgr._CAP_HINT.clear()
+        dgr._WS_CACHE.clear()
+        L.f3dg_set_option(b"small_path", 2)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            a0 = f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small))      # sizes the capacity hint of the shape
+            a1 = f3d.render_predicted_more_v2_gof(_pc(small, dev), 0, *cam(small))
+            hint = dict(dgr._CAP_HINT)
+            b = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))           # overflows the cached workspace: repaired before returning
+            c = f3d.render_predicted_more_v2_gof(_pc(big, dev), 0, *cam(big))
+            assert not w
+        assert not dgr._PENDING
+        assert all(dgr._CAP_HINT[k] > v for k, v in hint.items())
+    L.f3dg_set_option(b"small_path", 2)
+    for got, want in ((a0, want_small), (a1, want_small), (b, want_big), (c, want_big)):
+        for k in keys:
+            assert torch.equal(got[k], want[k]), k
