@@ -84,8 +84,13 @@ def parse():
     ap.add_argument("--channels", choices=["all", "rgb_depth_alpha"], default="all",
                     help="c2: output channels of the rasterizer calls; rgb_depth_alpha = what the reference's loops consume (visualize.py:304-306, "
                          "400-402) and the build's cycle / orbit loops ask for (F3DG_FLAG_SKIP_NORMAL | _SKIP_DISTORTION); the headline stays 9-channel")
+    ap.add_argument("--scan", type=int, choices=[0, 1], default=int(os.environ.get("F3DG_SCAN", "0")),
+                    help="1: the calls carry F3DG_FLAG_SCAN -- the split-pixel compositing schedule (render5_fwd_kernel), its own 1e-4-gated mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the timed loops with frame packing + device-to-host copy: `value` is then the in-HBM rate")
+    ap.add_argument("--d2h-issue", choices=["thread", "main"], default=os.environ.get("F3DG_D2H_ISSUE", "main"),
+                    help="who issues the pack + device-to-host copy of a finished step on the side stream: the step's own host thread "
+                         "(three asynchronous calls behind an event) or a second host thread")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra timed loop in the reference's arithmetic (value_exact / roofline_exact)")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
     return ap.parse_args()
@@ -212,7 +217,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     chunks = [(a, min(a + args.views_per_call, V)) for a in range(0, V, args.views_per_call)]
     workspaces = {}
 
-    call_opts = {"exact": None, "tile_cull": None, "channels": args.channels}     # per-call settings (F3DG_FLAG_EXACT / _NO_TILE_CULL): None = the process default
+    call_opts = {"exact": None, "tile_cull": None, "channels": args.channels, "scan": bool(args.scan)}     # per-call settings (F3DG_FLAG_EXACT / _NO_TILE_CULL): None = the process default
 
     def render_chunk(a, b, check, out=out):
         o, r, ws = f3d.rasterize_views(
@@ -338,6 +343,17 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         def step_d2h():
             k = state["i"] & 1
             state["i"] += 1
+            if args.d2h_issue == "main":
+                torch.cuda.current_stream().wait_event(copied[k])    # the side stream has read buffer k (two steps ago)
+                for a, b in chunks:
+                    render_chunk(a, b, check=False, out=outs[k])
+                rendered[k].record()
+                with torch.cuda.stream(side):
+                    side.wait_event(rendered[k])
+                    f3d.gaussian_renderer.pack_frames(outs[k], out=packed[k])
+                    host[k].copy_(packed[k], non_blocking=True)
+                    copied[k].record()
+                return
             wait_issued(issued[k])
             issued[k].clear()
             torch.cuda.current_stream().wait_event(copied[k])        # the side stream has read buffer k (two steps ago)
@@ -358,13 +374,27 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         L.f3dg_profile_enable(1)
         L.f3dg_debug_launch_count(1)
         elapsed = timed(step_d2h, d2h_barrier, 0, args.steps)
-        nlaunch = int(L.f3dg_debug_launch_count(1)) - args.steps       # (the pack kernel of every step is the copy thread's)
+        nlaunch = int(L.f3dg_debug_launch_count(1)) - args.steps       # (the pack kernel of every step is not the call's)
         L.f3dg_profile_enable(0)
         stage_ms, ncalls, rows = collect(args.steps)
         for ws in workspaces.values():      # no overflow happened in the timed region
             f3d.diff_gof_rasterization.read_status(ws)
         jobs.put(None)
         worker.join(timeout=10)
+
+        # the pack + copy leg alone, nothing else on the device (what has to hide behind the next step)
+        leg = []
+        for _ in range(3):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            with torch.cuda.stream(side):
+                e0.record()
+                f3d.gaussian_renderer.pack_frames(outs[0], out=packed[0])
+                e1.record()
+                host[0].copy_(packed[0], non_blocking=True)
+                e2.record()
+            e2.synchronize()
+            leg.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        leg_pack_ms, leg_copy_ms = min(x[0] for x in leg), min(x[1] for x in leg)
 
         host_f32 = torch.empty((V, 3, RES, RES), dtype=torch.float32).pin_memory()
 
@@ -374,7 +404,9 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
 
         e32 = timed(step_f32, gat.barrier, 1, args.steps)
         d2h = {"uint8_rgb": {"value": V * args.steps / elapsed, "unit": "views/s", "ms_per_step": 1e3 * elapsed / args.steps,
-                             "bytes_per_step": V * RES * RES * 3, "pipelined": True},
+                             "bytes_per_step": V * RES * RES * 3, "pipelined": True, "issued_by": args.d2h_issue,
+                             "leg_alone_ms": {"pack_frames": leg_pack_ms, "copy_to_pinned": leg_copy_ms,
+                                              "copy_GBps": V * RES * RES * 3 / (leg_copy_ms * 1e-3) / 1e9 if leg_copy_ms > 0 else None}},
                "float32_rgb": {"value": V * args.steps / e32, "unit": "views/s", "ms_per_step": 1e3 * e32 / args.steps,
                                "bytes_per_step": V * RES * RES * 12, "pipelined": False},
                "note": "uint8: f3dg_pack_frames + copy to pinned host memory on a side stream, double-buffered behind the next step's "
@@ -399,13 +431,25 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         cbuf = (C.c_ulonglong * 16)()
         L.f3dg_debug_render_counts(cbuf, 1)
         L.f3dg_debug_render4_counts(None, 1)
+        L.f3dg_debug_render5_counts(None, 1)
         step()
         gat.barrier()
         _lib.check(L.f3dg_debug_render_counts(cbuf, 1), "f3dg_debug_render_counts")
         _lib.check(L.f3dg_set_option(b"render_count", 0), "f3dg_set_option")
         c4 = (C.c_ulonglong * 16)()
         _lib.check(L.f3dg_debug_render4_counts(c4, 1), "f3dg_debug_render4_counts")
-        if c4[5]:       # the rank-packed kernel (render_kernel = 4) ran: its own counters
+        c5 = (C.c_ulonglong * 16)()
+        _lib.check(L.f3dg_debug_render5_counts(c5, 1), "f3dg_debug_render5_counts")
+        if c5[5]:       # the split-pixel kernel (F3DG_FLAG_SCAN) ran: its own counters
+            pairs = int(c5[4]) + int(c5[7])
+            counts = {"list_entries_staged": int(c5[0]), "list_entries_scanned": int(c5[1]), "fused_trips": int(c5[2]), "slides": int(c5[3]),
+                      "fused_lane_trips": int(c5[4]), "waves": int(c5[5]), "dense_batches": int(c5[6]), "pairs_in_dense_batches": int(c5[7]),
+                      "pixels_compacted": int(c5[8]), "slides_with_a_compaction": int(c5[9]), "phase2_lane_trips": pairs,
+                      "fused_trip_lane_utilisation": int(c5[4]) / (64.0 * int(c5[2])) if c5[2] else None,
+                      "dense_batch_lane_utilisation": int(c5[7]) / (64.0 * int(c5[6])) if c5[6] else None,
+                      "note": "one untimed step with option render_count = 1 (render5_fwd_kernel with work counters); a fused trip runs a pair's whole "
+                              "arithmetic in the pixel's lane, a dense batch = 64 (pixel, entry) pairs, one per lane, combined by segmented scans"}
+        elif c4[5]:       # the rank-packed kernel (render_kernel = 4) ran: its own counters
             pairs = int(c4[4]) + int(c4[9])
             counts = {"list_entries_staged": int(c4[0]), "list_entries_scanned": int(c4[1]), "fused_trips": int(c4[2]), "slides": int(c4[3]),
                       "fused_lane_trips": int(c4[4]), "waves": int(c4[5]), "packed_batches": int(c4[6]), "blend_trips": int(c4[7]),
@@ -515,6 +559,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         "value_in_hbm": world * V * args.steps / elapsed_hbm, "ms_per_step_in_hbm": 1e3 * elapsed_hbm / args.steps,
         "call_ms_spread": {"note": "device time of one call (projection + binning + compositing, HIP events) over the calls of the timed "
                                    "loop `value` comes from: a box-to-box or run-to-run effect shows here, not only in the mean",
+                           "slowest_call_index": (max(range(len(rows)), key=lambda i: sum(rows[i])) if rows else None),
                            "all_stages": spread(rows, None), "preprocess": spread(rows, 0), "binning": spread(rows, 1),
                            "compositing": spread(rows, 2)},
         "dist_backend": (os.environ.get("F3DG_DIST_BACKEND", "nccl") if world > 1 else None),

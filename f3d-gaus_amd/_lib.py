@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libf3dg_hip.so")
 
 OK, ERR_BAD_ARG, ERR_WORKSPACE, ERR_OVERFLOW, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 FLAG_SAVE_AUX, FLAG_BG_PER_VIEW, FLAG_SKIP_NORMAL, FLAG_SKIP_DISTORTION = 1, 2, 4, 8
-FLAG_EXACT, FLAG_FAST, FLAG_NO_TILE_CULL, FLAG_NO_SMALL_PATH = 16, 32, 64, 128
+FLAG_EXACT, FLAG_FAST, FLAG_NO_TILE_CULL, FLAG_NO_SMALL_PATH, FLAG_SCAN = 16, 32, 64, 128, 256
 PENDING = 1
 
 _ERR_TEXT = {
@@ -81,6 +81,7 @@ SIGNATURES = {
     "f3dg_debug_last_render_kernel": (C.c_char_p, []),
     "f3dg_debug_render_counts": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "f3dg_debug_render4_counts": (_i, [C.POINTER(C.c_ulonglong), _i]),
+    "f3dg_debug_render5_counts": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "f3dg_debug_render3q_clocks": (_i, [C.POINTER(C.c_ulonglong)]),
     "f3dg_debug_pass1_occupancy": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "f3dg_backward_pairs": (_i, [_p, _p, C.POINTER(_ll)]),

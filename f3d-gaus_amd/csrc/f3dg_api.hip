@@ -120,6 +120,7 @@ int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_pack = -1;
 int g_f3dg_render_dma = 1;
+int g_f3dg_render_replay = 0;
 int g_f3dg_render_wpb = 1;
 int g_f3dg_render_count = 0;
 #define F3DG_RENDER_TAIL_DEFAULT 0
@@ -146,6 +147,8 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; if (value == 4) g_f3dg_render_pack = 1; return F3DG_OK; }
     if (name && strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_scan") == 0) { g_f3dg_render_scan = value < 0 ? -1 : value != 0; return F3DG_OK; }
+    if (name && strcmp(name, "render_scan_th") == 0) { g_f3dg_render_scan_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) { std::lock_guard<std::mutex> lock(g_small_mutex); g_small_disabled.clear(); } return F3DG_OK; }
     if (name && strcmp(name, "small_path_aux") == 0) { g_f3dg_small_path_aux = value != 0; return F3DG_OK; }
@@ -160,6 +163,9 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (name && strcmp(name, "render_count") == 0) { g_f3dg_render_count = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_tail") == 0) { g_f3dg_render_tail = value < 0 ? F3DG_RENDER_TAIL_DEFAULT : value > 64 ? 64 : value; return F3DG_OK; }
     if (name && strcmp(name, "render_wpb") == 0) { g_f3dg_render_wpb = value == 4 ? 4 : 1; return F3DG_OK; }
+#ifdef F3DG_LAB
+    if (name && strcmp(name, "render_replay") == 0) { g_f3dg_render_replay = value; return F3DG_OK; }
+#endif
     if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
     if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
     if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
@@ -463,7 +469,7 @@ extern "C" int f3dg_forward_sets(void* stream, void* workspace, size_t workspace
                               (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, out_color,
                               reinterpret_cast<float*>(ws + L.final_T),
                               reinterpret_cast<unsigned*>(ws + L.n_contrib), save_aux,
-                              flags & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION), fast);
+                              flags & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION), fast, (flags & F3DG_FLAG_SCAN) ? 1 : 0);
     prof_mark(prof, ST_RENDER, s);
     return rc;
 }

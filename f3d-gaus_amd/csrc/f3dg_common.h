@@ -245,6 +245,7 @@ extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding 
 extern int g_f3dg_render_tail;         // N > 0: render3s switches a quadrant to the tail schedule once at most N of its pixels are unsaturated (0: never)
 extern int g_f3dg_render_count;        // 1: the one-wave kernel's counting variant (diagnostic; f3dg_debug_render_counts)
 extern int g_f3dg_render_wpb;          // quadrant waves per render3s workgroup: 1 (default) or 4 (a tile's four waves start together on one CU)
+extern int g_f3dg_render_replay;       // lab builds (-DF3DG_LAB) only: 2 / 3 = launch render3s_stage_only_kernel instead of the compositing kernel
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);
 void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);
@@ -256,7 +257,8 @@ extern int g_f3dg_render_fast;         // 1 (default): float64 island of the ble
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
-                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels = 0u, int fast = -1 /* -1: the process default */);
+                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels = 0u, int fast = -1 /* -1: the process default */,
+                       int scan = 0 /* the call carries F3DG_FLAG_SCAN */);
 
 // the rank-packed compositing forward (f3dg_render4.hip; option render_kernel = 4, inference launches)
 extern int g_f3dg_render_pack;         // -1 (default): inference launches in the reference's arithmetic take render4; 1: all inference launches; 0: none
@@ -265,6 +267,13 @@ int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x
                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
                         float* out_color, int fast, unsigned skip_channels, int count, int save_aux = 0, float* final_T = nullptr,
                         unsigned* n_contrib = nullptr);
+
+// the split-pixel compositing forward (f3dg_render5.hip; F3DG_FLAG_SCAN / option render_scan: fast inference launches of the general path)
+extern int g_f3dg_render_scan;         // -1 (default): calls with F3DG_FLAG_SCAN; 1: every eligible launch; 0: never
+extern int g_f3dg_render_scan_th;      // fused trips while more than this many pixels take part (default 20)
+int f3dg_launch_render5(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+                        const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
+                        float* out_color, unsigned skip_channels, int count);
 
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated);

@@ -446,6 +446,12 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
 // ([4] / (64 [2]) = lane utilisation of phase 2), [5] waves, [6] / [7] the trips of slides that began with at most 8 / at most 24 of the
 // quadrant's 64 pixels still unsaturated, [8] / [9] those slides. 64 rows against atomic contention; summed on the host.
 __device__ unsigned long long g_f3dg_counts[64][16];
+#ifdef F3DG_LAB
+// lab build: slides every quadrant wave of the last counting launch performed (option render_replay = 1 with render_count = 1), replayed
+// by render3s_stage_only_kernel (render_replay = 2): the launch's scan + staging + phase 1 without any phase 2
+#define F3DG_SLIDE_LOG_N (1u << 18)
+__device__ unsigned g_f3dg_slide_log[F3DG_SLIDE_LOG_N];
+#endif
 
 // ---- optional phase timing (build with -DF3DG_TIMING: tools/render_timing.py). Shader-clock cycles per wave, summed over all
 // waves of all launches since the last reset: [0] barrier waits, [1] staging, [2] list build, [3] phase 1, [4] phase 2,
@@ -1170,6 +1176,9 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         }
     }
     translate(2u);
+#ifdef F3DG_LAB
+    if (COUNT && lane == 0 && blockIdx.x < F3DG_SLIDE_LOG_N) g_f3dg_slide_log[blockIdx.x] = n_slides;
+#endif
     if (COUNT && lane == 0) {
         unsigned long long* c = g_f3dg_counts[blockIdx.x & 63u];
         atomicAdd(&c[10], (unsigned long long)n_tail_steps);
@@ -1222,6 +1231,97 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         if (DIST) out[8 * HW + pix_id] = distortion;
     }
 }
+
+#ifdef F3DG_LAB
+// ---- lab: the staging half of a render3s launch, replayed ----------------------------------------------------------------------------
+// Every quadrant wave repeats the list scan, the record gathers (global_load_lds) and phase 1 of exactly the slides the logged launch
+// performed (g_f3dg_slide_log) and never enters phase 2: what the launch costs as a stream of list reads, 64-byte gathers and ellipse
+// ballots, with the same addresses in the same order. The frames it writes are garbage (the XOR of the pass masks keeps the work alive).
+__global__ void __launch_bounds__(64, 8)
+render3s_stage_only_kernel(int V, int P, int W, int H, int tiles_x, int T, const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
+                           const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec, const float4* __restrict__ cull,
+                           float* __restrict__ out_color, int gather_records)
+{
+    unsigned view, unit;
+    f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
+    const unsigned tile = unit >> 2, quad = unit & 3u;
+    const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
+    uint2 range = ranges[(size_t)view * T + tile];
+    if (hdr->overflow) range = make_uint2(0, 0);
+    const unsigned n = range.y - range.x;
+    __shared__ float4 sR[4][F3DG_R3_WIN];
+    __shared__ uint2 sQ[F3DG_R3_RING];
+    const F3dgRec* vrec = rec + (size_t)view * P;
+    const float4* vcull = cull + (size_t)view * P;
+    const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned hl = lane & 31u, row4 = (lane >> 5) * 4u;
+    const unsigned slides = blockIdx.x < F3DG_SLIDE_LOG_N ? g_f3dg_slide_log[blockIdx.x] : 0u;
+    unsigned cursor = 0, qhead = 0, qpend = 0, flip = 0;
+    int acc = 0;
+    unsigned idn = lane < n ? point_list[range.x + lane] : 0u;
+    for (unsigned sl = 0; sl < slides; sl++) {
+        while (qpend < 32u && cursor < n) {
+            const unsigned idm = idn, pos = cursor + lane;
+            cursor += 64u;
+            idn = cursor + lane < n ? point_list[range.x + cursor + lane] : 0u;
+            const bool keep = pos < n && (idm & qbit) != 0u;
+            const unsigned long long kb = __ballot(keep);
+            if (keep) sQ[(qhead + qpend + (unsigned)__popcll(kb & lt)) & (F3DG_R3_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
+            qpend += (unsigned)__popcll(kb);
+        }
+        const unsigned m = qpend < 32u ? qpend : 32u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned base = flip * 32u;
+        float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float ec = 0.0f;
+        if (hl < m) {
+            const uint2 q = sQ[(qhead + hl) & (F3DG_R3_RING - 1)];
+            if (lane < 32u && gather_records) {
+                const float4* src = reinterpret_cast<const float4*>(vrec + q.y);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                                     (__attribute__((address_space(3))) void*)&sR[c][base], 16, 0, 0);
+            }
+            e4 = vcull[q.y];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (hl < m) ec = sR[3][base + hl].w;
+        qhead += m;
+        qpend -= m;
+        int fresh = 0;
+        if (m != 0u) {
+            const float u0 = hl < m ? (float)qx0 - e4.x : __builtin_nanf("");
+            const float v0 = (float)(qy0 + row4) - e4.y;
+            float dxx[8], adx[8], dyy[4], cdy[4];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                dxx[q] = u0 + (float)q;
+                adx[q] = e4.z * dxx[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                dyy[q] = v0 + (float)q;
+                cdy[q] = ec * dyy[q] * dyy[q];
+            }
+            half_ballots<0>(fresh, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+        }
+        acc ^= fresh;
+        flip ^= 1u;
+    }
+    const unsigned pix_x = qx0 + (lane & 7u), pix_y = qy0 + (lane >> 3);
+    if (pix_x < (unsigned)W && pix_y < (unsigned)H)
+        out_color[(size_t)view * F3DG_OUT_CHANNELS * H * W + (size_t)W * pix_y + pix_x] = __int_as_float(acc & 0x3fffff);
+}
+#endif
 
 // ---- render3 for SMALL launches: the next window's gathers in flight behind phase 2 ------------------------------------------------
 // A call of one or two 256^2 views is 1,024-2,048 waves on a chip that holds 8,192: every wave is alone on its SIMD and its time is a
@@ -1410,7 +1510,7 @@ int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
-                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels, int fast)
+                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels, int fast, int scan)
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
@@ -1427,9 +1527,15 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
                                                   focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view,       \
                                                   out_color, final_T, n_contrib)
 #define F3DG_LAUNCH3(AUX, FST, OCC) do { if (g_f3dg_render_dma) F3DG_LAUNCH3D(AUX, FST, true, OCC); else F3DG_LAUNCH3D(AUX, FST, false, OCC); } while (0)
+        // the split-pixel schedule of f3dg_render5.hip: fast inference launches that ask for it (F3DG_FLAG_SCAN, whatever their size) or,
+        // with option render_scan 1, every such launch that is not a one- or two-view latency chain (those keep their multi-wave kernels)
+        const bool small_launch = g_f3dg_render_lowocc && (long long)V * T * 4 <= (g_f3dg_render_lowocc > 1 ? 1024ll * g_f3dg_render_lowocc : 2048ll);
+        if (g_f3dg_render_slide && g_f3dg_render_fast && !save_aux && g_f3dg_render_scan != 0 && (scan || (g_f3dg_render_scan == 1 && !small_launch)))
+            return f3dg_launch_render5(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
+                                       skip_channels, g_f3dg_render_count);
         // every variant fits 64 VGPRs without spills: 8 waves per SIMD, 32 x 5 KB = the CU's 160 KB of LDS
         // small launches (at most two waves per SIMD: one or two 256^2 views) are latency chains: the prefetching variant
-        if (g_f3dg_render_lowocc && (long long)V * T * 4 <= (g_f3dg_render_lowocc > 1 ? 1024ll * g_f3dg_render_lowocc : 2048ll)) {
+        if (small_launch) {
             // one view (at most one quadrant per SIMD): the multi-wave kernels of f3dg_render4.hip. Defaults by measurement at 65,536 pixel-ordered
             // Gaussians (profiles/r05_final/one_view.md): fast arithmetic -- producer + consumer waves, two entries per trip (render3p, 76.6 ->
             // 57.9 us); the reference's arithmetic -- consumer + three evaluator waves + producer (render3q, 134 -> 100 us)
@@ -1450,6 +1556,15 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
             F3DG_HIP_CHECK(hipGetLastError());
             return F3DG_OK;
         }
+#ifdef F3DG_LAB
+        if (g_f3dg_render_replay >= 2 && !save_aux) {      // lab: the staging half of the last counting launch (3: without the record gathers)
+            F3DG_KLAUNCH(render3s_stage_only_kernel, grid3, dim3(64), 0, s, V, P, W, H, tiles_x, T, hdr, ranges, point_list, rec, cull, out_color,
+                         g_f3dg_render_replay == 2 ? 1 : 0);
+            note_kernel("render3s_stage_only_kernel", 0, 0, "");
+            F3DG_HIP_CHECK(hipGetLastError());
+            return F3DG_OK;
+        }
+#endif
         // the rank-packed kernel of f3dg_render4.hip (option render_pack: 1 = every inference launch, -1 = the default: inference launches
         // in the reference's arithmetic, whose stateless part is 2.5 x as long -- measured -38 % on the real merged set, -6 % at C2; in
         // fast arithmetic the packed trips' hand-over costs what they save: 8.4-8.7 against 8.6 ms)

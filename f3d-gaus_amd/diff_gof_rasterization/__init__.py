@@ -159,7 +159,7 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
                     tanfovx, tanfovy, sh=None, colors_precomp=None, scales=None, rotations=None, cov3Ds_precomp=None,
                     view2gaussian_precomp=None, sh_degree=0, scale_modifier=1.0, kernel_size=0.0, workspace=None,
                     max_rendered=None, save_aux=False, out=None, radii=None, check=True, n_sets=1, channels="all",
-                    exact=None, tile_cull=None, small_path=None):
+                    exact=None, tile_cull=None, small_path=None, scan=None):
     """Render ``n_views`` cameras of the same Gaussians in ONE launch sequence (f3dg_forward_batched).
 
     viewmatrices / projmatrices: [V,4,4] (any leading singleton dims), camposs [V,3], bg [3] or [V,3].
@@ -178,7 +178,10 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
     Per-call settings (``None`` = the process-wide default of ``f3dg_set_option``): ``exact=True`` composites this call in the
     reference's float32 / float64 operation order (F3DG_FLAG_EXACT: what a consumer of the distortion channel wants), ``exact=False``
     in the fast arithmetic (F3DG_FLAG_FAST); ``tile_cull=False`` builds the reference's tile lists (F3DG_FLAG_NO_TILE_CULL);
-    ``small_path=False`` keeps one- and two-view calls on the general launch sequence (F3DG_FLAG_NO_SMALL_PATH).
+    ``small_path=False`` keeps one- and two-view calls on the general launch sequence (F3DG_FLAG_NO_SMALL_PATH);
+    ``scan=True`` (fast inference calls of the general launch sequence) composites with the split-pixel schedule of
+    csrc/f3dg_render5.hip (F3DG_FLAG_SCAN): same blended entries per pixel, sums associated as a segmented wave scan -- within 1e-4 of
+    the reference like every fast call, not bit-identical to ``scan=False``.
     """
     L = _lib.lib()
     device = means3D.device
@@ -212,6 +215,8 @@ def rasterize_views(means3D, opacities, viewmatrices, projmatrices, camposs, bg,
         flags |= _lib.FLAG_NO_TILE_CULL
     if small_path is not None and not small_path:
         flags |= _lib.FLAG_NO_SMALL_PATH
+    if scan:
+        flags |= _lib.FLAG_SCAN
 
     means3D = _dev_f32(means3D, device)
     sh = _dev_f32(sh, device)

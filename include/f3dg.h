@@ -77,11 +77,18 @@ extern "C" {
  *   F3DG_FLAG_FAST           ... runs the fast arithmetic, also with F3DG_FLAG_SAVE_AUX (the backward repeats the forward's alpha from the
  *                            workspace header, so the pair stays consistent); EXACT wins when both are given;
  *   F3DG_FLAG_NO_TILE_CULL   the reference's tile lists (every tile of the 3-sigma square, forward.cu:364-374) instead of the culled ones;
- *   F3DG_FLAG_NO_SMALL_PATH  the general launch sequence also for the shapes the three-launch small-call path serves. */
+ *   F3DG_FLAG_NO_SMALL_PATH  the general launch sequence also for the shapes the three-launch small-call path serves;
+ *   F3DG_FLAG_SCAN           (inference calls in the fast arithmetic, general launch sequence) the split-pixel compositing schedule of
+ *                            csrc/f3dg_render5.hip: the entries of the pixels that hold a quadrant back are blended by helper lanes and
+ *                            combined by a segmented wave scan. The set of blended entries per pixel is unchanged, the sums are associated
+ *                            differently: every channel within the 1e-4 of the fast arithmetic against the reference, NOT bit-identical
+ *                            to a call without the flag. Ignored with F3DG_FLAG_EXACT / F3DG_FLAG_SAVE_AUX (option "render_scan" sets the
+ *                            process default: -1 flag only, 1 every eligible call, 0 never). */
 #define F3DG_FLAG_EXACT 16u
 #define F3DG_FLAG_FAST 32u
 #define F3DG_FLAG_NO_TILE_CULL 64u
 #define F3DG_FLAG_NO_SMALL_PATH 128u
+#define F3DG_FLAG_SCAN 256u
 
 #define F3DG_TILE 16             /* BLOCK_X = BLOCK_Y = 16, RAST/cuda_rasterizer/config.h:16-17 */
 #define F3DG_OUT_CHANNELS 9      /* RGB, normal xyz, median depth, alpha, distortion: auxiliary.h:21-24 */
@@ -430,6 +437,9 @@ int f3dg_debug_render_counts(unsigned long long* h_out8, int reset);
  * staged, scanned, fused trips, slides, lane-trips of fused trips, waves, packed batches (= dense trips), blend trips of the batches,
  * pairs evaluated in dense trips, pairs that reached a blend trip, 0 ... }. */
 int f3dg_debug_render4_counts(unsigned long long* h_out, int reset);
+/* The same for render5_fwd_kernel (F3DG_FLAG_SCAN): h_out[16] = { staged, scanned, fused trips, slides, lane-trips of fused trips, waves,
+ * dense batches, pairs in dense batches, pixels compacted, slides with a compaction, 0... }. */
+int f3dg_debug_render5_counts(unsigned long long* h_out, int reset);
 /* Debug: shader clocks of the roles of the small-launch pipeline kernel (render3q_fwd_kernel, options render_split = 2 / 3 and
  * render_count = 1), summed over the launches since the last reset of f3dg_debug_render4_counts. h_out[4][16]: rows { consumer,
  * evaluators, producer } x { total, waiting at the window barrier, waiting for a round counter, windows, rounds, waves }; row 3 =

@@ -158,7 +158,7 @@ def frac_within(a, b, atol, rtol=0.0):
     return float(np.mean(d <= atol + rtol * np.abs(b)))
 
 
-def assert_render_parity(hip_out, ora_out, label=""):
+def assert_render_parity(hip_out, ora_out, label="", dist_big_rtol=1e-3):
     """SURVEY section 8d 'Parity check used with timing' -- tolerance 1e-4 (north_star), robust to the isolated
     pixels a 1-ulp expf difference can flip at the alpha<1/255, T<1e-4 and T>0.5 discontinuities."""
     rgb_h, rgb_o = hip_out[0:3], ora_out[0:3]
@@ -180,5 +180,5 @@ def assert_render_parity(hip_out, ora_out, label=""):
     # ... and where the channel is well conditioned (values above 1e-4: scenes with a real depth spread), SURVEY 8d's rel 1e-3
     big = np.abs(ora_out[8]) > 1e-4
     if big.any():
-        assert frac_within(hip_out[8][big], ora_out[8][big], 0.0, 1e-3) >= 0.999, \
-            f"{label} distortion (rel 1e-3 on {int(big.sum())} px): {frac_within(hip_out[8][big], ora_out[8][big], 0.0, 1e-3)}"
+        assert frac_within(hip_out[8][big], ora_out[8][big], 0.0, dist_big_rtol) >= 0.999, \
+            f"{label} distortion (rel {dist_big_rtol:g} on {int(big.sum())} px): {frac_within(hip_out[8][big], ora_out[8][big], 0.0, dist_big_rtol)}"
