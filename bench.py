@@ -467,6 +467,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                       "phase2_trips_of_slides_with_at_most_8_live_pixels": int(cbuf[6]), "..._at_most_24": int(cbuf[7]),
                       "slides_with_at_most_8_live_pixels": int(cbuf[8]), "slides_with_at_most_24": int(cbuf[9]),
                       "tail_steps": int(cbuf[10]), "tail_wave_trips": int(cbuf[11]), "tail_entries_tested": int(cbuf[12]),
+                      "staged_entries_reaching_a_live_pixel": int(cbuf[13]),
                       "note": "one untimed step with option render_count = 1 (the same kernel with work counters); staged entries count "
                               "a list entry once per quadrant wave that gathers its record"}
 

@@ -62,16 +62,16 @@ SIGNATURES = {
     "f3dg_group_norm_silu_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
     "f3dg_group_norm_silu_pb": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p]),
     "f3dg_group_norm_silu_pb_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p]),
-    "f3dg_group_norm_silu_nhwc_pb": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
-    "f3dg_group_norm_silu_nhwc_pb_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
+    "f3dg_group_norm_silu_nhwc_pb": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _sz]),
+    "f3dg_group_norm_silu_nhwc_pb_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _sz]),
     "f3dg_group_norm_silu_pb_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p]),
-    "f3dg_group_norm_silu_nhwc_pb_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
+    "f3dg_group_norm_silu_nhwc_pb_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p, _p, _sz]),
     "f3dg_group_norm_nhwc_scratch_bytes": (C.c_size_t, [_i, _i, _i]),
     "f3dg_residual_join_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p]),
     "f3dg_residual_join": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p]),
     "f3dg_residual_join_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p]),
-    "f3dg_group_norm_silu_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p]),
-    "f3dg_group_norm_silu_nhwc_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p]),
+    "f3dg_group_norm_silu_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p, _sz]),
+    "f3dg_group_norm_silu_nhwc_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p, _sz]),
     "f3dg_set_option": (_i, [C.c_char_p, _i]),
     "f3dg_profile_enable": (_i, [_i]),
     "f3dg_debug_launch_count": (C.c_longlong, [_i]),

@@ -143,39 +143,50 @@ int g_f3dg_debug_skip_all = 0;       // experiment switch: pre-test threshold = 
 
 extern "C" int f3dg_set_option(const char* name, int value)
 {
-    if (name && strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_kernel") == 0) { g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3; if (value == 4) g_f3dg_render_pack = 1; return F3DG_OK; }
-    if (name && strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_scan") == 0) { g_f3dg_render_scan = value < 0 ? -1 : value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_scan_th") == 0) { g_f3dg_render_scan_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
-    if (name && strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) { std::lock_guard<std::mutex> lock(g_small_mutex); g_small_disabled.clear(); } return F3DG_OK; }
-    if (name && strcmp(name, "small_path_aux") == 0) { g_f3dg_small_path_aux = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "small_debug") == 0) { g_f3dg_small_debug = value; return F3DG_OK; }
-    if (name && strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = (value >= 2 && value <= 6) ? value : 5; return F3DG_OK; }
-    if (name && strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_split") == 0) { g_f3dg_render_split = value < 0 ? F3DG_RENDER_SPLIT_DEFAULT : value > 3 ? 3 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_unroll") == 0) { g_f3dg_render_unroll = value < 0 ? F3DG_RENDER_UNROLL_DEFAULT : value < 1 ? 1 : value > 2 ? 2 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value < 0 ? 1 : value > 64 ? 64 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_count") == 0) { g_f3dg_render_count = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_tail") == 0) { g_f3dg_render_tail = value < 0 ? F3DG_RENDER_TAIL_DEFAULT : value > 64 ? 64 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_wpb") == 0) { g_f3dg_render_wpb = value == 4 ? 4 : 1; return F3DG_OK; }
-#ifdef F3DG_LAB
-    if (name && strcmp(name, "render_replay") == 0) { g_f3dg_render_replay = value; return F3DG_OK; }
+    if (!name) return F3DG_ERR_BAD_ARG;
+    // ---- the options of the library (process-wide DEFAULTS: what a call's own flags do not say; include/f3dg.h)
+    if (strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
+    if (strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
+    if (strcmp(name, "small_path") == 0) { g_f3dg_small_path = value != 0; if (value == 2) { std::lock_guard<std::mutex> lock(g_small_mutex); g_small_disabled.clear(); } return F3DG_OK; }
+    if (strcmp(name, "small_path_aux") == 0) { g_f3dg_small_path_aux = value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
+    if (strcmp(name, "render_scan") == 0) { g_f3dg_render_scan = value < 0 ? -1 : value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_scan_th") == 0) { g_f3dg_render_scan_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
+    if (strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value < 0 ? 1 : value > 64 ? 64 : value; return F3DG_OK; }
+    if (strcmp(name, "render_unroll") == 0) { g_f3dg_render_unroll = value < 0 ? F3DG_RENDER_UNROLL_DEFAULT : value < 1 ? 1 : value > 2 ? 2 : value; return F3DG_OK; }
+    if (strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = (value >= 2 && value <= 6) ? value : 5; return F3DG_OK; }
+    // diagnostics
+    if (strcmp(name, "render_count") == 0) { g_f3dg_render_count = value != 0; return F3DG_OK; }
+    if (strcmp(name, "time_launches") == 0) { g_f3dg_time_launches = value != 0; return F3DG_OK; }
+#ifndef F3DG_LAB
+    // small launches: 1 = producer + consumer waves (render3p), 2 / 3 = consumer + evaluators + producer (render3q, one view); -1 / 0 = by arithmetic
+    if (strcmp(name, "render_split") == 0) { g_f3dg_render_split = value < 1 ? F3DG_RENDER_SPLIT_DEFAULT : value > 3 ? 3 : value; return F3DG_OK; }
+#else
+    // ---- lab builds (-DF3DG_LAB: builder-side experiments; the default library neither compiles the kernels behind these nor knows the names)
+    if (strcmp(name, "render_split") == 0) { g_f3dg_render_split = value < 0 ? F3DG_RENDER_SPLIT_DEFAULT : value > 3 ? 3 : value; return F3DG_OK; }   // 0: render3l
+    if (strcmp(name, "render_kernel") == 0) {       // 1 / 2 / 3: the kernel generations; 4: shorthand for render3s + the packed kernel everywhere
+        g_f3dg_render_kernel = value == 1 ? 1 : value == 2 ? 2 : 3;
+        g_f3dg_render_pack = value == 4 ? 1 : -1;   // (leaving the shorthand restores the default: ADVICE r05)
+        return F3DG_OK;
+    }
+    if (strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_slide") == 0) { g_f3dg_render_slide = value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_tail") == 0) { g_f3dg_render_tail = value < 0 ? F3DG_RENDER_TAIL_DEFAULT : value > 64 ? 64 : value; return F3DG_OK; }
+    if (strcmp(name, "render_wpb") == 0) { g_f3dg_render_wpb = value == 4 ? 4 : 1; return F3DG_OK; }
+    if (strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
+    if (strcmp(name, "render_lds_pad") == 0) { g_f3dg_render_lds_pad = value < 0 ? 0 : value; return F3DG_OK; }
+    if (strcmp(name, "render_replay") == 0) { g_f3dg_render_replay = value; return F3DG_OK; }
+    if (strcmp(name, "small_debug") == 0) { g_f3dg_small_debug = value; return F3DG_OK; }
+    if (strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
+    if (strcmp(name, "sort_fused_rects") == 0) { g_f3dg_sort_fused_rects = value != 0; return F3DG_OK; }
+    if (strcmp(name, "pre_hoist") == 0) { g_f3dg_pre_hoist = value != 0; return F3DG_OK; }
+    if (strcmp(name, "pre_order") == 0) { g_f3dg_pre_order = value & 3; return F3DG_OK; }
+    if (strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
 #endif
-    if (name && strcmp(name, "render_dma") == 0) { g_f3dg_render_dma = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "render_round") == 0) { g_f3dg_render_round = value == 256 ? 256 : 192; return F3DG_OK; }
-    if (name && strcmp(name, "render_fast") == 0) { g_f3dg_render_fast = value < 0 ? 0 : value > 2 ? 2 : value; return F3DG_OK; }
-    if (name && strcmp(name, "render_cull") == 0) { g_f3dg_render_cull = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "sort_wide_groups") == 0) { g_f3dg_sort_wide_groups = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "pre_hoist") == 0) { g_f3dg_pre_hoist = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "sort_fused_rects") == 0) { g_f3dg_sort_fused_rects = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "tile_cull") == 0) { g_f3dg_tile_cull = value != 0; return F3DG_OK; }
-    if (name && strcmp(name, "pre_order") == 0) { g_f3dg_pre_order = value & 3; return F3DG_OK; }
-    if (name && strcmp(name, "debug_skip_all") == 0) { g_f3dg_debug_skip_all = value != 0; return F3DG_OK; }
     return F3DG_ERR_BAD_ARG;
 }
 
@@ -266,7 +277,11 @@ int f3dg_set_hip_error(hipError_t e, const char* where)
     return F3DG_ERR_HIP;
 }
 
-extern "C" const char* f3dg_version(void) { return "f3dg-hip gfx950 0.1.0"; }
+#ifdef F3DG_LAB
+extern "C" const char* f3dg_version(void) { return "f3dg-hip gfx950 0.2.0 lab"; }
+#else
+extern "C" const char* f3dg_version(void) { return "f3dg-hip gfx950 0.2.0"; }
+#endif
 extern "C" const char* f3dg_last_error(void) { return g_last_error; }
 
 int f3dg_sort_passes(int V, int T);

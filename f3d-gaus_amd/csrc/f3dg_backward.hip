@@ -131,6 +131,7 @@ __device__ __forceinline__ double row_total(double v)
     return v;
 }
 
+#ifdef F3DG_LAB      // ---- rounds 1-2: the lock-step and the four-wave compositing backward, lab builds only
 __global__ void __launch_bounds__(F3DG_BLOCK)
 render_bwd_lockstep_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                   const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
@@ -698,6 +699,8 @@ render_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     if (lane == 0 && n_pairs)
         atomicAdd(&hdr->bwd_pairs, (unsigned long long)n_pairs);
 }
+
+#endif // F3DG_LAB (render_bwd_lockstep_kernel, render_bwd_kernel)
 
 // ---- render3's counterpart: ONE wave64 per 8x8 quadrant, no workgroup barriers (the default) ------------------------------------
 // Same arithmetic per contributing (pixel, Gaussian) pair and the same transposed wave reduction as render_bwd_kernel above. What
@@ -1372,7 +1375,12 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     F3DG_HIP_CHECK(hipMemsetAsync(&hdr->bwd_pairs, 0, sizeof(hdr->bwd_pairs), s));
     const int prof = f3dg_prof_bwd_begin(s);
 
-    if (g_f3dg_render_cull && g_f3dg_render_kernel == 3) {
+#ifdef F3DG_LAB
+    const bool bwd3 = g_f3dg_render_cull && g_f3dg_render_kernel == 3;
+#else
+    const bool bwd3 = true;
+#endif
+    if (bwd3) {
 #define F3DG_LAUNCH_BWD3(OCC) F3DG_KLAUNCH((render3_bwd_kernel<OCC>), dim3((unsigned)n_views * (unsigned)T * 4u), dim3(64), 0, s, n_views, P, W, H,  \
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),                                        \
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const unsigned*>(ws + L.small_list), reinterpret_cast<const F3dgRec*>(ws + L.rec),                        \
@@ -1383,7 +1391,9 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
         if (g_f3dg_bwd_occ == 4) F3DG_LAUNCH_BWD3(4); else if (g_f3dg_bwd_occ == 6) F3DG_LAUNCH_BWD3(6); else if (g_f3dg_bwd_occ == 3) F3DG_LAUNCH_BWD3(3);
         else if (g_f3dg_bwd_occ == 2) F3DG_LAUNCH_BWD3(2); else F3DG_LAUNCH_BWD3(5);
 #undef F3DG_LAUNCH_BWD3
-    } else if (g_f3dg_render_cull)
+    }
+#ifdef F3DG_LAB
+    else if (g_f3dg_render_cull)
         F3DG_KLAUNCH(render_bwd_kernel, dim3((unsigned)n_views * (unsigned)T), dim3(F3DG_BLOCK), 0, s, n_views, P, W, H,
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const unsigned*>(ws + L.small_list), reinterpret_cast<const F3dgRec*>(ws + L.rec),
@@ -1400,6 +1410,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
                            background, (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
                            reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor,
                            acc);
+#endif
     f3dg_prof_bwd_mark(prof, 0, s);
     F3DG_KLAUNCH(preprocess_bwd_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, P,
                        D, M, means3D, radii_used, shs, reinterpret_cast<const unsigned char*>(ws + L.clamped), scales,

@@ -66,6 +66,8 @@ __device__ __forceinline__ F3dgPair f3dg_pair_eval(float ray_x, float ray_y, con
         if (NORMAL) {
             const float ninv = -__builtin_amdgcn_rsqf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)) + 1e-7f);
             pr.nn0 = n0 * ninv; pr.nn1 = n1 * ninv; pr.nn2 = n2 * ninv;
+            // (the branch-free recurrences give a rejected pair weight 0 instead of skipping it: its normal must be finite whatever the record holds)
+            if (SANITIZE && pr.alpha == 0.0f) { pr.nn0 = 0.0f; pr.nn1 = 0.0f; pr.nn2 = 0.0f; }
         }
     } else {
         const double AA = aaf;

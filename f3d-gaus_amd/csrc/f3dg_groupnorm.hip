@@ -329,12 +329,17 @@ gn_nhwc_apply_kernel(int C, int HW, int groups, int rows, const T* __restrict__ 
     }
 }
 
+extern "C" size_t f3dg_group_norm_nhwc_scratch_bytes(int N, int HW, int groups);
+
 template <typename T>
 int launch_gn_nhwc(void* stream, int N, int C, int HW, int groups, const T* x, const float* pre_bias, const float* weight, const float* bias, float eps,
-                   int apply_silu, T* y, double* moments)
+                   int apply_silu, T* y, double* moments, size_t moments_bytes)
 {
     constexpr int PN = Packet<T>::N;
     if (N < 0 || C <= 0 || HW <= 0 || groups <= 0 || C % groups != 0 || !x || !weight || !bias || !y || !moments) return F3DG_ERR_BAD_ARG;
+    // the scratch grew when the statistics became atomics-free (round 5: a partial pair per workgroup): the caller says how much it
+    // handed over, an allocation sized by an older header is refused instead of being written past its end
+    if (N > 0 && moments_bytes < f3dg_group_norm_nhwc_scratch_bytes(N, HW, groups)) return F3DG_ERR_WORKSPACE;
     if (C % PN != 0 || C / PN > 256 || C > GN_NHWC_MAXC) return F3DG_ERR_BAD_ARG;   // whole 16-byte packets per pixel, one packet column per thread
     if (N == 0) return F3DG_OK;
     if (((uintptr_t)x | (uintptr_t)y) & 15u) return F3DG_ERR_BAD_ARG;
@@ -481,35 +486,35 @@ extern "C" int f3dg_group_norm_silu_pb_f16(void* stream, int N, int C, int HW, i
 
 // ... and channels-last
 extern "C" int f3dg_group_norm_silu_nhwc_pb_f16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
-                                                const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments)
+                                                const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments, size_t moments_bytes)
 {
     return launch_gn_nhwc<_Float16>(stream, N, C, HW, groups, reinterpret_cast<const _Float16*>(x), pre_bias, weight, bias, eps, apply_silu,
-                                    reinterpret_cast<_Float16*>(y), moments);
+                                    reinterpret_cast<_Float16*>(y), moments, moments_bytes);
 }
 
 extern "C" int f3dg_group_norm_silu_nhwc_pb(void* stream, int N, int C, int HW, int groups, const float* x, const float* pre_bias, const float* weight,
-                                            const float* bias, float eps, int apply_silu, float* y, double* moments)
+                                            const float* bias, float eps, int apply_silu, float* y, double* moments, size_t moments_bytes)
 {
-    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y, moments);
+    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y, moments, moments_bytes);
 }
 
 extern "C" int f3dg_group_norm_silu_nhwc_pb_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
-                                                 const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments)
+                                                 const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments, size_t moments_bytes)
 {
-    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y, moments);
+    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, pre_bias, weight, bias, eps, apply_silu, y, moments, moments_bytes);
 }
 
 // GroupNorm (+ SiLU) of a channels-last tensor, x and y [N][HW][C]; `moments` is scratch of f3dg_group_norm_nhwc_scratch_bytes(N, HW, groups) bytes
 extern "C" int f3dg_group_norm_silu_nhwc(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
-                                         const float* bias, float eps, int apply_silu, float* y, double* moments)
+                                         const float* bias, float eps, int apply_silu, float* y, double* moments, size_t moments_bytes)
 {
-    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y, moments);
+    return launch_gn_nhwc<float>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y, moments, moments_bytes);
 }
 
 extern "C" int f3dg_group_norm_silu_nhwc_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
-                                              const float* bias, float eps, int apply_silu, uint16_t* y, double* moments)
+                                              const float* bias, float eps, int apply_silu, uint16_t* y, double* moments, size_t moments_bytes)
 {
-    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y, moments);
+    return launch_gn_nhwc<unsigned short>(stream, N, C, HW, groups, x, nullptr, weight, bias, eps, apply_silu, y, moments, moments_bytes);
 }
 
 extern "C" int f3dg_group_norm_silu(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,

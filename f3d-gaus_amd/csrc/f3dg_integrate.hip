@@ -130,6 +130,7 @@ __device__ __forceinline__ bool ray_apply(Pass1State& st, const RayEval& e, cons
     return true;
 }
 
+#ifdef F3DG_LAB      // ---- round 1's per-pixel pass and its plain variant, lab builds only (the baseline of the bit-identity tests)
 template <bool FILTER>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 integrate_pass1_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, const F3dgHeader* __restrict__ hdr,
@@ -292,6 +293,8 @@ integrate_pass1_kernel(int W, int H, int tiles_x, float focal_x, float focal_y, 
         out_color[7 * HW + pix_id] = st.C7;
     }
 }
+
+#endif // F3DG_LAB (integrate_pass1_kernel)
 
 // The same pass with the culling machinery of the compositing forward (f3dg_render.hip: render2): the per-ray K pre-test above costs
 // ~25 instructions per (ray, Gaussian) = 125 per (pixel, list entry), and no pixel ever leaves the loop early here (a saturated ray
@@ -1057,8 +1060,13 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int V, int P, int W, int H, float
     unsigned* n_contrib = reinterpret_cast<unsigned*>(ws + L.n_contrib);
     unsigned short* contrib_ids = reinterpret_cast<unsigned short*>(ws + I.contrib_ids);
     unsigned* contrib_n = reinterpret_cast<unsigned*>(ws + I.contrib_n);
-    if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 3) {
-        // the default: 545 shared rays per tile, then the per-pixel kernel on the tiles that hit the contributor limit (normally none)
+#ifdef F3DG_LAB
+    const bool rays = g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 3;
+#else
+    const bool rays = true;
+#endif
+    if (rays) {
+        // 545 shared rays per tile, then the per-pixel kernel on the tiles that hit the contributor limit (normally none)
         unsigned* redo = reinterpret_cast<unsigned*>(ws + I.redo);
         F3DG_KLAUNCH(integrate_pass1_rays_kernel, dim3((unsigned)V * (unsigned)T), dim3(F3DG_RAYS_THREADS), 0, s, V, P, T, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
@@ -1066,7 +1074,9 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int V, int P, int W, int H, float
         F3DG_KLAUNCH(integrate_pass1_cull_kernel, dim3((unsigned)V * (unsigned)T), dim3(F3DG_BLOCK), 0, s, V, P, T, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n, redo);
-    } else if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 2)
+    }
+#ifdef F3DG_LAB
+    else if (g_f3dg_render_pretest && g_f3dg_render_cull && g_f3dg_render_kernel >= 2)
         F3DG_KLAUNCH(integrate_pass1_cull_kernel, dim3((unsigned)V * (unsigned)T), dim3(F3DG_BLOCK), 0, s, V, P, T, W, H, tiles_x, focal_x, focal_y,
                            hdr, ranges, point_list, rec, reinterpret_cast<const float4*>(ws + L.cull), background,
                            out_color, final_T, n_contrib, contrib_ids, contrib_n, (const unsigned*)nullptr);
@@ -1084,6 +1094,9 @@ int f3dg_launch_integrate_pass1(hipStream_t s, int V, int P, int W, int H, float
                                    out_color + (size_t)v * F3DG_OUT_CHANNELS * HW, final_T + (size_t)v * 4 * HW, n_contrib + (size_t)v * 2 * HW,
                                    contrib_ids + (size_t)v * HW * F3DG_MAX_CONTRIB, contrib_n + (size_t)v * HW);
         }
+#else
+    (void)HW;
+#endif
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

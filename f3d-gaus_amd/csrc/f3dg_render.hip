@@ -182,6 +182,7 @@ __device__ __forceinline__ bool blend_entry_fast(PixelState& st, unsigned contri
     return false;
 }
 
+#ifdef F3DG_LAB      // ---- generation 1, lab builds only (the plain-transcription baseline of the bit-identity tests)
 #define F3DG_ROUND (F3DG_BLOCK - 1)     // list entries staged per round; LDS slot F3DG_ROUND is the sentinel
 
 template <bool SAVE_AUX, bool PRETEST, bool CULL, bool QUEUE, bool FAST>
@@ -420,6 +421,8 @@ render_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x,
     }
 }
 
+#endif // F3DG_LAB (render_fwd_kernel)
+
 // =====================================================================================================================
 // render2: the same compositing with phase 1 turned around -- GAUSSIANS across the lanes instead of pixels.
 //
@@ -468,6 +471,7 @@ __device__ unsigned long long g_f3dg_timing[8];
 #define F3DG_T_FLUSH do { } while (0)
 #endif
 
+#ifdef F3DG_LAB      // ---- generation 2, lab builds only
 template <bool SAVE_AUX, bool FAST, int ROUND, int OCC>
 __global__ void __launch_bounds__(F3DG_BLOCK, OCC)
 render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
@@ -664,6 +668,8 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     }
 }
 
+#endif // F3DG_LAB (render2_fwd_kernel)
+
 // =====================================================================================================================
 // render3: ONE wave64 per 8x8 pixel quadrant of a tile -- no workgroup barriers, nothing shared between waves.
 //
@@ -708,6 +714,7 @@ render2_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 #define F3DG_R3_RING 128            // queue ring of (list position, id) pairs
 #define F3DG_R3_FLAG 0x80000000u    // contributor values of the current window are slots (flag | slot) until the window ends
 
+#ifdef F3DG_LAB      // ---- generation 3 with fixed windows, lab builds only
 template <bool SAVE_AUX, bool FAST, bool DMA, int OCC>
 __global__ void __launch_bounds__(64, OCC)
 render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
@@ -877,6 +884,8 @@ render3_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     }
 }
 
+#endif // F3DG_LAB (render3_fwd_kernel)
+
 // ---- render3 with a SLIDING window (the default) ----------------------------------------------------------------------------------
 // With fixed 64-entry windows every lane waits at the end of a window for the lane with the most passing entries: the CPU model
 // (tests/tools/wave1_model.py) puts the lane utilisation of phase 2 at 0.54. Here the 64 staged entries are two halves of 32; a slide
@@ -952,7 +961,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         }
     };
 
-    unsigned n_tail_steps = 0, n_tail_trips = 0, n_tail_tests = 0;
+    unsigned n_tail_steps = 0, n_tail_trips = 0, n_tail_tests = 0, n_useful = 0;
     bool go_tail = false;
     unsigned n_staged = 0, n_trips = 0, n_wave_trips = 0, n_slides = 0, n_t8 = 0, n_t24 = 0, n_s8 = 0, n_s24 = 0;    // COUNT (option render_count): what this wave did, summed into g_f3dg_counts at its end
     unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
@@ -1028,6 +1037,12 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
                 cdy[q] = ec * dyy[q] * dyy[q];
             }
             half_ballots<0>(fresh, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
+        }
+        if (COUNT) {        // staged entries that reach at least one pixel that is still alive (the others were gathered for nothing)
+            unsigned u = done ? 0u : (unsigned)fresh;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) u |= (unsigned)__shfl_xor((int)u, o, 64);
+            n_useful += (unsigned)__popc(u);
         }
         // ---- slide: the newer half becomes the older one, the fresh bits the newer one
         pass = (pass >> 32) | (done ? 0ull : ((unsigned long long)(unsigned)fresh << 32));
@@ -1184,6 +1199,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         atomicAdd(&c[10], (unsigned long long)n_tail_steps);
         atomicAdd(&c[11], (unsigned long long)n_tail_trips);
         atomicAdd(&c[12], (unsigned long long)n_tail_tests);
+        atomicAdd(&c[13], (unsigned long long)n_useful);
         atomicAdd(&c[0], (unsigned long long)n_staged);
         atomicAdd(&c[1], (unsigned long long)(cursor < n ? cursor : n));
         atomicAdd(&c[2], (unsigned long long)n_wave_trips);
@@ -1323,6 +1339,7 @@ render3s_stage_only_kernel(int V, int P, int W, int H, int tiles_x, int T, const
 }
 #endif
 
+#ifdef F3DG_LAB      // ---- the one-wave kernel for small launches, lab builds only (superseded by render3p / render3q)
 // ---- render3 for SMALL launches: the next window's gathers in flight behind phase 2 ------------------------------------------------
 // A call of one or two 256^2 views is 1,024-2,048 waves on a chip that holds 8,192: every wave is alone on its SIMD and its time is a
 // chain of latencies -- list ids, record gathers, the dependent instructions of a phase-2 trip -- that no other wave fills. At that
@@ -1494,6 +1511,8 @@ render3l_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     }
 }
 
+#endif // F3DG_LAB (render3l_fwd_kernel)
+
 } // namespace
 
 namespace {
@@ -1507,7 +1526,120 @@ void note_kernel(const char* base, int save_aux, int fast, const char* extra)
 
 int f3dg_render_uses_fast(int save_aux) { return g_f3dg_render_fast == 2 || (g_f3dg_render_fast == 1 && !save_aux); }
 
+namespace {
+
+// what every compositing launch is handed
+struct RenderArgs {
+    hipStream_t s;
+    int V, P, W, H, tiles_x, T;
+    float focal_x, focal_y;
+    const F3dgHeader* hdr;
+    const uint2* ranges;
+    const unsigned* point_list;
+    const F3dgRec* rec;
+    const float4* cull;
+    const float* background;
+    int bg_per_view;
+    float* out_color;
+    float* final_T;
+    unsigned* n_contrib;
+};
+
+// render3s_fwd_kernel, one quadrant wave per workgroup, 8 waves per SIMD (every variant fits 64 VGPRs and 5 KB of LDS)
+template <bool AUX, bool FAST, bool NORMAL, bool DIST, bool COUNT>
+void launch3s(const RenderArgs& a)
+{
+    F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FAST, 8, 1, NORMAL, DIST, COUNT, false>), dim3((unsigned)a.V * (unsigned)a.T * 4u), dim3(64), 0, a.s,
+                 a.V, a.P, a.W, a.H, a.tiles_x, a.T, a.focal_x, a.focal_y, a.hdr, a.ranges, a.point_list, a.rec, a.cull, a.background, a.bg_per_view,
+                 a.out_color, a.final_T, a.n_contrib, 0);
+}
+
+} // namespace
+
+#ifdef F3DG_LAB
+// lab builds: the launches only an option of the lab reaches (kernel generations 1-3, render3l, the tail schedule, four-wave workgroups,
+// LDS padding, the staging replay). Returns false when the launch is the default dispatch's.
+static bool f3dg_launch_render_lab(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
+                                   const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
+                                   const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
+                                   float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels, int fast, int* rc_out);
+#endif
+
+// The compositing forward of a call. The arithmetic is the CALL's (f3dg_forward_sets resolves its flags against the process default and
+// records the choice in the workspace header for the backward): fast arithmetic is for inference calls -- a SAVE_AUX forward feeds
+// f3dg_backward, which rebuilds every pixel's transmittance back to front by dividing final_T by (1 - alpha) with ITS alphas: they must be
+// the forward's to the bit, or the 1e-6 relative difference is amplified by 1 / (1 - alpha) per layer (measured at C5: compositing-stage
+// gradients 2.5e-5 instead of 1.8e-6 off the oracle).
 int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
+                       const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
+                       const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
+                       float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels, int fast_arg, int scan)
+{
+    const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    const int T = tiles_x * tiles_y;
+    const int fast = fast_arg < 0 ? f3dg_render_uses_fast(save_aux) : fast_arg;
+    const long long waves = (long long)V * T * 4;           // one wave per 8 x 8 pixel quadrant
+#ifdef F3DG_LAB
+    {
+        int rc = F3DG_OK;
+        if (f3dg_launch_render_lab(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, bbox, cull, background, bg_per_view, out_color,
+                                   final_T, n_contrib, save_aux, skip_channels, fast, &rc))
+            return rc;
+    }
+#else
+    (void)bbox;
+#endif
+    // (1) small launches -- at most two waves per SIMD: one or two 256^2 views -- are latency chains nobody fills
+    const bool small_launch = g_f3dg_render_lowocc && waves <= (g_f3dg_render_lowocc > 1 ? 1024ll * g_f3dg_render_lowocc : 2048ll);
+    // (2) the split-pixel schedule of f3dg_render5.hip: fast inference launches that ask for it (F3DG_FLAG_SCAN, whatever their size) or,
+    // with option render_scan 1, every such launch that is not small
+    if (fast && !save_aux && g_f3dg_render_scan != 0 && (scan || (g_f3dg_render_scan == 1 && !small_launch)))
+        return f3dg_launch_render5(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
+                                   skip_channels, g_f3dg_render_count);
+    if (small_launch) {
+        // the multi-wave kernels of f3dg_render4.hip. Defaults by measurement at 65,536 pixel-ordered Gaussians (profiles/r05_final/
+        // one_view.md): fast arithmetic -- producer + consumer waves, two entries per trip (render3p, 76.6 -> 57.9 us; two views 79.7 ->
+        // 63.6 us per call); the reference's arithmetic -- consumer + three evaluator waves + producer for one view (render3q, 134 -> 100 us:
+        // its LDS does not fit two quadrants per SIMD), render3p for two
+        const bool one_view = waves <= 1024ll;
+        const int split = g_f3dg_render_split >= 1 ? g_f3dg_render_split : fast ? 1 : one_view ? 3 : 1;
+        const int unroll = g_f3dg_render_unroll >= 1 ? g_f3dg_render_unroll : fast ? 2 : 1;
+        return f3dg_launch_render_small(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
+                                        fast, save_aux, final_T, n_contrib, unroll, split, g_f3dg_render_count);
+    }
+    // (3) the rank-packed kernel of f3dg_render4.hip (option render_pack: 1 = every launch, -1 = the default: launches in the reference's
+    // arithmetic, whose stateless part is 2.5 x as long -- measured -38 % on the real merged set, -6 % at C2; in fast arithmetic the packed
+    // trips' hand-over costs what they save: 8.4-8.7 against 8.6 ms). A SAVE_AUX forward in the reference's
+    // arithmetic takes it too (its auxiliary planes are bit-identical to render3s's).
+    if (g_f3dg_render_pack == 1 || (g_f3dg_render_pack < 0 && !fast))
+        return f3dg_launch_render4(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
+                                   fast, skip_channels, g_f3dg_render_count, save_aux, final_T, n_contrib);
+    // (4) render3s_fwd_kernel: one wave per quadrant, sliding half-windows
+    const RenderArgs a = { s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color, final_T, n_contrib };
+    // the batched loops of the build that consume RGB, depth and alpha only (cycle aggregation, orbit frames) skip the normal and
+    // distortion accumulators: the channels they do write are bit-identical
+    const bool lean = !save_aux && (skip_channels & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION)) == (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION);
+    const bool count = g_f3dg_render_count && !save_aux;        // (diagnostic: the same kernel with its work counters on)
+    const char* extra = ", OCC=8, WPB=1";
+    if (count) {
+        if (fast) launch3s<false, true, true, true, true>(a); else launch3s<false, false, true, true, true>(a);
+        extra = ", OCC=8, WPB=1, COUNT=true";
+    } else if (lean) {
+        if (fast) launch3s<false, true, false, false, false>(a); else launch3s<false, false, false, false, false>(a);
+        extra = ", OCC=8, WPB=1, NORMAL=false, DIST=false";
+    } else if (save_aux) {
+        if (fast) launch3s<true, true, true, true, false>(a); else launch3s<true, false, true, true, false>(a);
+    } else {
+        if (fast) launch3s<false, true, true, true, false>(a); else launch3s<false, false, true, true, false>(a);
+    }
+    note_kernel("render3s_fwd_kernel", lean || count ? 0 : save_aux, fast, extra);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+#ifdef F3DG_LAB
+// ---- lab builds only: the dispatch of rounds 1-5 for the launches a lab option selects ------------------------------------------------
+static int f3dg_launch_render_lab_impl(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
                        const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
                        const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
                        float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels, int fast, int scan)
@@ -1656,6 +1788,27 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }
+
+
+static bool f3dg_launch_render_lab(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y,
+                                   const F3dgHeader* hdr, const uint2* ranges, const unsigned* point_list, const F3dgRec* rec,
+                                   const float4* bbox, const float4* cull, const float* background, int bg_per_view, float* out_color,
+                                   float* final_T, unsigned* n_contrib, int save_aux, unsigned skip_channels, int fast, int* rc_out)
+{
+    const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
+    const long long waves = (long long)V * tiles_x * tiles_y * 4;
+    const bool small_launch = g_f3dg_render_lowocc && waves <= (g_f3dg_render_lowocc > 1 ? 1024ll * g_f3dg_render_lowocc : 2048ll);
+    const bool lab = g_f3dg_render_kernel != 3 || !g_f3dg_render_slide || g_f3dg_render_tail > 0 || g_f3dg_render_wpb == 4 || g_f3dg_render_lds_pad != 0 ||
+                     (g_f3dg_render_replay >= 2 && !save_aux) || (small_launch && g_f3dg_render_split == 0);
+    if (!lab) return false;
+    const int keep_scan = g_f3dg_render_scan;
+    g_f3dg_render_scan = 0;                 // (a lab option overrides the split-pixel mode)
+    *rc_out = f3dg_launch_render_lab_impl(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, bbox, cull, background, bg_per_view, out_color,
+                                          final_T, n_contrib, save_aux, skip_channels, fast, 0);
+    g_f3dg_render_scan = keep_scan;
+    return true;
+}
+#endif // F3DG_LAB
 
 // debug: the work counters of the counting variant of the one-wave kernel (option render_count = 1), summed over all launches since
 // the last reset: h_out8[16] = { staged, scanned, wave trips, slides, lane-trips, waves, trips with <= 8 / <= 24 live pixels, slides with <= 8 / <= 24, 0... }

@@ -303,14 +303,25 @@ def _resolve(key, keep=0):
     """Checks the oldest unchecked calls of the stream until at most ``keep`` are left."""
     q = _PENDING.get(key)
     while q and len(q) > keep:
-        _resolve_one(q.pop(0))
+        try:
+            _resolve_one(q[0])      # (an exception while REPAIRING an overflow -- no memory for the grown workspace -- leaves the entry queued:
+        except Exception:           # the next call or flush() tries the repair again instead of losing it; a failed poll has released its
+            if "polled" not in q[0]:    # ticket and cannot be repeated)
+                q.pop(0)
+            raise
+        q.pop(0)
     if q is not None and not q:
         del _PENDING[key]
 
 
 def _resolve_one(p):
-    n = C.c_longlong(0)
-    rc = _lib.lib().f3dg_status_poll(p["ticket"], 1, C.byref(n))
+    if "polled" not in p:           # (the poll releases the ticket: a retry after a failed repair must not poll it again)
+        n = C.c_longlong(0)
+        rc = _lib.lib().f3dg_status_poll(p["ticket"], 1, C.byref(n))
+        if rc != _lib.ERR_OVERFLOW:
+            _lib.check(rc, "f3dg_status_poll")
+        p["polled"] = (rc, n)
+    rc, n = p["polled"]
     if rc == _lib.ERR_OVERFLOW:
         import warnings
         warnings.warn("f3dgaus_amd: a rasterizer call whose status check was deferred needed %d instances, more than its workspace "
@@ -368,13 +379,13 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
     and by the wrapper's inference path (`rasterize_nograd`)."""
     device = means3D.device
     key = (device.index, _raw_stream(device.index) if device.type == "cuda" else 0)
-    ws = None if needs_grad else _WS_CACHE.get(key)
 
     shape_key = (means3D.size(0), int(rs.image_width), int(rs.image_height), 1)
     deferred = _DEFERRED["on"] and not needs_grad and not rs.debug and device.type == "cuda"
     if deferred:
         _resolve(key, keep=_DEFERRED["depth"] - 1)      # the call `depth` calls back on this stream: its status has landed long ago
         deferred = shape_key in _CAP_HINT             # no capacity known yet: check this one at once
+    ws = None if needs_grad else _WS_CACHE.get(key)     # (after the checks: a repair replaces the cached workspace by a larger one)
 
     def call(check=True, out=None, radii=None, workspace=ws, max_rendered=None):
         return rasterize_views(

@@ -157,9 +157,10 @@ class GroupNorm(nn.Module):
                 N, Cc = x.shape[0], x.shape[1]
                 HW = x.shape[2] * x.shape[3]
                 mom = torch.empty(L.f3dg_group_norm_nhwc_scratch_bytes(N, HW, self.num_groups) // 8 + 1, dtype=torch.float64, device=x.device)
+                mom_bytes = mom.numel() * 8
                 fn = getattr(L, "f3dg_group_norm_silu_nhwc_pb" + _KERNEL_SUFFIX[x.dtype])
                 rc = fn(_stream(), N, Cc, x.shape[2] * x.shape[3], self.num_groups, _lib.ptr(x), _lib.ptr(pre_bias), _lib.ptr(self.weight),
-                        _lib.ptr(self.bias), float(self.eps), 1 if silu else 0, _lib.ptr(y), _lib.ptr(mom))
+                        _lib.ptr(self.bias), float(self.eps), 1 if silu else 0, _lib.ptr(y), _lib.ptr(mom), mom_bytes)
                 _lib.check(rc, "f3dg_group_norm_silu_nhwc_pb")
                 return y
             xc = x.contiguous()

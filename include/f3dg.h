@@ -319,12 +319,14 @@ int f3dg_group_norm_silu_bf16(void* stream, int N, int C, int HW, int groups, co
  * transposes around them): x, y [N,HW,C] contiguous, C a multiple of 4 (float32) / 8 (bfloat16) and at most 1024;
  * `moments` is scratch of f3dg_group_norm_nhwc_scratch_bytes(N, HW, groups) bytes: one (sum, sum of squares) pair per workgroup, sample
  * and group, added up in workgroup order by a second-stage kernel -- no atomics, the statistics are bit-reproducible from run to run
- * (round 5; until then the workgroups added into 8 atomic slots in arrival order). Same statistics, same formula. */
+ * (round 5; until then the workgroups added into 8 atomic slots in arrival order). Same statistics, same formula.
+ * `moments_bytes` = the size of the buffer behind `moments` (round 6: the scratch has grown with the kernel once -- a buffer smaller than
+ * f3dg_group_norm_nhwc_scratch_bytes() is refused with F3DG_ERR_WORKSPACE instead of being written past its end). */
 size_t f3dg_group_norm_nhwc_scratch_bytes(int N, int HW, int groups);
 int f3dg_group_norm_silu_nhwc(void* stream, int N, int C, int HW, int groups, const float* x, const float* weight,
-                              const float* bias, float eps, int apply_silu, float* y, double* moments);
+                              const float* bias, float eps, int apply_silu, float* y, double* moments, size_t moments_bytes);
 int f3dg_group_norm_silu_nhwc_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* weight,
-                                   const float* bias, float eps, int apply_silu, uint16_t* y, double* moments);
+                                   const float* bias, float eps, int apply_silu, uint16_t* y, double* moments, size_t moments_bytes);
 /* The four GroupNorm entry points with the bias of the convolution that produced x folded in: y = gn(x + pre_bias[c]) (pre_bias [C]
  * float32, may be null). PyTorch-ROCm applies a convolution's bias as a separate elementwise pass behind MIOpen's kernel
  * (src/gaussian_predictor.py:163-178 `x = conv2d(x, w) ; x = x.add_(b)`); the residual blocks hand it to the GroupNorm that follows. */
@@ -333,15 +335,15 @@ int f3dg_group_norm_silu_pb(void* stream, int N, int C, int HW, int groups, cons
 int f3dg_group_norm_silu_pb_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias, const float* weight,
                                  const float* bias, float eps, int apply_silu, uint16_t* y);
 int f3dg_group_norm_silu_nhwc_pb(void* stream, int N, int C, int HW, int groups, const float* x, const float* pre_bias, const float* weight,
-                                 const float* bias, float eps, int apply_silu, float* y, double* moments);
+                                 const float* bias, float eps, int apply_silu, float* y, double* moments, size_t moments_bytes);
 int f3dg_group_norm_silu_nhwc_pb_bf16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
-                                      const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments);
+                                      const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments, size_t moments_bytes);
 /* ... and with IEEE float16 activations in and out (the fp16 option of the backbone, round 5: the bf16 MFMA rate with 10 mantissa bits
  * instead of 7; every activation of the backbone is GroupNorm-bounded). Weight / bias and all arithmetic float32, the moments float64. */
 int f3dg_group_norm_silu_pb_f16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias, const float* weight,
                                 const float* bias, float eps, int apply_silu, uint16_t* y);
 int f3dg_group_norm_silu_nhwc_pb_f16(void* stream, int N, int C, int HW, int groups, const uint16_t* x, const float* pre_bias,
-                                     const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments);
+                                     const float* weight, const float* bias, float eps, int apply_silu, uint16_t* y, double* moments, size_t moments_bytes);
 /* The residual join of a backbone block (src/gaussian_predictor.py:325-327: the second convolution's bias, `x = x + skip(orig)` with the
  * skip convolution's bias, `x = x * skip_scale`) as ONE elementwise pass: y = ((a + bias_a[c]) + (b + bias_b[c])) * scale in float32,
  * the reference's order. a, b, y [N,C,HW] (nhwc = 0) or [N,HW,C] (nhwc = 1), 16-byte aligned, N*C*HW a multiple of 4 (float32) / 8
@@ -353,61 +355,43 @@ int f3dg_residual_join_bf16(void* stream, int N, int C, int HW, int nhwc, const 
 int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const uint16_t* a, const float* bias_a, const uint16_t* b,
                            const float* bias_b, float scale, uint16_t* y);
 
-/* Runtime switches (process-wide). Known names: "render_pretest" (default 1): the compositing kernel first runs a
- * conservative float32 test that proves alpha < 1/255 and skips the float64 path for that (pixel, Gaussian) pair;
- * results are bit-identical with it on or off (asserted by the tests). "render_cull" (default 1): every 16-lane group (a 4x4
- * pixel block) of the pixel-lane kernel walks only the staged Gaussians whose conservative alpha >= 1/255 box touches its block, and
- * the compositing backward walks per-quadrant culled lists (0: its lock-step variant); also bit-identical.
- * "render_queue" (default 1): two-phase compositing loop (cheap test for 64 entries, then per-pixel queues of the passing
- * ones); also bit-identical. These three act on render_kernel = 1 (and the backward); render2 / render3 always filter. "sort_wide_groups" (default 0): forces the 32-bit (view, tile) stream of the binning stage, which
- * is otherwise only used when views << tile_bits exceeds 16 bits (tests).
- * "render_kernel" (default 3): 3 = render3, one wave64 per 8x8 pixel quadrant with no workgroup barriers: the wave scans the tile's
- * list, keeps the entries whose quadrant bit is set (instance generation leaves a 4-bit quadrant mask above the 28-bit Gaussian id of
- * every list entry, from the box of the conservative alpha >= 1/255 ellipse), stages 64 records per window by global_load_lds, tests
- * them with the Gaussians across the lanes and blends with the pixels across the lanes; 2 = render2, four coupled waves per tile
- * with per-4x4-block lists; 1 = the round-1 pixel-lane kernel (its plain variant is the transcription-order baseline of the tests).
- * "render_slide" (default 1): render3 with sliding half-windows (render3s_fwd_kernel) or fixed 64-entry windows (0).
- * "render_lowocc" (default 1; n > 1: up to n x 1,024 quadrants -- measured: from four views per call on the general kernel wins):
- * launches of at most 2,048 quadrant waves (one or two 256^2 views) take render3l_fwd_kernel, which
- * keeps the next window's gathers in flight behind phase 2; 0 = the general kernel for every launch. Launches of at most 1,024 waves
- * (ONE 256^2 view: every wave alone on its SIMD, its time a chain of latencies) use several waves per quadrant, bit-identical:
- * "render_split" (default -1: 1 in fast arithmetic -- also for two views --, 3 in the reference's): 1 = render3p_fwd_kernel, a producer wave scans the list,
- * gathers the records and runs phase 1 of the next window while the consumer wave composites; 2 / 3 = render3q_fwd_kernel, consumer +
- * 2 / 3 evaluator waves (the stateless part of every pair, parked in LDS) + producer; 0 = one wave. "render_unroll" (default -1: 2
- * in fast arithmetic on one-view launches, else 1): entries per phase-2 trip of render3p (1 or 2; 3 and 4 measured equal to 2).
- * "render_dma" (default 1): render3 stages records by global_load_lds_dwordx4 (1) or through registers (0); "render_lds_pad"
- * (default 0): extra dynamic LDS bytes per render3 workgroup (occupancy experiments).
- * "bwd_occ" (default 5): waves per SIMD the compositing backward (render3_bwd_kernel) is compiled for (2..6).
- * "small_path" (default 1): calls of one or two views of at most 2^18 Gaussians on at most 1,024 tiles take the three-launch
- * path of f3dg_small.hip (2 = on, and forget the shapes an earlier overflow disabled); "small_path_aux" (default 1): forwards with
- * F3DG_FLAG_SAVE_AUX too -- f3dg_backward then walks the per-tile slots (0: only inference calls, as in round 4);
- * "small_debug", "time_launches": diagnostics.
- * The render_kernel value also selects the per-pixel pass of f3dg_integrate: 3 = shared rays (integrate_pass1_rays_kernel), 2 = one
- * pixel per lane with the culled lists, 1 = round 1's per-ray pre-test; all bit-identical.
- * "render_round" (default 192): list entries a workgroup of render2 stages per round (192 at 7 waves/SIMD or 256 at 6).
- * "render_fast" (default 1): arithmetic of the compositing forward: 0 = the reference's float32 / float64 operation order,
- * 1 = error-free float32 pairs for the float64 island and FMA-contracted accumulations downstream of alpha, in inference calls (no
- * auxiliary planes; within 3e-7 of mode 0), exact in calls a backward follows,
- * 2 = fast in every call.
- * "tile_cull" (default 1): a Gaussian is instantiated only in the tiles that the box of its conservative alpha >= 1/255 ellipse
- * reaches instead of every tile of the reference's 3-sigma square (forward.cu:364-374). The dropped (Gaussian, tile) pairs are a
- * bare `continue` for every pixel of the tile, so all outputs and gradients are unchanged (asserted by the tests on every
- * scene); num_rendered and the exported lists are then SHORTER than the reference's. 0 = the reference's lists, bit for bit.
- * f3dg_integrate always uses the reference's lists.
- * Round 4, all bit-identical and measured without gain, hence off: "render_tail" (default 0; N > 0: a quadrant's wave of
- * render3s_fwd_kernel changes to the tail schedule once at most N of its 64 pixels are unsaturated: 64 entries per step, the ellipse test
- * for the live pixels only, records gathered for the entries some live pixel passes); "sort_fused_rects" (default 0; 1: a view's last
- * depth-sort pass also delivers its tile rectangles in sorted order instead of gsort_gather_rects_kernel); "pre_order" (default 0;
- * bit 0: the projection grid runs chunk-major -- the views of one chunk of 256 Gaussians follow each other --, bit 1: the record and
- * the ellipse leave as non-temporal stores). "render_count" (default 0): the counting variant of render3s_fwd_kernel
- * (f3dg_debug_render_counts); "render_wpb" (default 1; 4: a tile's four quadrant waves are one workgroup).
- * Round 5: "render_pack" (default -1) sends inference launches to the rank-packed kernel (f3dg_render4.hip: the trips of a slide in
- * which at most "render_pack_th" pixels (default 32; 0: none, 64: all) take part are packed -- the stateless two thirds of the loop body
- * of forward.cu:493-583 evaluated one (pixel, Gaussian) pair per lane for pairs of different pixels, the recurrence left to the lane
- * that owns the pixel); bit-identical to render3s_fwd_kernel. -1: inference launches in the reference's arithmetic ("render_fast" 0:
- * -38 % on the real merged set, -6 % at C2), 1: every inference launch, 0: none ("render_kernel" = 4 is shorthand for 3 + render_pack 1).
- * A SAVE_AUX forward stays on render3s_fwd_kernel.
- * Returns F3DG_ERR_BAD_ARG for unknown names. */
+/* Runtime switches: process-wide DEFAULTS for what a call's own flags do not say (every arithmetic / list / path choice of a call has a
+ * flag, above). The library knows thirteen names and one diagnostic pair; everything else returns F3DG_ERR_BAD_ARG.
+ *   "render_fast"   (default 1) arithmetic of the compositing forward: 0 = the reference's float32 / float64 operation order, 1 = error-free
+ *                   float32 pairs for the float64 island and FMA-contracted accumulations downstream of alpha in inference calls (no
+ *                   auxiliary planes; within 3e-7 of mode 0), exact in calls a backward follows, 2 = fast in every call.
+ *   "tile_cull"     (default 1) a Gaussian is instantiated only in the tiles that the box of its conservative alpha >= 1/255 ellipse reaches
+ *                   instead of every tile of the reference's 3-sigma square (forward.cu:364-374). The dropped (Gaussian, tile) pairs are a
+ *                   bare `continue` for every pixel of the tile: outputs and gradients are unchanged (asserted on every scene of the
+ *                   tests); num_rendered and the exported lists are SHORTER than the reference's. 0 = the reference's lists, bit for bit.
+ *                   f3dg_integrate always uses the reference's lists.
+ *   "small_path"    (default 1) calls of one or two views of at most 2^18 Gaussians on at most 1,024 tiles take the three-launch path of
+ *                   f3dg_small.hip (2 = on, and forget the shapes an earlier overflow disabled); "small_path_aux" (default 1): forwards
+ *                   with F3DG_FLAG_SAVE_AUX too -- f3dg_backward then walks the per-tile slots.
+ *   "render_lowocc" (default 1; n > 1: up to n x 1,024 quadrant waves) compositing launches of at most 2,048 quadrant waves (one or two
+ *                   256^2 views: every wave alone on its SIMD, its time a chain of latencies) take the multi-wave kernels of
+ *                   f3dg_render4.hip, bit-identical to the general kernel; 0 = the general kernel for every launch.
+ *   "render_split"  (default -1: by arithmetic) those kernels: 1 = render3p_fwd_kernel, a producer wave scans the list, gathers the records
+ *                   and runs phase 1 of the next window while the consumer wave composites (the default in fast arithmetic, and for two
+ *                   views); 2 / 3 = render3q_fwd_kernel, consumer + 2 / 3 evaluator waves (the stateless part of every pair, parked in
+ *                   LDS) + producer (3: the default for one view in the reference's arithmetic).
+ *   "render_unroll" (default -1: 2 in fast arithmetic, else 1) entries per phase-2 trip of render3p (1 or 2).
+ *   "render_pack"   (default -1) the rank-packed kernel (f3dg_render4.hip; bit-identical to render3s_fwd_kernel, also its auxiliary planes):
+ *                   -1 = launches in the reference's arithmetic (-38 % on pixel-aligned predicted sets, -6 % at C2), 1 = every launch,
+ *                   0 = none; "render_pack_th" (default 32; 0: none, 64: all): the trips of a slide in which at most that many pixels take
+ *                   part are packed.
+ *   "render_scan"   (default -1) the split-pixel schedule (f3dg_render5.hip): -1 = the calls that carry F3DG_FLAG_SCAN, 1 = every fast
+ *                   inference launch of the general path, 0 = never; "render_scan_th" (default 12; 64: every pending entry goes through
+ *                   dense batches): fused trips while more than that many pixels take part.
+ *   "bwd_occ"       (default 5) waves per SIMD the compositing backward (render3_bwd_kernel) is compiled for (2..6).
+ *   diagnostics: "render_count" (default 0) swaps in the counting variants of the compositing kernels (f3dg_debug_render_counts /
+ *                   _render4_counts / _render5_counts); "time_launches" (default 0): f3dg_debug_launch_times.
+ * A library built with -DF3DG_LAB (`F3DG_LAB=1 python f3d-gaus_amd/build.py --force`; f3dg_version() then ends in "lab") also compiles the
+ * kernel generations and schedules that were measured and superseded -- the round-1 pixel-lane kernel and its filters ("render_kernel",
+ * "render_pretest", "render_cull", "render_queue"), render2 ("render_round"), render3 with fixed windows ("render_slide", "render_dma"),
+ * render3l ("render_split" 0), the tail schedule ("render_tail"), four-wave workgroups ("render_wpb"), "render_lds_pad",
+ * "sort_wide_groups", "sort_fused_rects", "pre_hoist", "pre_order", "small_debug", "debug_skip_all", the staging replay ("render_replay")
+ * -- for the bit-identity tests against the plain transcription and for A/B runs; NOTES.md has their measurements. */
 int f3dg_set_option(const char* name, int value);
 
 /* Diagnostic: number of kernels this library has launched from this process since the last reset (host-side counter, every

@@ -10,6 +10,27 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lab: needs a library built with -DF3DG_LAB (the superseded kernel generations and A/B switches: "
+                                       "`F3DG_LAB=1 python f3d-gaus_amd/build.py --force`); skipped on the default library")
+
+
+def lab_build():
+    """True when libf3dg_hip.so was built with -DF3DG_LAB (f3dg_version() ends in "lab")."""
+    from f3dgaus_amd import _lib
+    return _lib.lib().f3dg_version().endswith(b"lab")
+
+
+def pytest_collection_modifyitems(config, items):
+    try:
+        lab = lab_build()
+    except Exception:
+        lab = False
+    if lab:
+        return
+    skip = pytest.mark.skip(reason="needs a -DF3DG_LAB build of the library (superseded kernel generations / A/B switches)")
+    for item in items:
+        if "lab" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

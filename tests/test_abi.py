@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound(f3d):
 def test_library_is_gfx950_code_object():
     lib = os.path.join(ROOT, "f3d-gaus_amd", "csrc", "libf3dg_hip.so")
     data = open(lib, "rb").read()
-    assert b"gfx950" in data and b"render_fwd_kernel" in data
+    assert b"gfx950" in data and b"render3s_fwd_kernel" in data
 
 
 def test_workspace_arithmetic_and_host_side_errors(f3d):
@@ -98,14 +98,18 @@ def test_round3_host_logic(f3d):
     """Options, diagnostics, the small-call path's workspace carving and the integrate layouts: pure host arithmetic."""
     from f3dgaus_amd import _lib
     L = _lib.lib()
-    for name in (b"render_kernel", b"render_slide", b"render_lowocc", b"render_dma", b"render_lds_pad", b"bwd_occ", b"small_path", b"small_debug",
-                 b"tile_cull", b"render_fast", b"time_launches"):
-        assert L.f3dg_set_option(name, 1) == 0, name
-    for name, v in ((b"render_kernel", 3), (b"bwd_occ", 5), (b"render_lds_pad", 0), (b"small_debug", 0), (b"time_launches", 0), (b"small_path", 2)):
-        assert L.f3dg_set_option(name, v) == 0
-    for name, v in ((b"render_tail", 16), (b"render_tail", -1), (b"sort_fused_rects", 1), (b"sort_fused_rects", 0), (b"pre_order", 3), (b"pre_order", 0),
-                    (b"render_count", 0), (b"render_wpb", 1)):      # round 4's measured-and-off switches
+    # the default library knows thirteen options and two diagnostics; the switches of the superseded generations exist in lab builds only
+    defaults = ((b"render_fast", 1), (b"tile_cull", 1), (b"small_path", 2), (b"small_path_aux", 1), (b"render_lowocc", 1), (b"render_split", -1),
+                (b"render_unroll", -1), (b"render_pack", -1), (b"render_pack_th", 32), (b"render_scan", -1), (b"render_scan_th", 12), (b"bwd_occ", 5),
+                (b"render_count", 0), (b"time_launches", 0))
+    for name, v in defaults:
         assert L.f3dg_set_option(name, v) == 0, name
+    lab_only = ((b"render_kernel", 3), (b"render_slide", 1), (b"render_dma", 1), (b"render_lds_pad", 0), (b"small_debug", 0), (b"render_tail", 16), (b"render_tail", -1),
+                (b"sort_fused_rects", 1), (b"sort_fused_rects", 0), (b"pre_order", 3), (b"pre_order", 0), (b"render_wpb", 1), (b"render_pretest", 1),
+                (b"render_cull", 1), (b"render_queue", 1), (b"render_round", 192), (b"sort_wide_groups", 0), (b"pre_hoist", 0), (b"debug_skip_all", 0))
+    lab = L.f3dg_version().endswith(b"lab")
+    for name, v in lab_only:
+        assert L.f3dg_set_option(name, v) == (0 if lab else _lib.ERR_BAD_ARG), name
     assert L.f3dg_set_option(b"no_such_option", 1) == _lib.ERR_BAD_ARG
     assert L.f3dg_debug_launch_count(1) >= 0 and L.f3dg_debug_launch_count(0) == 0
     # the per-tile slots of the small-call path exist for one or two views of at most 2^18 Gaussians only: 4096 x 4 B per (view, tile)

@@ -97,3 +97,40 @@ def test_exact_flag_reaches_the_backward(gpu_device):
         assert torch.isfinite(b).all()
         scale = float(a.abs().max()) + 1e-12
         assert float((a - b).abs().max()) / scale < 1e-4, k
+
+
+@pytest.mark.parametrize("name", ["depth_spread", "small_splats"])
+def test_dropin_distortion_map_meets_survey_8d_with_raster_exact(name, gpu_device):
+    """SURVEY 8d asks rel 1e-3 of the distortion term (forward.cu:552-557). The drop-in renderer composites inference calls in the fast
+    arithmetic by default, which moves `distortion_map` by 3-17 % relative (<= 2.5e-6 absolute: INTEGRATION.md, first bullet); a caller
+    that consumes the key sets cfg['model']['raster_exact'] = True, and THAT path -- render_predicted_more_v2_gof as visualize.py calls
+    it, under torch.no_grad() -- is held to 8d here: |d| <= 1e-6 + 1e-3 |ref| on >= 99.9 % of the pixels, rel 1e-3 wherever the
+    reference's value exceeds 1e-4."""
+    import f3dgaus_amd as f3d
+    from f3dgaus_amd import cameras
+    from helpers import frac_within
+    kw = {"depth_spread": dict(P=800, res=(64, 64), s0=0.3, view="canonical", depth_range=(1.0, 30.0)),
+          "small_splats": dict(P=30000, res=(128, 128), s0=0.01, view="oblique")}[name]
+    scene = make_scene(**kw)
+    o = run_oracle(scene)["out_color"]
+    res = scene["W"]
+    cfg = cameras.default_cfg(res)
+    import math
+    assert math.tan(cfg['model']['fov'] * np.pi / 360) == scene["tanfovx"]       # the scene's cameras are the default configuration's
+    cfg['model']['max_sh_degree'] = scene["sh_degree"]
+    pc = {"xyz": scene["means3D"], "opacity": scene["opacities"], "scaling": scene["scales"], "rotation": scene["rotations"],
+          "features_dc": scene["shs"][:, :1], "features_rest": scene["shs"][:, 1:]}
+    pc = {k: v.unsqueeze(0).to(gpu_device) for k, v in pc.items()}
+    args = (scene["viewmatrix"][:1].unsqueeze(0).to(gpu_device), scene["projmatrix"][:1].unsqueeze(0).to(gpu_device),
+            scene["campos"][:1].unsqueeze(0).to(gpu_device), scene["bg"].reshape(1, 3).to(gpu_device))
+    with torch.no_grad():
+        cfg['model']['raster_exact'] = True
+        exact = f3d.render_predicted_more_v2_gof(pc, 0, *args, cfg)["distortion_map"][0].cpu().numpy()
+        cfg['model']['raster_exact'] = False
+        fast = f3d.render_predicted_more_v2_gof(pc, 0, *args, cfg)["distortion_map"][0].cpu().numpy()
+    assert frac_within(exact, o[8], 1e-6, 1e-3) >= 0.999, frac_within(exact, o[8], 1e-6, 1e-3)
+    big = np.abs(o[8]) > 1e-4
+    if big.any():
+        assert frac_within(exact[big], o[8][big], 0.0, 1e-3) >= 0.999
+    # the default (fast) key stays inside the north_star's absolute 1e-4 -- and is NOT the reference's to 1e-3 everywhere
+    assert np.abs(fast - o[8]).max() <= 1e-4

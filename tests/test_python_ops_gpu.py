@@ -310,6 +310,30 @@ def test_group_norm_silu_channels_last_kernel(gpu_device):
                         assert err <= 2.0 ** -8 * max(1.0, ref.abs().max().item()), (N, Cc, H, W, silu, err)
 
 
+def test_group_norm_channels_last_refuses_an_undersized_scratch(gpu_device):
+    """The `moments` scratch of the channels-last GroupNorm grew in round 5 (a partial pair per workgroup): every entry point takes the
+    size of the buffer it is handed and answers F3DG_ERR_WORKSPACE instead of writing past the end of one sized by an older header."""
+    import ctypes as C
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    N, Cc, H, W, groups = 2, 128, 64, 64, 32
+    x = torch.randn(N, H * W, Cc, device=gpu_device)
+    y = torch.empty_like(x)
+    w = torch.ones(Cc, device=gpu_device); b = torch.zeros(Cc, device=gpu_device)
+    need = L.f3dg_group_norm_nhwc_scratch_bytes(N, H * W, groups)
+    old = 16 * N * groups * 8                                   # the round-4 header's size: too small from 64 x 64 on
+    assert need > old
+    mom = torch.zeros(need // 8 + 1, dtype=torch.float64, device=gpu_device)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = (s, N, Cc, H * W, groups, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), 1e-6, 1, _lib.ptr(y), _lib.ptr(mom))
+    assert L.f3dg_group_norm_silu_nhwc(*args, old) == _lib.ERR_WORKSPACE
+    assert L.f3dg_group_norm_silu_nhwc(*args, need - 1) == _lib.ERR_WORKSPACE
+    assert L.f3dg_group_norm_silu_nhwc(*args, need) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_conv_bias_folding_and_residual_join(dtype, gpu_device):
     """GroupNorm(pre_bias=) and residual_join() -- the kernels that take over the convolutions' bias passes and the residual add + scale

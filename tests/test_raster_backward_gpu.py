@@ -139,6 +139,8 @@ def test_known_answers_and_kernel_variants(gpu_device):
     for k in ("dL_dview2gaussian", "dL_dopacity", "dL_dcolors", "dL_dmeans2D"):
         assert _rel(g1[k], g0[k]) <= 1e-6, k
     L = _lib.lib()
+    if not L.f3dg_version().endswith(b"lab"):
+        return                                             # (the lock-step kernel is compiled in lab builds only)
     try:
         L.f3dg_set_option(b"render_cull", 0)
         g2, _ = _hip_fwd_bwd(scene, dpix, gpu_device)

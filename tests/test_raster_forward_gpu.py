@@ -116,6 +116,7 @@ def test_forward_batched_views_equal_single_views(gpu_device, kw):
     assert total == h["num_rendered"]
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("kw", [
     dict(P=8000, res=(128, 128), s0=0.03, view=[0, 1, 3, 5, 6, 2, 4, 7, 8]),
     dict(P=4001, res=(96, 80), s0=0.2, view=[0, 3, 5], depth_range=(1.0, 30.0)),       # four-pass views: the last pass is pass 3
@@ -138,6 +139,7 @@ def test_fused_rectangle_gather_is_invisible(gpu_device, kw):
     assert np.array_equal(a["out_color"].view(np.uint32), b["out_color"].view(np.uint32))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("save_aux", [True, False])
 def test_projection_hoist_is_bit_identical(gpu_device, save_aux):
     """Option pre_hoist (round 5): the view-independent part of the projection -- 3D covariance, rotation matrix, float64 scale
@@ -209,6 +211,7 @@ def test_c2_view_with_large_splats_full_size(gpu_device):
     assert (h["n_contrib"][0] == o["n_contrib"]).mean() >= 0.999
 
 
+@pytest.mark.lab
 def test_wide_group_stream_is_identical(gpu_device):
     """The binning stage carries (view << tile_bits | tile) as u16 when it fits, else u32: both must give the same lists
     (the u32 path is otherwise only reached with more than 65,536 (view, tile) groups)."""
@@ -273,6 +276,7 @@ def test_c1_full_size_single_view(gpu_device):
     assert_render_parity(h["out_color"][0], o["out_color"], "C1")
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("name", ["F1_tiny_identity", "F2_oblique_aniso", "F5_odd_size", "F6_small_splats", "F4_filter_scalemod", "C1", "tiny_sigma", "huge_sigma"])
 def test_pretest_is_conservative_bit_identical_outputs(name, gpu_device):
     """The float32 pre-test of the compositing kernel may only skip pairs whose alpha is certainly < 1/255:
@@ -389,8 +393,8 @@ def test_small_launch_kernels_bit_identical(name, gpu_device):
     """Launches of at most 2,048 quadrant waves (one or two 256^2 views: the reference's per-view loop) take the latency-chain
     kernels of csrc/f3dg_render4.hip: render3p_fwd_kernel (option render_split = 1: a producer wave prepares the next window while the
     consumer wave composites, render_unroll = 2: two entries per phase-2 trip evaluated as independent instruction streams) and
-    render3q_fwd_kernel (render_split = 2 / 3: consumer + evaluator waves + producer). Images and auxiliary planes must be render3l's
-    (render_split 0) to the bit, for every variant, and meet the oracle."""
+    render3q_fwd_kernel (render_split = 2 / 3: consumer + evaluator waves + producer). Images and auxiliary planes must be the general kernel's
+    (render_lowocc 0) to the bit, for every variant, and meet the oracle."""
     from f3dgaus_amd import _lib
     extra = {"C1": dict(P=65536, res=(256, 256), s0=0.01, view="oblique"),
              "thin": dict(P=40000, res=(120, 88), s0=0.03, view="oblique", n_views=2, seed=7),
@@ -403,10 +407,11 @@ def test_small_launch_kernels_bit_identical(name, gpu_device):
     L = _lib.lib()
     res = {}
     try:
-        L.f3dg_set_option(b"render_split", 0)
+        L.f3dg_set_option(b"render_lowocc", 0)           # the general kernel (render3s; render4 in the reference's arithmetic)
         for aux in (False, True):
             res[1, aux] = run_hip(scene, gpu_device, save_aux=aux)
-            assert b"render3l" in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
+            assert b"render3s" in L.f3dg_debug_last_render_kernel() or b"render4" in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
+        L.f3dg_set_option(b"render_lowocc", 1)
         # two waves per quadrant (option render_split): the producer wave prepares the next window while the consumer composites
         L.f3dg_set_option(b"render_split", 1)
         for U in (1, 2):
@@ -426,12 +431,13 @@ def test_small_launch_kernels_bit_identical(name, gpu_device):
         res["split", 0, False] = run_hip(scene, gpu_device, save_aux=False)
         import helpers
         one_view = V * ((scene["W"] + 15) // 16) * ((scene["H"] + 15) // 16) * 4 <= 1024
-        want = b"render3p" if helpers.RENDER_MODE == "fast" else (b"render3q" if one_view else b"render3l") if helpers.RENDER_MODE == "exact" else b"render3"
+        want = b"render3p" if helpers.RENDER_MODE == "fast" else (b"render3q" if one_view else b"render3p") if helpers.RENDER_MODE == "exact" else b"render3"
         assert want in L.f3dg_debug_last_render_kernel(), L.f3dg_debug_last_render_kernel()
         res["split", 0, True] = run_hip(scene, gpu_device, save_aux=True)
     finally:
         L.f3dg_set_option(b"render_unroll", -1)
         L.f3dg_set_option(b"render_split", -1)
+        L.f3dg_set_option(b"render_lowocc", 1)
     for U in (0, 1, 2, 20, 30):
         assert np.array_equal(res[1, False]["out_color"].view(np.uint32), res["split", U, False]["out_color"].view(np.uint32)), ("split", U)
         for k in ("out_color", "final_T", "n_contrib"):
@@ -441,6 +447,7 @@ def test_small_launch_kernels_bit_identical(name, gpu_device):
         assert_render_parity(res["split", 2, False]["out_color"][v], o["out_color"], "small launch %s view %d" % (name, v))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("tail", [64, 16, 3])
 def test_tail_schedule_thin_coverage(tail, gpu_device):
     """The tail schedule of the one-wave kernel (option render_tail) on the case it exists for: long tile lists of faint

@@ -3,7 +3,13 @@ formula-defined weights; fp16: three more mantissa bits) do to a rendered frame:
 aggregation with the fp32 and with the 16-bit backbone, the same 32-view orbit of the merged sets, PSNR of the 8-bit RGB frames (and of
 depth / alpha) between them.
 
-  python tools/backbone_frame_psnr.py [bf16 fp16]
+  python tools/backbone_frame_psnr.py [bf16 fp16] [--checkpoint PATH]
+
+Without --checkpoint the weights are the fixture generator's FORMULA weights (no checkpoint travels with this repository): what the
+numbers then say is how far a perturbation of that size is amplified by an untrained network of this architecture -- nothing follows
+from them for the released checkpoint. --checkpoint PATH loads a `state_dict` (a .pth / .pt file as the reference's visualize.py loads
+it: either the dict itself or {"model_state_dict": ...}) into the predictor, so a maintainer who has the checkpoint can measure the
+16-bit options on the trained network.
 """
 import os
 import sys
@@ -20,8 +26,16 @@ dev = torch.device("cuda:0")
 images, depth, _ = load_real_image(dev)
 frames = {}
 OPTIONS = [a for a in sys.argv[1:] if a in ("bf16", "fp16")] or ["bf16", "fp16"]
+CKPT = sys.argv[sys.argv.index("--checkpoint") + 1] if "--checkpoint" in sys.argv else None
+print("weights: %s" % (CKPT or "formula weights of the fixture generator (NOT a trained network: see the module docstring)"))
 for backbone in ["fp32"] + OPTIONS:
     model, cfg = real_predictor(dev, 256, backbone)
+    if CKPT:
+        sd = torch.load(CKPT, map_location="cpu")
+        sd = sd.get("model_state_dict", sd) if isinstance(sd, dict) else sd
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        print("  %s: loaded %s (%d missing, %d unexpected keys)" % (backbone, CKPT, len(missing), len(unexpected)))
+        model = model.to(dev)
     with torch.no_grad():
         merged = f3d.cycle.cycle_aggregate(model, images, depth, cfg)
         frames[backbone] = f3d.cycle.render_orbit(merged, cfg, num_views=32, views_per_call=32)
