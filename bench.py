@@ -795,6 +795,7 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
     stage_ms = (C.c_double * 5)()
     ncalls = C.c_int(0)
     _lib.check(L.f3dg_profile_collect(stage_ms, C.byref(ncalls)), "f3dg_profile_collect")
+    fwd_kernel = L.f3dg_debug_last_render_kernel().decode()        # what the library launched for the forward (the packed kernel, render4, by default)
     pairs = C.c_longlong(0)
     _lib.check(L.f3dg_backward_pairs(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(ws.buffer.data_ptr()), C.byref(pairs)),
                "f3dg_backward_pairs")
@@ -830,7 +831,7 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
                    "tile_cull": args.tile_cull, "contributing_pairs_per_step": pairs.value},
         "roofline": bwd_rf,
         "rooflines_other": {
-            "render3s_fwd_kernel<SAVE_AUX=true, FAST=false>": {"bound": "hbm", "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": stage_ms[2] / n,
+            fwd_kernel: {"bound": "hbm", "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": stage_ms[2] / n,
                                                                "achieved": gbs(b_fwd, stage_ms[2] / n), "unit": "GB/s",
                                                                "frac": gbs(b_fwd, stage_ms[2] / n) / HBM_PEAK_GBS}},
         "stage_ms_per_step": {"preprocess": stage_ms[0] / n, "binning": stage_ms[1] / n, "compositing": stage_ms[2] / n,

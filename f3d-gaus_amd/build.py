@@ -40,7 +40,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+STAMP = os.path.join(CSRC, ".build_flags")      # the flag set the objects in the tree were compiled with
+
+
 def build(force=False, verbose=False):
+    # a tree that holds the objects of the OTHER flag set (a lab build left behind, or the default one when F3DG_LAB is asked for) is rebuilt
+    # as a whole: the driver's build() must never pick up a -DF3DG_LAB library because its objects look newer than the sources
+    stamp = " ".join(FLAGS) + " | " + " ".join("%s:%s" % (k, " ".join(v)) for k, v in sorted(EXTRA_FLAGS.items()))
+    try:
+        if open(STAMP).read() != stamp:
+            force = True
+    except OSError:
+        force = True
     srcs = sources()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "f3dg.h"))
@@ -63,6 +74,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(stamp)
     return LIB
 
 

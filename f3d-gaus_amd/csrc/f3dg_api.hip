@@ -152,6 +152,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
     if (strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_scan") == 0) { g_f3dg_render_scan = value < 0 ? -1 : value != 0; return F3DG_OK; }
+    if (strcmp(name, "render_scan_min") == 0) { g_f3dg_render_scan_min = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_scan_th") == 0) { g_f3dg_render_scan_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value < 0 ? 1 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_unroll") == 0) { g_f3dg_render_unroll = value < 0 ? F3DG_RENDER_UNROLL_DEFAULT : value < 1 ? 1 : value > 2 ? 2 : value; return F3DG_OK; }

@@ -240,7 +240,7 @@ int f3dg_launch_render_small(hipStream_t s, int V, int P, int W, int H, float fo
                          const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
                          float* out_color, int fast, int save_aux, float* final_T, unsigned* n_contrib, int unroll, int split, int count);
 extern int g_f3dg_render_split;        // small launches: 1 = two waves per quadrant (render3p_fwd_kernel: a producer wave scans, gathers and runs phase 1 for the window after the one the consumer wave composites)
-extern int g_f3dg_render_lowocc;       // 1 (default): launches of at most 2048 quadrant waves take render3l_fwd_kernel (next window's gathers in flight)
+extern int g_f3dg_render_lowocc;       // n >= 1 (default 1): launches of at most max(2, n) x 1024 quadrant waves take the multi-wave kernels of f3dg_render4.hip; 0: never
 extern int g_f3dg_render_slide;        // 1 (default): render3 with the sliding half-window (render3s_fwd_kernel); 0: fixed 64-entry windows
 extern int g_f3dg_render_tail;         // N > 0: render3s switches a quadrant to the tail schedule once at most N of its pixels are unsaturated (0: never)
 extern int g_f3dg_render_count;        // 1: the one-wave kernel's counting variant (diagnostic; f3dg_debug_render_counts)
@@ -270,6 +270,7 @@ int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x
 
 // the split-pixel compositing forward (f3dg_render5.hip; F3DG_FLAG_SCAN / option render_scan: fast inference launches of the general path)
 extern int g_f3dg_render_scan;         // -1 (default): calls with F3DG_FLAG_SCAN; 1: every eligible launch; 0: never
+extern int g_f3dg_render_scan_min;     // stragglers holding fewer older-half entries than this finish the slide in fused trips (default 4; 0: always compact)
 extern int g_f3dg_render_scan_th;      // fused trips while more than this many pixels take part (default 20)
 int f3dg_launch_render5(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,

@@ -38,6 +38,7 @@
 
 extern thread_local const char* g_f3dg_last_render_kernel;
 int g_f3dg_render_scan = -1;          // option render_scan: -1 (default) = calls that ask for it (F3DG_FLAG_SCAN); 1 = every fast inference launch of the general path; 0 = never
+int g_f3dg_render_scan_min = 4;       // option render_scan_min: stragglers that hold fewer than this many older-half entries each finish the slide in fused trips (0: always compact)
 int g_f3dg_render_scan_th = 12;       // option render_scan_th: fused trips while more than this many pixels take part (64: every trip is compacted)
 
 // work counters (option render_count = 1; f3dg_debug_render5_counts): [0] staged entries, [1] scanned, [2] fused trips, [3] slides,
@@ -136,7 +137,7 @@ render5_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                    const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                    const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
                    const float4* __restrict__ cull, const float* __restrict__ background, int bg_per_view,
-                   float* __restrict__ out_color, int th)
+                   float* __restrict__ out_color, int th, int min_trips)
 {
     unsigned view, unit;
     f3dg_xcd_map(blockIdx.x, (unsigned)V, 4u * (unsigned)T, view, unit);
@@ -255,6 +256,28 @@ render5_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
         // half (they gate the slide) and as many of the newer half, in pixel order, as fill the last batch -- those entries are resident,
         // would have to be blended later anyway, and a lane of a batch costs the same empty or not
         unsigned long long tk = __ballot((unsigned)pass != 0u);
+        if (tk != 0ull && min_trips > 0) {
+            // what the busiest straggler still holds in the older half = the fused trips the rest of this slide would take: a compaction +
+            // a batch cost about four of them
+            int rem = __popc((unsigned)pass);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rem = max(rem, __shfl_xor(rem, o, 64));
+            if (__builtin_amdgcn_readfirstlane(rem) < min_trips) {
+                while (pass != 0ull && __ballot((unsigned)pass != 0u) != 0ull) {
+                    const unsigned j = (unsigned)__builtin_ctzll(pass) ^ xr;
+                    pass &= pass - 1;
+                    if (COUNT) n_lane_fused++;
+                    const float4 q0 = sR[0][j], q1 = sR[1][j], q2 = sR[2][j], q3 = sR[3][j];
+                    const F3dgPair pr = f3dg_pair_eval<true, NORMAL, DIST, false>(ray_x, ray_y, q0, q1, q2);
+                    asm volatile("" :: "v"(q2.w), "v"(q3.w), "v"(pr.alpha));
+                    if (pr.alpha != 0.0f)
+                        done = f3dg_pair_apply<true, NORMAL, DIST>(st, 0u, pr, q3.x, q3.y, q3.z);
+                    if (done) pass = 0ull;
+                    if (COUNT && __builtin_ctzll(__ballot(true)) == (int)lane) n_fused++;
+                }
+                tk = 0ull;
+            }
+        }
         if (tk != 0ull) {
             unsigned plo = (unsigned)pass, phi = (unsigned)(pass >> 32);
             unsigned budget;                        // newer-half entries the batches of this slide have room for
@@ -445,7 +468,7 @@ int f3dg_launch_render5(hipStream_t s, int V, int P, int W, int H, float focal_x
     const bool lean = (skip_channels & (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION)) == (F3DG_FLAG_SKIP_NORMAL | F3DG_FLAG_SKIP_DISTORTION);
     const int th = g_f3dg_render_scan_th;
 #define F3DG_LAUNCH5(NRM, DST, CNT) F3DG_KLAUNCH((render5_fwd_kernel<NRM, DST, CNT>), grid, dim3(64), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges, \
-                                                 point_list, rec, cull, background, bg_per_view, out_color, th)
+                                                 point_list, rec, cull, background, bg_per_view, out_color, th, g_f3dg_render_scan_min)
     if (lean) { if (count) F3DG_LAUNCH5(false, false, true); else F3DG_LAUNCH5(false, false, false); }
     else { if (count) F3DG_LAUNCH5(true, true, true); else F3DG_LAUNCH5(true, true, false); }
 #undef F3DG_LAUNCH5

@@ -2,7 +2,7 @@
 # PMC passes (counters only, one rocprofv3 run per counter set) over one bench.py command, condensed to per-kernel means of the
 # dispatches with the LARGEST grid of each kernel name (the timed launches: set-up launches of the same kernel on fewer views are
 # left out).   usage: tools/pmc_kernel.sh <out_tag> <kernel substring> <bench.py args...>     (env F3DG_* pass through)
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; TAG=$1; KSUB=$2; shift 2
+export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; KSUB=$2; shift 2
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-d2h --no-exact $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- $B > $O/bench_under_rocprof.log 2>&1
