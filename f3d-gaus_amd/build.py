@@ -25,7 +25,7 @@ if os.environ.get("F3DG_LAB"):          # builder-side experiments: diagnostic k
 # v_pk_mul_f32 / v_pk_add_f32; on gfx950 those issue at half rate, so nothing is gained and the v_mov shuffles that feed them
 # are pure overhead (measured on the compositing kernel: DESIGN.md section 5). Results are bit-identical either way.
 EXTRA_FLAGS = {name: os.environ.get("F3DG_EXTRA_" + name.split(".")[0].upper(), default).split()
-               for name, default in (("f3dg_render.hip", "-fno-slp-vectorize"), ("f3dg_render4.hip", "-fno-slp-vectorize"), ("f3dg_render5.hip", "-fno-slp-vectorize"), ("f3dg_backward.hip", "-fno-slp-vectorize"),
+               for name, default in (("f3dg_render.hip", "-fno-slp-vectorize"), ("f3dg_render4.hip", "-fno-slp-vectorize"), ("f3dg_render5.hip", "-fno-slp-vectorize"), ("f3dg_backward.hip", "-fno-slp-vectorize"), ("f3dg_backward5.hip", "-fno-slp-vectorize"),
                                      ("f3dg_integrate.hip", "-fno-slp-vectorize"), ("f3dg_preprocess.hip", "-fno-slp-vectorize"))}
 
 

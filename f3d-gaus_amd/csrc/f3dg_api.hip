@@ -120,6 +120,7 @@ int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_pack = -1;
 int g_f3dg_render_dma = 1;
+int g_f3dg_render_prefetch = 0;
 int g_f3dg_render_replay = 0;
 int g_f3dg_render_wpb = 1;
 int g_f3dg_render_count = 0;
@@ -151,11 +152,13 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (strcmp(name, "small_path_aux") == 0) { g_f3dg_small_path_aux = value != 0; return F3DG_OK; }
     if (strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
     if (strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
+    if (strcmp(name, "render_prefetch") == 0) { g_f3dg_render_prefetch = value != 0; return F3DG_OK; }
     if (strcmp(name, "render_scan") == 0) { g_f3dg_render_scan = value < 0 ? -1 : value != 0; return F3DG_OK; }
     if (strcmp(name, "render_scan_min") == 0) { g_f3dg_render_scan_min = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_scan_th") == 0) { g_f3dg_render_scan_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_lowocc") == 0) { g_f3dg_render_lowocc = value < 0 ? 1 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_unroll") == 0) { g_f3dg_render_unroll = value < 0 ? F3DG_RENDER_UNROLL_DEFAULT : value < 1 ? 1 : value > 2 ? 2 : value; return F3DG_OK; }
+    if (strcmp(name, "bwd_dense") == 0) { g_f3dg_bwd_dense = value != 0; return F3DG_OK; }
     if (strcmp(name, "bwd_occ") == 0) { g_f3dg_bwd_occ = (value >= 2 && value <= 6) ? value : 5; return F3DG_OK; }
     // diagnostics
     if (strcmp(name, "render_count") == 0) { g_f3dg_render_count = value != 0; return F3DG_OK; }
@@ -330,7 +333,7 @@ F3dgLayout f3dg_layout(int P, int W, int H, int V, long long cap)
     L.ranges = take((size_t)V * T * sizeof(uint2));
     L.final_T = take((size_t)V * 4 * HW * sizeof(float));
     L.n_contrib = take((size_t)V * 2 * HW * sizeof(unsigned));
-    L.bwd_acc = take(VP * 10 * sizeof(double));
+    L.bwd_acc = take(VP * 16 * sizeof(double));      // 128 bytes per (view, Gaussian): ten float64 sums + (dense backward) seven float32 ones in ONE line
     L.small_cap = f3dg_small_shape(P, W, H, V) ? (unsigned)F3DG_SMALL_CAP : 0u;
     L.small_boxes = take(L.small_cap ? (size_t)V * ((P + 63) / 64) * sizeof(uint2) : 0);
     L.small_cnt = take((size_t)V * T * sizeof(unsigned));

@@ -1088,8 +1088,10 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       const float* __restrict__ viewmatrices, const float* __restrict__ cam_positions,
                       const double* __restrict__ dL_dv2g_acc, float* __restrict__ dL_dv2g_out,
-                      const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
-                      float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int V)
+                      float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
+                      float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int V,
+                      int acc_stride /* doubles per (view, Gaussian) of dL_dv2g_acc: 10, or 16 = the packed records of the dense compositing backward */,
+                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity)
 {
     const int g = blockIdx.x * F3DG_BLOCK + threadIdx.x;
     if (g >= P) return;
@@ -1098,15 +1100,29 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 #pragma unroll
     for (int i = 0; i < 48; i++) sum_sh[i] = 0.0f;
     bool any = false;
+    float op_sum = 0.0f;
 
     for (int v = 0; v < V; v++) {
     const size_t idx = (size_t)v * P + g;
 
     float dv[10];
+    const double* arec = dL_dv2g_acc + idx * (size_t)acc_stride;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        dv[i] = (float)dL_dv2g_acc[idx * 10 + i];
+        dv[i] = (float)arec[i];
         dL_dv2g_out[idx * 10 + i] = dv[i];
+    }
+    if (acc_stride == 16) {
+        // the dense compositing backward (f3dg_backward5.hip) adds colour, mean2D and opacity into the same 128-byte record as the ten
+        // float64 sums (one line per atomic event instead of four arrays): they leave for the caller's arrays here, the opacity summed
+        // over the views by its single writer
+        const float* f = reinterpret_cast<const float*>(arec + 10);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            dL_dcolor[idx * 3 + c] = f[c];
+            dL_dmean2D[idx * 3 + c] = f[3 + c];
+        }
+        op_sum += f[6];
     }
     if (!(radii[idx] > 0)) continue;
     any = true;
@@ -1316,6 +1332,7 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
     sum_mean[0] += dmean[0]; sum_mean[1] += dmean[1]; sum_mean[2] += dmean[2];
     }   // views
 
+    if (acc_stride == 16) dL_dopacity[g] += op_sum;
     if (!any) return;
 #pragma unroll
     for (int q = 0; q < 3; q++) dL_dmeans[3 * (size_t)g + q] += sum_mean[q];
@@ -1371,7 +1388,13 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
 
     // float64 accumulator of dL/dview2gaussian (its own region of the workspace)
     double* acc = reinterpret_cast<double*>(ws + L.bwd_acc);
-    F3DG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * 10 * (size_t)n_views * P, s));
+#ifdef F3DG_LAB
+    const bool dense = g_f3dg_bwd_dense && g_f3dg_render_cull && g_f3dg_render_kernel == 3;
+#else
+    const bool dense = g_f3dg_bwd_dense != 0;
+#endif
+    const int acc_stride = dense ? 16 : 10;           // the dense kernel's 128-byte records (ten float64 + seven float32 sums) or [V*P][10]
+    F3DG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)acc_stride * (size_t)n_views * P, s));
     F3DG_HIP_CHECK(hipMemsetAsync(&hdr->bwd_pairs, 0, sizeof(hdr->bwd_pairs), s));
     const int prof = f3dg_prof_bwd_begin(s);
 
@@ -1380,7 +1403,15 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
 #else
     const bool bwd3 = true;
 #endif
-    if (bwd3) {
+    if (dense) {
+        const int rc5 = f3dg_launch_render5_bwd(s, n_views, P, W, H, tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),
+                                                reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const unsigned*>(ws + L.small_list),
+                                                reinterpret_cast<const F3dgRec*>(ws + L.rec), reinterpret_cast<const float4*>(ws + L.cull),
+                                                reinterpret_cast<const float2*>(ws + L.means2D), reinterpret_cast<const float4*>(ws + L.conic), background,
+                                                (flags & F3DG_FLAG_BG_PER_VIEW) ? 1 : 0, reinterpret_cast<const float*>(ws + L.final_T),
+                                                reinterpret_cast<const unsigned*>(ws + L.n_contrib), dL_dpix, dL_dmean2D, dL_dopacity, dL_dcolor, acc, g_f3dg_small_debug == 9);
+        if (rc5 != F3DG_OK) return rc5;
+    } else if (bwd3) {
 #define F3DG_LAUNCH_BWD3(OCC) F3DG_KLAUNCH((render3_bwd_kernel<OCC>), dim3((unsigned)n_views * (unsigned)T * 4u), dim3(64), 0, s, n_views, P, W, H,  \
                            tiles_x, T, focal_x, focal_y, hdr, reinterpret_cast<const uint2*>(ws + L.ranges),                                        \
                            reinterpret_cast<const unsigned*>(ws + L.vals[0]), reinterpret_cast<const unsigned*>(ws + L.small_list), reinterpret_cast<const F3dgRec*>(ws + L.rec),                        \
@@ -1415,7 +1446,7 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     F3DG_KLAUNCH(preprocess_bwd_kernel, dim3((P + F3DG_BLOCK - 1) / F3DG_BLOCK), dim3(F3DG_BLOCK), 0, s, P,
                        D, M, means3D, radii_used, shs, reinterpret_cast<const unsigned char*>(ws + L.clamped), scales,
                        rotations, viewmatrix, cam_pos, acc, dL_dview2gaussian, dL_dcolor, dL_dmean3D, dL_dsh, dL_dscale,
-                       dL_drot, n_views);
+                       dL_drot, n_views, acc_stride, dL_dmean2D, dL_dopacity);
     f3dg_prof_bwd_mark(prof, 1, s);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;

@@ -134,7 +134,8 @@ struct F3dgLayout {
     size_t ranges;         // [V*T] uint2
     size_t final_T;        // [V][4][H*W] float
     size_t n_contrib;      // [V][2][H*W] u32
-    size_t bwd_acc;        // [V*P][10] double: float64 accumulator of dL/dview2gaussian (backward only)
+    size_t bwd_acc;        // [V*P][16] double-sized slots (128 B): float64 accumulator of dL/dview2gaussian [10]; with the dense backward also the seven
+                           // float32 sums of colour, mean2D and opacity at byte 80 (lock-step backward: the first 80 V P bytes as [V*P][10])
     // small-call path (f3dg_small.hip; carved only for the shapes it serves, small_cap = 0 otherwise)
     size_t small_boxes;    // [V][ceil(P/64)] uint2: union of the tile rectangles of every 64 consecutive Gaussians (small path only)
     size_t small_cnt;      // [V*T] u32: length of every (view, tile) list
@@ -246,6 +247,7 @@ extern int g_f3dg_render_tail;         // N > 0: render3s switches a quadrant to
 extern int g_f3dg_render_count;        // 1: the one-wave kernel's counting variant (diagnostic; f3dg_debug_render_counts)
 extern int g_f3dg_render_wpb;          // quadrant waves per render3s workgroup: 1 (default) or 4 (a tile's four waves start together on one CU)
 extern int g_f3dg_render_replay;       // lab builds (-DF3DG_LAB) only: 2 / 3 = launch render3s_stage_only_kernel instead of the compositing kernel
+extern int g_f3dg_render_prefetch;     // 1: render3s touches the record / ellipse lines of the next slide's entries one slide ahead
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);
 void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);
@@ -275,6 +277,14 @@ extern int g_f3dg_render_scan_th;      // fused trips while more than this many 
 int f3dg_launch_render5(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
                         const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
                         float* out_color, unsigned skip_channels, int count);
+
+// the dense compositing backward (f3dg_backward5.hip; option bwd_dense)
+extern int g_f3dg_bwd_dense;           // 1: render5_bwd_kernel (entry-major batches of (pixel, entry) pairs, segmented scans); 0: render3_bwd_kernel (lock-step walk)
+int f3dg_launch_render5_bwd(hipStream_t s, int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y, F3dgHeader* hdr,
+                            const uint2* ranges, const unsigned* point_list, const unsigned* small_list, const F3dgRec* rec, const float4* cull,
+                            const float2* means2D, const float4* conic, const float* background, int bg_per_view, const float* final_T,
+                            const unsigned* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolors,
+                            double* dL_dv2g_acc, int debug_no_atomics);
 
 int f3dg_launch_integrate_fill(hipStream_t s, int W, int H, int PN, float* out_color, float* out_alpha_integrated,
                                float* out_color_integrated);
