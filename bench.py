@@ -806,7 +806,8 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     b_fwd = 72.0 * R + (60.0 * RES * RES + 8.0 * T) * V                       # with the auxiliary planes
     b_bwd = 80.0 * R + 60.0 * RES * RES * V + 68.0 * pairs.value
-    bwd_rf = {"bound": "hbm", "kernel": "render3_bwd_kernel", "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": stage_ms[3] / n,
+    bwd_kernel = "render3_bwd_kernel" if "bwd_dense=0" in os.environ.get("F3DG_OPTIONS", "").replace(" ", "") else "render5_bwd_kernel"
+    bwd_rf = {"bound": "hbm", "kernel": bwd_kernel, "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": stage_ms[3] / n,
               "achieved": gbs(b_bwd, stage_ms[3] / n), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(b_bwd, stage_ms[3] / n) / HBM_PEAK_GBS,
               "traffic": None, "formula": "80 R + 60 W H V + 68 C (R = instances_per_step, the reference's num_rendered; C = contributing "
                                           "pairs, counted by the kernel)",

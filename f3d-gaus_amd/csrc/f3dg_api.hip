@@ -120,7 +120,6 @@ int g_f3dg_render_fast = 1;
 int g_f3dg_render_kernel = 3;
 int g_f3dg_render_pack = -1;
 int g_f3dg_render_dma = 1;
-int g_f3dg_render_prefetch = 0;
 int g_f3dg_render_replay = 0;
 int g_f3dg_render_wpb = 1;
 int g_f3dg_render_count = 0;
@@ -152,7 +151,6 @@ extern "C" int f3dg_set_option(const char* name, int value)
     if (strcmp(name, "small_path_aux") == 0) { g_f3dg_small_path_aux = value != 0; return F3DG_OK; }
     if (strcmp(name, "render_pack") == 0) { g_f3dg_render_pack = value < 0 ? -1 : value != 0; return F3DG_OK; }
     if (strcmp(name, "render_pack_th") == 0) { g_f3dg_render_pack_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
-    if (strcmp(name, "render_prefetch") == 0) { g_f3dg_render_prefetch = value != 0; return F3DG_OK; }
     if (strcmp(name, "render_scan") == 0) { g_f3dg_render_scan = value < 0 ? -1 : value != 0; return F3DG_OK; }
     if (strcmp(name, "render_scan_min") == 0) { g_f3dg_render_scan_min = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }
     if (strcmp(name, "render_scan_th") == 0) { g_f3dg_render_scan_th = value < 0 ? 0 : value > 64 ? 64 : value; return F3DG_OK; }

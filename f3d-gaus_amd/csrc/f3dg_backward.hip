@@ -1107,23 +1107,24 @@ preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, co
 
     float dv[10];
     const double* arec = dL_dv2g_acc + idx * (size_t)acc_stride;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        dv[i] = (float)arec[i];
-        dL_dv2g_out[idx * 10 + i] = dv[i];
-    }
     if (acc_stride == 16) {
         // the dense compositing backward (f3dg_backward5.hip) adds colour, mean2D and opacity into the same 128-byte record as the ten
-        // float64 sums (one line per atomic event instead of four arrays): they leave for the caller's arrays here, the opacity summed
-        // over the views by its single writer
-        const float* f = reinterpret_cast<const float*>(arec + 10);
+        // float64 sums (one line per atomic event instead of four arrays): the record is read as seven 16-byte words, its float32 sums
+        // leave for the caller's arrays here, the opacity summed over the views by its single writer
+        const double2* a2 = reinterpret_cast<const double2*>(arec);
+        const double2 d0 = a2[0], d1 = a2[1], d2 = a2[2], d3 = a2[3], d4 = a2[4];
+        const float4 f0 = reinterpret_cast<const float4*>(arec)[5], f1 = reinterpret_cast<const float4*>(arec)[6];
+        dv[0] = (float)d0.x; dv[1] = (float)d0.y; dv[2] = (float)d1.x; dv[3] = (float)d1.y; dv[4] = (float)d2.x;
+        dv[5] = (float)d2.y; dv[6] = (float)d3.x; dv[7] = (float)d3.y; dv[8] = (float)d4.x; dv[9] = (float)d4.y;
+        dL_dcolor[idx * 3] = f0.x; dL_dcolor[idx * 3 + 1] = f0.y; dL_dcolor[idx * 3 + 2] = f0.z;
+        dL_dmean2D[idx * 3] = f0.w; dL_dmean2D[idx * 3 + 1] = f1.x; dL_dmean2D[idx * 3 + 2] = f1.y;
+        op_sum += f1.z;
+    } else {
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            dL_dcolor[idx * 3 + c] = f[c];
-            dL_dmean2D[idx * 3 + c] = f[3 + c];
-        }
-        op_sum += f[6];
+        for (int i = 0; i < 10; i++) dv[i] = (float)arec[i];
     }
+#pragma unroll
+    for (int i = 0; i < 10; i++) dL_dv2g_out[idx * 10 + i] = dv[i];
     if (!(radii[idx] > 0)) continue;
     any = true;
     const float* view = viewmatrices + 16 * v;

@@ -25,7 +25,9 @@ int g_f3dg_bwd_dense = 1;             // option bwd_dense: 1 (default) = render5
 
 namespace {
 
-#define F3DG_B5_STAGE 12            // runs whose totals go through LDS together
+#ifndef F3DG_B5_STAGE
+#define F3DG_B5_STAGE 6             // runs whose totals go through LDS together (12: 8.5 ms at C5, 6: 8.0, 3: 8.2 -- LDS decides the occupancy)
+#endif
 #ifndef F3DG_B5_OCC
 #define F3DG_B5_OCC 5               // 96 VGPRs, 8 KB of LDS: five waves per SIMD
 #endif
@@ -68,10 +70,10 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     }
 
     __shared__ float4 sR[4][64];          // records of the window, [16-byte chunk][entry] (global_load_lds image)
-    __shared__ float4 sC[64];             // 2D conic + opacity * coef
-    __shared__ float2 sX[64];             // projected centre
+    __shared__ float4 sC[64];             // 2D conic (x, y, z) and, over the opacity * coef the record carries as well, the projected centre's x
+    __shared__ float sY[64];              // the projected centre's y
     __shared__ uint2 sQ[128];             // (list position, Gaussian id) of the kept entries, ring
-    __shared__ unsigned sK[128];          // (position in the entry's run << 12) | (owning lane << 6) | window slot: the pairs of the batches, ring
+    __shared__ unsigned short sK[128];    // (owning lane << 6) | window slot: the pairs of the batches, entry-major, ring
     __shared__ __attribute__((aligned(16))) float sOut[F3DG_B5_STAGE][20];     // the 17 totals + Gaussian id of up to twelve runs on their way to one-element-per-lane
     __shared__ float4 sS[64];             // per pixel: (T in front of its last blended entry, blended dot behind it, that entry's alpha, its dot)
 
@@ -115,7 +117,6 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
     sS[lane] = make_float4(T_final, 0.0f, 0.0f, 0.0f);
     const unsigned el_run = lane / 20u, el = lane - 20u * el_run;      // lane 20 r + c adds element c of the r-th run of a group of three
     const float TfBg = T_final * bg_dot_dpixel;
-    const float pixx = (float)pix_x, pixy = (float)pix_y;
     // one 128-byte record per (view, Gaussian) takes all 17 sums of an entry: ten float64 (view2gaussian) at byte 0, seven float32 (colour,
     // mean2D, opacity) at byte 80 -- an atomic event touches ONE line (three 64-byte requests at most) instead of four arrays;
     // preprocess_bwd_kernel hands the float32 ones to the caller's arrays
@@ -143,6 +144,7 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 
         float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float ec = 0.0f;
+        float2 m2 = make_float2(0.0f, 0.0f);
         if (lane < m) {
             const unsigned id = sQ[(qhead + lane) & 127u].y;
             const float4* src = reinterpret_cast<const float4*>(vrec + id);
@@ -153,10 +155,14 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(conic + vP + id),
                                              (__attribute__((address_space(3))) void*)&sC[0], 16, 0, 0);
             e4 = vcull[id];
-            sX[lane] = means2D[vP + id];
+            m2 = means2D[vP + id];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane < m) ec = sR[3][lane].w;
+        if (lane < m) {
+            ec = sR[3][lane].w;
+            sC[lane].w = m2.x;          // (conic.w = opacity * coef is record word 10: sR[2][j].z)
+            sY[lane] = m2.y;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -193,7 +199,7 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                 if (rowmask == 0ull)
                     continue;
                 const unsigned r = __builtin_amdgcn_mbcnt_hi((unsigned)(rowmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rowmask, 0u));
-                if (mine) sK[(qt + r) & 127u] = (r << 12) | (lane << 6) | (unsigned)j;
+                if (mine) sK[(qt + r) & 127u] = (unsigned short)((lane << 6) | (unsigned)j);
                 qt += (unsigned)__popcll(rowmask);
             }
             const unsigned nb = qt - qh < 64u ? qt - qh : 64u;
@@ -204,13 +210,17 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---- one batch: lane q takes pair q of the ring
-            const unsigned kk = sK[(qh + lane) & 127u];
+            const unsigned kk = (unsigned)sK[(qh + lane) & 127u];
             const bool valid = lane < nb;
-            const unsigned k = valid ? kk : (unsigned)__builtin_amdgcn_readfirstlane((int)kk);      // (lanes beyond the batch repeat pair 0, inactive)
-            const unsigned rrun = k >> 12;
-            const unsigned rr = valid ? (rrun < lane ? rrun : lane) : 0u;       // lanes between this pair and the first pair of its entry INSIDE the batch
+            const unsigned k = valid ? (unsigned)kk : (unsigned)__builtin_amdgcn_readfirstlane((int)kk);      // (lanes beyond the batch repeat pair 0, inactive)
             const unsigned own = (k >> 6) & 63u;
             const int j = (int)(k & 63u);
+            // the runs of the batch: consecutive pairs of one entry (a window slot appears in one run only). A lane's distance to the first
+            // lane of its run is what the segmented scans below need
+            const int jprev = __builtin_amdgcn_update_dpp(-1, j, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const unsigned long long heads_all = __ballot(valid && j != jprev);
+            const unsigned long long upto = heads_all & (~0ull >> (63u - lane));
+            const unsigned rr = valid ? lane - (63u - (unsigned)__builtin_clzll(upto | 1ull)) : 0u;
             const int oaddr = (int)(own << 2);
 #define F3DG_B5_PULL(v) __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v)))
             const float p_ray_x = F3DG_B5_PULL(ray_x), p_ray_y = F3DG_B5_PULL(ray_y);
@@ -219,7 +229,7 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             const float p_dmaxd = F3DG_B5_PULL(dL_dmax_depth), p_dreg = F3DG_B5_PULL(dL_dreg);
             const float p_final_A = F3DG_B5_PULL(final_A), p_final_D = F3DG_B5_PULL(final_D), p_TfBg = F3DG_B5_PULL(TfBg);
             const int p_maxc = __builtin_amdgcn_ds_bpermute(oaddr, max_contributor);
-            const float p_pixx = F3DG_B5_PULL(pixx), p_pixy = F3DG_B5_PULL(pixy);
+            const float p_pixx = (float)(qx0 + (own & 7u)), p_pixy = (float)(qy0 + (own >> 3));      // the owner's pixel
 #undef F3DG_B5_PULL
             const uint2 pe = sQ[(qhead + (unsigned)j) & 127u];
             const int contributor = (int)pe.x;
@@ -262,8 +272,9 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
             {
 #pragma clang fp contract(fast)
                 const float4 q3 = sR[3][j];
-                const float4 con = sC[j];
-                const float2 xy = sX[j];
+                float4 con = sC[j];
+                const float2 xy = make_float2(con.w, sY[j]);
+                con.w = q2.z;
                 const float inv_len = __builtin_amdgcn_rsqf(n0 * n0 + n1 * n1 + n2 * n2 + 1e-7f);
                 const float nn0 = -n0 * inv_len, nn1 = -n1 * inv_len, nn2 = -n2 * inv_len;
                 const float c0 = q3.x, c1 = q3.y, c2 = q3.z;
@@ -273,7 +284,6 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                 // ---- the recurrence, entry after entry (a pixel has at most one pair per entry, so the lanes of a run never share a
                 // state slot; successive runs of the batch do): T is rebuilt by the reference's own IEEE division (backward.cu:803)
                 float Tr = 0.0f, A = 0.0f;
-                const unsigned long long heads_all = __ballot(valid && rr == 0u);
                 unsigned long long heads = heads_all;
                 while (heads != 0ull) {
                     const unsigned a0 = (unsigned)__builtin_ctzll(heads);
@@ -374,7 +384,7 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                 // one float32 and one float64 atomic instruction add runs of neighbouring addresses.
                 const unsigned nruns = (unsigned)__popcll(heads_all);
                 const unsigned ord = __builtin_amdgcn_mbcnt_hi((unsigned)(heads_all >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)heads_all, 0u)) +
-                                     ((valid && rr == 0u) ? 1u : 0u) - 1u;       // which run of the batch this lane belongs to
+                                     ((valid && j != jprev) ? 1u : 0u) - 1u;       // which run of the batch this lane belongs to
                 for (unsigned base = 0u; base < nruns; base += F3DG_B5_STAGE) {
                     if (last && ord - base < (unsigned)F3DG_B5_STAGE) {
                         float* o = sOut[ord - base];

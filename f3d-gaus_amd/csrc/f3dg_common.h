@@ -247,7 +247,6 @@ extern int g_f3dg_render_tail;         // N > 0: render3s switches a quadrant to
 extern int g_f3dg_render_count;        // 1: the one-wave kernel's counting variant (diagnostic; f3dg_debug_render_counts)
 extern int g_f3dg_render_wpb;          // quadrant waves per render3s workgroup: 1 (default) or 4 (a tile's four waves start together on one CU)
 extern int g_f3dg_render_replay;       // lab builds (-DF3DG_LAB) only: 2 / 3 = launch render3s_stage_only_kernel instead of the compositing kernel
-extern int g_f3dg_render_prefetch;     // 1: render3s touches the record / ellipse lines of the next slide's entries one slide ahead
 extern int g_f3dg_render_dma;          // render3 stages the records with global_load_lds_dwordx4 (1, default) or through registers (0)
 int f3dg_prof_bwd_begin(hipStream_t s);
 void f3dg_prof_bwd_mark(int slot, int stage_done, hipStream_t s);

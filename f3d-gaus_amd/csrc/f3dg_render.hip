@@ -968,17 +968,13 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
     unsigned long long pass = 0ull;               // per pixel: bits 0..31 older half, 32..63 newer half, in list order
     unsigned idn = lane < n ? point_list[range.x + lane] : 0u;
-    const bool prefetch = !TAIL && (tail_n & 0x100) != 0;      // (the launch argument's bit 8 when the tail schedule is not compiled in)
-    const unsigned scan_goal = prefetch ? 64u : 32u;
-    unsigned touch = 0u;
     if (__ballot(!done) != 0ull)
     for (;;) {
 #if F3DG_R3S_PRIO
         __builtin_amdgcn_s_setprio(F3DG_R3S_PRIO);     // scan + staging are chains of memory latencies: their loads should leave first
 #endif
-        // ---- scan: keep the entries whose box reaches this quadrant until 32 are pending (64 with the prefetch: the NEXT slide's ids are then
-        // known one slide ahead)
-        while (qpend < scan_goal && cursor < n) {
+        // ---- scan: keep the entries whose box reaches this quadrant until 32 are pending
+        while (qpend < 32u && cursor < n) {
             const unsigned idm = idn, pos = cursor + lane;
             cursor += 64u;
             idn = cursor + lane < n ? point_list[range.x + cursor + lane] : 0u;
@@ -1020,15 +1016,6 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         qhead += m;
         qpend -= m;
         if (COUNT) { n_staged += m; n_slides++; }
-        // ---- prefetch (option render_prefetch): one dword of the record line (lanes 0..31) and of the ellipse line (lanes 32..63) of the
-        // entries the NEXT slide will stage -- the lines arrive in the L2 while this slide's phase 2 runs, the gathers then find them there.
-        // The loaded word is never used; it stays "live" until the next slide's s_waitcnt so that the register is not reused under the load.
-        asm volatile("" :: "v"(touch));
-        touch = 0u;
-        if (prefetch && hl < qpend) {
-            const unsigned idp = sQ[(qhead + hl) & (F3DG_R3_RING - 1)].y;
-            touch = lane < 32u ? *reinterpret_cast<const unsigned*>(vrec + idp) : *reinterpret_cast<const unsigned*>(vcull + idp);
-        }
 #if F3DG_R3S_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1204,7 +1191,6 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         }
     }
     translate(2u);
-    asm volatile("" :: "v"(touch));
 #ifdef F3DG_LAB
     if (COUNT && lane == 0 && blockIdx.x < F3DG_SLIDE_LOG_N) g_f3dg_slide_log[blockIdx.x] = n_slides;
 #endif
@@ -1565,7 +1551,7 @@ void launch3s(const RenderArgs& a)
 {
     F3DG_KLAUNCH((render3s_fwd_kernel<AUX, FAST, 8, 1, NORMAL, DIST, COUNT, false>), dim3((unsigned)a.V * (unsigned)a.T * 4u), dim3(64), 0, a.s,
                  a.V, a.P, a.W, a.H, a.tiles_x, a.T, a.focal_x, a.focal_y, a.hdr, a.ranges, a.point_list, a.rec, a.cull, a.background, a.bg_per_view,
-                 a.out_color, a.final_T, a.n_contrib, g_f3dg_render_prefetch ? 0x100 : 0);
+                 a.out_color, a.final_T, a.n_contrib, 0);
 }
 
 } // namespace

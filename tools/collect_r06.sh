@@ -32,8 +32,14 @@ timeout 700 bash tools/pmc_kernel.sh $TAG/pmc_c2_fast render3s > /dev/null 2>&1
 timeout 700 bash tools/pmc_kernel.sh $TAG/pmc_real_fast render3s --data real > /dev/null 2>&1
 timeout 700 bash tools/pmc_kernel.sh $TAG/pmc_real_scan render5 --data real --scan 1 > /dev/null 2>&1
 timeout 700 bash tools/pmc_kernel.sh $TAG/pmc_c2_scan render5 --scan 1 > /dev/null 2>&1
+# the compositing backward: lock-step walk against the dense batches (C5, the real set's training step, one-view training calls)
+F3DG_OPTIONS="bwd_dense=0" $T python bench.py --workload c5 --steps 3 --warmup 1 > $O/bench_c5_lockstep.log 2>&1
+for o in 0 1; do F3DG_OPTIONS="bwd_dense=$o" $T python tools/bench_real_train.py 32 2>&1 | grep -v amdgpu.ids | tail -1 > $O/real_train_dense$o.log; done
+for o in 0 1; do F3DG_OPTIONS="bwd_dense=$o" $T python tools/bench_one_view_train.py 2>&1 | grep -v amdgpu.ids | tail -2 > $O/one_view_train_dense$o.log; done
+F3DG_OPTIONS="bwd_dense=0" timeout 700 bash tools/pmc_kernel.sh $TAG/pmc_c5_bwd3 render3_bwd --workload c5 > /dev/null 2>&1
+F3DG_OPTIONS="bwd_dense=1" timeout 700 bash tools/pmc_kernel.sh $TAG/pmc_c5_bwd5 render5_bwd --workload c5 > /dev/null 2>&1
 python tests/tools/parity_report.py > $O/parity_report.md 2>&1
 ( time timeout 1500 python -m pytest tests -m gpu -q --durations=10 ) > $O/pytest_gpu.log 2>&1
 tail -4 $O/pytest_gpu.log
-for f in bench_default bench_default_thread bench_default_main2 bench_real bench_real_scan bench_real_lean bench_real_lean_scan bench_default_scan bench_lean bench_sigma005 bench_589k bench_dropin bench_c5 bench_c4_fp32; do echo "$f: $(grep '^{' $O/$f.log | tail -1 | cut -c1-200)"; done
-for d in pmc_c2_fast pmc_real_fast pmc_real_scan pmc_c2_scan; do echo "== $d"; cat $O/$d/summary.txt 2>/dev/null | head -60; done
+for f in bench_default bench_default_thread bench_default_main2 bench_real bench_real_scan bench_real_lean bench_real_lean_scan bench_default_scan bench_lean bench_sigma005 bench_589k bench_dropin bench_c5 bench_c5_lockstep bench_c4_fp32; do echo "$f: $(grep '^{' $O/$f.log | tail -1 | cut -c1-200)"; done
+for d in pmc_c2_fast pmc_real_fast pmc_real_scan pmc_c2_scan pmc_c5_bwd3 pmc_c5_bwd5; do echo "== $d"; cat $O/$d/summary.txt 2>/dev/null | head -60; done
