@@ -98,9 +98,9 @@ def test_round3_host_logic(f3d):
     """Options, diagnostics, the small-call path's workspace carving and the integrate layouts: pure host arithmetic."""
     from f3dgaus_amd import _lib
     L = _lib.lib()
-    # the default library knows thirteen options and two diagnostics; the switches of the superseded generations exist in lab builds only
+    # the default library knows fifteen options and two diagnostics; the switches of the superseded generations exist in lab builds only
     defaults = ((b"render_fast", 1), (b"tile_cull", 1), (b"small_path", 2), (b"small_path_aux", 1), (b"render_lowocc", 1), (b"render_split", -1),
-                (b"render_unroll", -1), (b"render_pack", -1), (b"render_pack_th", 32), (b"render_scan", -1), (b"render_scan_th", 12), (b"bwd_occ", 5),
+                (b"render_unroll", -1), (b"render_pack", -1), (b"render_pack_th", 32), (b"render_scan", -1), (b"render_scan_th", 12), (b"render_scan_min", 4), (b"bwd_dense", 1), (b"bwd_occ", 5),
                 (b"render_count", 0), (b"time_launches", 0))
     for name, v in defaults:
         assert L.f3dg_set_option(name, v) == 0, name
