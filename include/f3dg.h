@@ -356,7 +356,7 @@ int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const u
                            const float* bias_b, float scale, uint16_t* y);
 
 /* Runtime switches: process-wide DEFAULTS for what a call's own flags do not say (every arithmetic / list / path choice of a call has a
- * flag, above). The library knows thirteen names and one diagnostic pair; everything else returns F3DG_ERR_BAD_ARG.
+ * flag, above). The library knows sixteen names and one diagnostic pair; everything else returns F3DG_ERR_BAD_ARG.
  *   "render_fast"   (default 1) arithmetic of the compositing forward: 0 = the reference's float32 / float64 operation order, 1 = error-free
  *                   float32 pairs for the float64 island and FMA-contracted accumulations downstream of alpha in inference calls (no
  *                   auxiliary planes; within 3e-7 of mode 0), exact in calls a backward follows, 2 = fast in every call.
@@ -383,7 +383,10 @@ int f3dg_residual_join_f16(void* stream, int N, int C, int HW, int nhwc, const u
  *   "render_scan"   (default -1) the split-pixel schedule (f3dg_render5.hip): -1 = the calls that carry F3DG_FLAG_SCAN, 1 = every fast
  *                   inference launch of the general path, 0 = never; "render_scan_th" (default 12; 64: every pending entry goes through
  *                   dense batches): fused trips while more than that many pixels take part.
- *   "bwd_occ"       (default 5) waves per SIMD the compositing backward (render3_bwd_kernel) is compiled for (2..6).
+ *   "bwd_dense"     (default 1) the compositing backward: 1 = render5_bwd_kernel (f3dg_backward5.hip: entry-major batches of (pixel, entry) pairs,
+ *                   segmented scans, one 128-byte accumulation record per (view, Gaussian)), 0 = render3_bwd_kernel (the lock-step walk of
+ *                   rounds 2-5); "bwd_occ" (default 5): waves per SIMD the lock-step kernel is compiled for (2..6).
+ *   "render_scan_min" (default 4) split-pixel mode: stragglers that hold fewer older-half entries than this finish the slide in fused trips.
  *   diagnostics: "render_count" (default 0) swaps in the counting variants of the compositing kernels (f3dg_debug_render_counts /
  *                   _render4_counts / _render5_counts); "time_launches" (default 0): f3dg_debug_launch_times.
  * A library built with -DF3DG_LAB (`F3DG_LAB=1 python f3d-gaus_amd/build.py --force`; f3dg_version() then ends in "lab") also compiles the
