@@ -8,7 +8,8 @@
 // position tail + mbcnt) and processed 64 to a batch, one pair per lane:
 //   * the pair's pixel constants (ray, dL/dpixel, the pixel's totals) come by ds_bpermute from the lane that owns the pixel, its record from
 //     the staged window; alpha is recomputed exactly as the forward did (f3dg_fast_t_G or the reference's float32 / float64 order);
-//   * the per-pixel recurrence -- T rebuilt by the reference's IEEE division, the colour / normal blended behind the entry -- lives in LDS
+//   * the per-pixel recurrence -- T rebuilt back to front (a correctly rounded reciprocal per pair, a multiply per layer), the colour /
+//     normal blended behind the entry -- lives in LDS
 //     (one float4 per pixel) and is advanced entry after entry: the lanes of one entry's run update the slots of their pixels together,
 //     successive runs of the batch follow each other. The six recurrences accum_rec[c] / accum_normal[k] of backward.cu are ONE here:
 //     they only ever meet dL/dpixel as a dot product and dL/dpixel is constant per pixel;
@@ -282,8 +283,12 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                 const float oma = 1.f - alpha;
 
                 // ---- the recurrence, entry after entry (a pixel has at most one pair per entry, so the lanes of a run never share a
-                // state slot; successive runs of the batch do): T is rebuilt by the reference's own IEEE division (backward.cu:803)
+                // state slot; successive runs of the batch do)
                 float Tr = 0.0f, A = 0.0f;
+                // T is rebuilt back to front as the reference does (backward.cu:803, T = T / (1 - alpha)), with the division taken off the
+                // serial chain: one correctly rounded reciprocal per pair up front, a multiply per run (<= 1 ulp from the quotient per layer;
+                // C5 8.1 -> 7.8 ms; the gradient tests, incl. the ill-conditioned B2, hold their bars)
+                const float inv_oma_ieee = 1.0f / oma;
                 unsigned long long heads = heads_all;
                 while (heads != 0ull) {
                     const unsigned a0 = (unsigned)__builtin_ctzll(heads);
@@ -291,7 +296,7 @@ render5_bwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
                     const unsigned b0 = heads != 0ull ? (unsigned)__builtin_ctzll(heads) : nb;
                     if (active && lane >= a0 && lane < b0) {
                         const float4 st = sS[own];
-                        Tr = st.x / oma;
+                        Tr = st.x * inv_oma_ieee;
                         A = st.z * st.w + (1.f - st.z) * st.y;
                         sS[own] = make_float4(Tr, A, alpha, u);
                     }
