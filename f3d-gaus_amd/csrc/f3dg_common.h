@@ -278,6 +278,9 @@ int f3dg_launch_render5(hipStream_t s, int V, int P, int W, int H, float focal_x
                         float* out_color, unsigned skip_channels, int count);
 
 // the dense compositing backward (f3dg_backward5.hip; option bwd_dense)
+int f3dg_launch_render5_small(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
+                              const unsigned* point_list, const F3dgRec* rec, const float4* cull, const float* background, int bg_per_view,
+                              float* out_color);
 extern int g_f3dg_bwd_dense;           // 1: render5_bwd_kernel (entry-major batches of (pixel, entry) pairs, segmented scans); 0: render3_bwd_kernel (lock-step walk)
 int f3dg_launch_render5_bwd(hipStream_t s, int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y, F3dgHeader* hdr,
                             const uint2* ranges, const unsigned* point_list, const unsigned* small_list, const F3dgRec* rec, const float4* cull,

@@ -1593,9 +1593,12 @@ int f3dg_launch_render(hipStream_t s, int V, int P, int W, int H, float focal_x,
     const bool small_launch = g_f3dg_render_lowocc && waves <= (g_f3dg_render_lowocc > 1 ? 1024ll * g_f3dg_render_lowocc : 2048ll);
     // (2) the split-pixel schedule of f3dg_render5.hip: fast inference launches that ask for it (F3DG_FLAG_SCAN, whatever their size) or,
     // with option render_scan 1, every such launch that is not small
-    if (fast && !save_aux && g_f3dg_render_scan != 0 && (scan || (g_f3dg_render_scan == 1 && !small_launch)))
+    if (fast && !save_aux && g_f3dg_render_scan != 0 && (scan || g_f3dg_render_scan == 1)) {
+        if (small_launch)       // one or two views: four lanes per pixel instead of helper-lane batches (render5p_fwd_kernel)
+            return f3dg_launch_render5_small(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color);
         return f3dg_launch_render5(s, V, P, W, H, focal_x, focal_y, hdr, ranges, point_list, rec, cull, background, bg_per_view, out_color,
                                    skip_channels, g_f3dg_render_count);
+    }
     if (small_launch) {
         // the multi-wave kernels of f3dg_render4.hip. Defaults by measurement at 65,536 pixel-ordered Gaussians (profiles/r05_final/
         // one_view.md): fast arithmetic -- producer + consumer waves, two entries per trip (render3p, 76.6 -> 57.9 us; two views 79.7 ->

@@ -28,12 +28,15 @@ def fast_mode():
     helpers.RENDER_MODE = None
 
 
-def _render(scene, device, scan, channels="all", th=None):
+def _render(scene, device, scan, channels="all", th=None, small_kernels=False):
+    """small_kernels=False: launches of one or two views take the general kernel too (option render_lowocc 0), so that render5_fwd_kernel is
+    what every scene exercises; True: the library's choice (render5p_fwd_kernel for such launches)."""
     from f3dgaus_amd import _lib
     L = _lib.lib()
     dev = lambda t: None if t is None else t.to(device)
     if th is not None:
         assert L.f3dg_set_option(b"render_scan_th", th) == 0
+    assert L.f3dg_set_option(b"render_lowocc", 1 if small_kernels else 0) == 0
     try:
         out, radii, ws = f3d.rasterize_views(
             dev(scene["means3D"]), dev(scene["opacities"]), dev(scene["viewmatrix"]), dev(scene["projmatrix"]), dev(scene["campos"]), dev(scene["bg"]),
@@ -45,6 +48,7 @@ def _render(scene, device, scan, channels="all", th=None):
         kernel = L.f3dg_debug_last_render_kernel()
     finally:
         L.f3dg_set_option(b"render_scan_th", 12)
+        L.f3dg_set_option(b"render_lowocc", 1)
     return out.cpu().numpy(), kernel
 
 
@@ -59,7 +63,7 @@ def test_scan_mode_meets_the_oracle(name, gpu_device):
     oracle = [run_oracle(scene, view=v)["out_color"] for v in range(scene["viewmatrix"].shape[0])]
     for th in (64, 12, 4):
         out, k = _render(scene, gpu_device, scan=True, th=th)
-        assert b"render5" in k, k
+        assert b"render5_fwd_kernel" in k, k
         assert np.isfinite(out).all()
         for v, o in enumerate(oracle):
             # (the well-conditioned part of the distortion channel -- fixture F12 -- lies 1.3e-3 from the oracle at most where the default fast
@@ -69,6 +73,16 @@ def test_scan_mode_meets_the_oracle(name, gpu_device):
         # 1e-4 each way; what is measured is two orders below)
         d = np.abs(out[:, [0, 1, 2, 7]] - base[:, [0, 1, 2, 7]])
         assert np.mean(d <= 2e-5) >= 0.9995, (name, th, float(d.max()), float(np.mean(d <= 2e-5)))
+    # launches of one or two views: four lanes per pixel (render5p_fwd_kernel), the same arithmetic class
+    n_waves = scene["viewmatrix"].shape[0] * ((scene["W"] + 15) // 16) * ((scene["H"] + 15) // 16) * 4
+    if n_waves <= 2048:
+        out, k = _render(scene, gpu_device, scan=True, small_kernels=True)
+        assert b"render5p_fwd_kernel" in k, k
+        assert np.isfinite(out).all()
+        for v, o in enumerate(oracle):
+            assert_render_parity(out[v], o, "scan, four lanes per pixel, %s view %d" % (name, v), dist_big_rtol=2e-3)
+        d = np.abs(out[:, [0, 1, 2, 7]] - base[:, [0, 1, 2, 7]])
+        assert np.mean(d <= 2e-5) >= 0.9995, (name, "render5p", float(d.max()), float(np.mean(d <= 2e-5)))
     # the build's own loops ask for rgb + depth + alpha only: the channels they read agree with the nine-channel call of the mode
     lean, kl = _render(scene, gpu_device, scan=True, channels="rgb_depth_alpha", th=12)
     full, _ = _render(scene, gpu_device, scan=True, th=12)
