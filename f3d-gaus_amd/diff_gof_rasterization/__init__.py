@@ -374,7 +374,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 
 def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp,
-                  exact=None):
+                  exact=None, scan=None):
     """One reference-shaped rasterizer call (one view): (color [1,9,H,W], radii [1,P], workspace). Shared by the autograd Function
     and by the wrapper's inference path (`rasterize_nograd`)."""
     device = means3D.device
@@ -394,7 +394,7 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
             colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp,
             view2gaussian_precomp=view2gaussian_precomp, sh_degree=rs.sh_degree, scale_modifier=rs.scale_modifier,
             kernel_size=rs.kernel_size, workspace=workspace, save_aux=needs_grad, check=check, out=out, radii=radii,
-            max_rendered=max_rendered, exact=exact)
+            max_rendered=max_rendered, exact=exact, scan=scan if not needs_grad else None)
 
     if rs.debug:
         # rast_py:88-98: keep a host copy of the arguments (in the order of the reference's tuple, rast_py:61-84) and dump
@@ -427,11 +427,12 @@ def _forward_impl(rs, needs_grad, means3D, sh, colors_precomp, opacities, scales
     return color, radii, ws
 
 
-def rasterize_nograd(means3D, sh, colors_precomp, opacities, scales, rotations, raster_settings, exact=None):
+def rasterize_nograd(means3D, sh, colors_precomp, opacities, scales, rotations, raster_settings, exact=None, scan=None):
     """The inference call of `GaussianRasterizer_GOF.forward` without the nn.Module and autograd.Function around it (the wrapper's
-    own no-grad path: ~30 us of host time per call less). Returns (color [9,H,W], radii [P]). ``exact``: see `rasterize_views`."""
+    own no-grad path: ~30 us of host time per call less). Returns (color [9,H,W], radii [P]). ``exact``, ``scan``: see `rasterize_views`
+    (a one-view call with ``scan=True`` composites with four lanes per pixel: render5p_fwd_kernel)."""
     color, radii, _ = _forward_impl(raster_settings, False, means3D, sh, colors_precomp, opacities, scales, rotations, None, None,
-                                    exact=exact)
+                                    exact=exact, scan=scan)
     return color[0], radii[0]
 
 

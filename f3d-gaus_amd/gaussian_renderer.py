@@ -31,6 +31,17 @@ def _raster_exact(cfg):
     return None if v is None else bool(v)
 
 
+def _raster_scan(cfg):
+    """cfg['model']['raster_scan'] (this build's key, default absent = off): inference calls composite with the split-pixel schedule
+    (F3DG_FLAG_SCAN: same blended entries, sums associated as a scan; within the fast arithmetic's 1e-4, not bit-identical to it)."""
+    try:
+        m = cfg['model']
+        v = m.get('raster_scan', None) if hasattr(m, 'get') else (m['raster_scan'] if 'raster_scan' in m else None)
+    except (KeyError, TypeError):
+        return None
+    return None if v is None else bool(v)
+
+
 def focal2fov(focal, pixels):
     return 2 * math.atan(pixels / (2 * focal))
 
@@ -178,7 +189,7 @@ def _render_one(get, bs, world_view_transform, full_proj_transform, camera_cente
         # inference: the same call without the nn.Module / autograd.Function wrapping (host time; the kernels are the same)
         shs = _cat_sh(get("features_dc"), get("features_rest")) if override_color is None else None
         rendered_image, radii = rasterize_nograd(means3D, shs, None if override_color is None else get("rgbs"), opacity, scales,
-                                                 rotations, raster_settings, exact=exact)
+                                                 rotations, raster_settings, exact=exact, scan=_raster_scan(cfg))
     elif override_color is None:
         shs = _cat_sh(get("features_dc"), get("features_rest"))
         rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None,
@@ -324,7 +335,7 @@ def render_views(pc: dict, bs, world_view_transforms, full_proj_transforms, came
             image_height=res, image_width=res, tanfovx=tanfov, tanfovy=tanfov, sh=shs, colors_precomp=colors,
             scales=take(pc["scaling"]), rotations=take(pc["rotation"]), sh_degree=cfg['model']['max_sh_degree'],
             scale_modifier=scaling_modifier, kernel_size=kernel_size, workspace=workspace, check=check, n_sets=n_sets,
-            channels=channels, exact=_raster_exact(cfg))
+            channels=channels, exact=_raster_exact(cfg), scan=_raster_scan(cfg))
         lean = channels != "all"
         nw = dn = None
         if epilogue:

@@ -108,3 +108,29 @@ def test_scan_flag_is_ignored_where_the_mode_does_not_apply(gpu_device):
     assert b"render5" not in L.f3dg_debug_last_render_kernel()
     d = f3d.rasterize_views(*args, save_aux=True, scan=False, **kw)[0]
     assert torch.equal(c, d)
+
+
+def test_dropin_renderer_takes_the_scan_mode_from_cfg(gpu_device):
+    """cfg['model']['raster_scan'] = True: render_predicted_more_v2_gof as visualize.py calls it (one view, no gradient) composites with four
+    lanes per pixel (render5p_fwd_kernel) and stays inside the 1e-4 gate; absent, the call is the default fast kernel's, bit for bit."""
+    from f3dgaus_amd import _lib, cameras
+    L = _lib.lib()
+    scene = make_scene(P=65536, res=(256, 256), s0=0.01, view="oblique", pixel_ordered=True, seed=1)
+    o = run_oracle(scene)["out_color"]
+    cfg = cameras.default_cfg(256)
+    pc = {"xyz": scene["means3D"], "opacity": scene["opacities"], "scaling": scene["scales"], "rotation": scene["rotations"],
+          "features_dc": scene["shs"][:, :1], "features_rest": scene["shs"][:, 1:]}
+    pc = {k: v.unsqueeze(0).to(gpu_device) for k, v in pc.items()}
+    args = (scene["viewmatrix"][:1].unsqueeze(0).to(gpu_device), scene["projmatrix"][:1].unsqueeze(0).to(gpu_device),
+            scene["campos"][:1].unsqueeze(0).to(gpu_device), scene["bg"].reshape(1, 3).to(gpu_device))
+    with torch.no_grad():
+        base = f3d.render_predicted_more_v2_gof(pc, 0, *args, cfg)
+        assert b"render5" not in L.f3dg_debug_last_render_kernel()
+        cfg['model']['raster_scan'] = True
+        out = f3d.render_predicted_more_v2_gof(pc, 0, *args, cfg)
+        assert b"render5p_fwd_kernel" in L.f3dg_debug_last_render_kernel()
+    raster = lambda r: torch.cat([r["render"], torch.zeros(3, 256, 256, device=gpu_device), r["rendered_depth"], r["rendered_alpha"], r["distortion_map"]]).cpu().numpy()
+    ref = o.copy(); ref[3:6] = 0
+    assert_render_parity(raster(out), ref, "drop-in, raster_scan", dist_big_rtol=2e-3)
+    d = np.abs(raster(out)[[0, 1, 2, 7]] - raster(base)[[0, 1, 2, 7]])
+    assert np.mean(d <= 2e-5) >= 0.9995
