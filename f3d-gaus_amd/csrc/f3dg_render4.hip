@@ -25,6 +25,7 @@
 // (the hand-over and its scalar bookkeeping cost what the packing saves) -- hence the default of f3dg_launch_render: render_pack -1.
 #include "f3dg_blend.h"
 #include "f3dg_ellipse.h"
+#include "f3dg_producer.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -443,79 +444,17 @@ render3p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     const bool producer = threadIdx.x >= 64u;             // (wave-uniform)
     const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
 
-    __shared__ float4 sR[2][4][F3DG_R4_WIN];              // two windows of records, [window][16-byte chunk][entry]
-    __shared__ uint2 sQ[F3DG_R3U_RING];                   // (list position, Gaussian id) of the kept entries (the producer's ring)
-    __shared__ unsigned long long sPass[2][64];           // per window: the pass mask of every pixel
-    __shared__ unsigned sM[2], sHead[2];                  // per window: its number of entries (0: the list has ended), its first ring slot
+    __shared__ float4 sR[3][4][F3DG_PROD_WIN];            // three windows of records, [window % 3][16-byte chunk][entry]
+    __shared__ uint2 sQ[F3DG_PROD_RING];                  // (list position, Gaussian id) of the kept entries (the producer's ring)
+    __shared__ unsigned long long sPass[2][64];           // per window (k & 1): the pass mask of every pixel
+    __shared__ uint2 sMH[2];                              // per window: (its number of entries (0: the list has ended), its first ring slot)
     __shared__ unsigned sStop[2];                         // [b]: set by the consumer when every pixel was done after the window in buffer b
 
     if (threadIdx.x < 2u) sStop[threadIdx.x] = 0u;
 
     if (producer) {
-        // ================================================ wave 1: scan, gather, phase 1 ================================================
-        uint2 range = ranges[(size_t)view * T + tile];
-        if (hdr->overflow) range = make_uint2(0, 0);
-        const unsigned n = range.y - range.x;
-        const F3dgRec* vrec = rec + (size_t)view * P;
-        const float4* vcull = cull + (size_t)view * P;
-        const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        unsigned cursor = 0, qhead = 0, qcount = 0;
-        unsigned id0 = lane < n ? point_list[range.x + lane] : 0u;
-        unsigned id1 = 64u + lane < n ? point_list[range.x + 64u + lane] : 0u;
-        unsigned id2 = 128u + lane < n ? point_list[range.x + 128u + lane] : 0u;      // three 64-id chunks of the list in flight
-        unsigned buf = 0;
-        for (;;) {
-            // the next window: entries [qhead, qhead + m) of the ring
-            while (qcount < F3DG_R4_WIN && cursor < n) {
-                const unsigned idm = id0, pos = cursor + lane;
-                cursor += 64u;
-                id0 = id1;
-                id1 = id2;
-                id2 = cursor + 128u + lane < n ? point_list[range.x + cursor + 128u + lane] : 0u;
-                const bool keep = pos < n && (idm & qbit) != 0u;
-                const unsigned long long kb = __ballot(keep);
-                if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R3U_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
-                qcount += (unsigned)__popcll(kb);
-            }
-            wave_lds_fence();
-            const unsigned m = qcount < F3DG_R4_WIN ? qcount : F3DG_R4_WIN;
-            float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (lane < m) {
-                const unsigned id = sQ[(qhead + lane) & (F3DG_R3U_RING - 1)].y;
-                const float4* src = reinterpret_cast<const float4*>(vrec + id);
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
-                                                     (__attribute__((address_space(3))) void*)&sR[buf][c][0], 16, 0, 0);
-                e4 = vcull[id];
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_lds_fence();
-            if (m != 0u) {
-                const float ec = lane < m ? sR[buf][3][lane].w : 0.0f;
-                int pass_lo = 0, pass_hi = 0;
-                const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
-                const float v0 = (float)qy0 - e4.y;
-                float dxx[8], adx[8], dyy[8], cdy[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    dxx[q] = u0 + (float)q;
-                    adx[q] = e4.z * dxx[q];
-                    dyy[q] = v0 + (float)q;
-                    cdy[q] = ec * dyy[q] * dyy[q];
-                }
-                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
-                sPass[buf][lane] = ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
-            }
-            if (lane == 0) { sM[buf] = m; sHead[buf] = qhead; }
-            __syncthreads();                                  // window `buf` is ready; the consumer has finished the window before it
-            if (m == 0u || sStop[buf ^ 1u] != 0u)           // (the flag of the window composited before this barrier: the consumer's next write goes to the other one)
-                break;
-            qhead += m;
-            qcount -= m;
-            buf ^= 1u;
-        }
+        // ================================================ wave 1: scan, gather, phase 1 (f3dg_producer.h) ================================
+        f3dg_window_producer(lane, view, tile, quad, qx0, qy0, P, T, hdr, ranges, point_list, rec, cull, sR, sQ, sPass, sMH, sStop, 1u);
         return;
     }
 
@@ -531,10 +470,10 @@ render3p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     F3dgPixel st;
     f3dg_pixel_init(st);
     {
-        unsigned buf = 0;
+        unsigned buf = 0, rb = 0;                          // window k: pass masks in [k & 1], records in [k % 3]
         for (;;) {
             __syncthreads();                                  // window `buf` is ready
-            const unsigned m = sM[buf];
+            const unsigned m = sMH[buf].x;
             if (m == 0u || sStop[buf ^ 1u] != 0u)
                 break;
             unsigned long long pass = done ? 0ull : sPass[buf][lane];
@@ -551,7 +490,7 @@ render3p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
                 float cr[U], cg[U], cb[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const float4 q0 = sR[buf][0][j[u]], q1 = sR[buf][1][j[u]], q2 = sR[buf][2][j[u]], q3 = sR[buf][3][j[u]];
+                    const float4 q0 = sR[rb][0][j[u]], q1 = sR[rb][1][j[u]], q2 = sR[rb][2][j[u]], q3 = sR[rb][3][j[u]];
                     pr[u] = f3dg_pair_eval<FAST, true, true, FAST>(ray_x, ray_y, q0, q1, q2);
                     if (!have[u]) pr[u].alpha = 0.0f;
                     cr[u] = q3.x; cg[u] = q3.y; cb[u] = q3.z;
@@ -568,14 +507,15 @@ render3p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
                 }
             }
             if (SAVE_AUX) {             // slots -> 1-based list positions (the reference's `contributor`)
-                const unsigned head = sHead[buf];
+                const unsigned head = sMH[buf].y;
                 if (st.last_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
-                    st.last_contributor = sQ[(head + (st.last_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+                    st.last_contributor = sQ[(head + (st.last_contributor - F3DG_R4_FLAG)) & (F3DG_PROD_RING - 1)].x + 1u;
                 if (st.max_contributor - F3DG_R4_FLAG < (unsigned)F3DG_R4_WIN)
-                    st.max_contributor = sQ[(head + (st.max_contributor - F3DG_R4_FLAG)) & (F3DG_R3U_RING - 1)].x + 1u;
+                    st.max_contributor = sQ[(head + (st.max_contributor - F3DG_R4_FLAG)) & (F3DG_PROD_RING - 1)].x + 1u;
             }
             if (__ballot(!done) == 0ull && lane == 0) sStop[buf] = 1u;  // (read by both waves after the next barrier)
             buf ^= 1u;
+            rb = rb == 2u ? 0u : rb + 1u;
         }
     }
 

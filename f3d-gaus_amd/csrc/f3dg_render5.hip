@@ -32,6 +32,7 @@
 // (tests/test_scan_mode_gpu.py). LDS per wave: 4 KB of records + 512 B id ring + 512 B triple ring.
 #include "f3dg_blend.h"
 #include "f3dg_ellipse.h"
+#include "f3dg_producer.h"
 #include "f3dg_segscan.h"
 
 #include <stdio.h>
@@ -41,6 +42,7 @@ extern thread_local const char* g_f3dg_last_render_kernel;
 int g_f3dg_render_scan = -1;          // option render_scan: -1 (default) = calls that ask for it (F3DG_FLAG_SCAN); 1 = every fast inference launch of the general path; 0 = never
 int g_f3dg_render_scan_min = 4;       // option render_scan_min: stragglers that hold fewer than this many older-half entries each finish the slide in fused trips (0: always compact)
 int g_f3dg_render_scan_th = 12;       // option render_scan_th: fused trips while more than this many pixels take part (64: every trip is compacted)
+int g_f3dg_render_scan_lanes = 4;     // lab option render_scan_lanes: lanes per pixel of the one- and two-view kernel (4, or 2: measured 54.8 against 52.7 us)
 
 // work counters (option render_count = 1; f3dg_debug_render5_counts): [0] staged entries, [1] scanned, [2] fused trips, [3] slides,
 // [4] lane-trips of fused trips, [5] waves, [6] dense batches, [7] pairs in dense batches, [8] pixels compacted, [9] slides with a compaction
@@ -393,18 +395,18 @@ render5_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x
 // ---- SMALL launches (one or two views: every wave alone on its SIMD) in the split-pixel arithmetic --------------------------------------
 // A one-view launch is 1,024 quadrants on 1,024 SIMDs: a quadrant lasts as long as its pixels' chains of dependent instructions (render3p,
 // f3dg_render4.hip: a producer wave prepares the next window while a consumer wave composites, ~85 dependent instructions per entry and
-// pixel). Lanes are free there, so here every pixel gets FOUR: a workgroup is the producer wave of render3p + four consumer waves of 16
-// pixels x 4 lanes; a trip takes the pixel's next four passing entries, one per lane, evaluates their stateless parts side by side
+// pixel). Here every pixel gets FOUR lanes (LPP; two were measured slower, eight do not fit the CU's wave slots): a workgroup is the producer
+// wave of render3p (f3dg_producer.h) + four consumer waves of 16 pixels x 4 lanes; a trip takes the pixel's next four passing entries, one per lane, evaluates their stateless parts side by side
 // (f3dg_pair_eval), and a two-step segmented product over the quad (DPP quad_perm) gives every lane the transmittance in front of ITS
 // entry -- hence its weight, the 1e-4 stop as a per-lane predicate, the median-depth candidate. Nothing else crosses lanes per trip: each
 // lane adds its own contributions to its own accumulators (the distortion term needs the quad's prefix sums of m w and m^2 w), and the four
 // partial sums of a pixel meet once, at the end. ~150 dependent instructions per FOUR entries. The arithmetic class of F3DG_FLAG_SCAN (same
 // blended entries per pixel, sums associated differently): gated with it (tests/test_scan_mode_gpu.py).
-#define F3DG_R5P_RING 256
 #define F3DG_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 #define F3DG_QDPP(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false))
 
-__global__ void __launch_bounds__(320, 1)
+template <int LPP>          // lanes per pixel: 4 (four consumer waves of 16 pixels) or 2 (two consumer waves of 32 pixels)
+__global__ void __launch_bounds__(64 * (LPP + 1), 1)
 render5p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_x, float focal_y,
                     const F3dgHeader* __restrict__ hdr, const uint2* __restrict__ ranges,
                     const unsigned* __restrict__ point_list, const F3dgRec* __restrict__ rec,
@@ -416,89 +418,27 @@ render5p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     const unsigned tile = unit >> 2, quad = unit & 3u;
     const unsigned tile_x = tile % (unsigned)tiles_x, tile_y = tile / (unsigned)tiles_x;
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned wv = threadIdx.x >> 6;                 // 0..3: consumers, 4: the producer (wave-uniform)
-    const bool producer = wv == 4u;
+    const unsigned wv = threadIdx.x >> 6;                 // 0..LPP-1: consumers, LPP: the producer (wave-uniform)
+    const bool producer = wv == (unsigned)LPP;
     const unsigned qx0 = tile_x * F3DG_TILE + (quad & 1u) * 8u, qy0 = tile_y * F3DG_TILE + (quad >> 1) * 8u;
 
-    __shared__ float4 sR[2][4][F3DG_R5_WIN];              // two windows of records, [window][16-byte chunk][entry]
-    __shared__ uint2 sQ[F3DG_R5P_RING];                   // (list position, Gaussian id) of the kept entries (the producer's ring)
+    __shared__ float4 sR[3][4][F3DG_PROD_WIN];            // three windows of records, [window % 3][16-byte chunk][entry]
+    __shared__ uint2 sQ[F3DG_PROD_RING];                   // (list position, Gaussian id) of the kept entries (the producer's ring)
     __shared__ unsigned long long sPass[2][64];           // per window: the pass mask of every pixel
-    __shared__ unsigned sM[2], sHead[2];                  // per window: its number of entries (0: the list has ended), its first ring slot
+    __shared__ uint2 sMH[2];                              // per window: (its number of entries (0: the list has ended), its first ring slot)
     __shared__ unsigned sStop[2];                         // [b]: bit w set by consumer wave w when its 16 pixels were done after the window in buffer b
 
     if (threadIdx.x < 2u) sStop[threadIdx.x] = 0u;
 
     if (producer) {
-        // ================================================ wave 4: scan, gather, phase 1 (render3p's producer) ================================================
-        uint2 range = ranges[(size_t)view * T + tile];
-        if (hdr->overflow) range = make_uint2(0, 0);
-        const unsigned n = range.y - range.x;
-        const F3dgRec* vrec = rec + (size_t)view * P;
-        const float4* vcull = cull + (size_t)view * P;
-        const unsigned qbit = 1u << (F3DG_ID_BITS + quad);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        unsigned cursor = 0, qhead = 0, qcount = 0;
-        unsigned id0 = lane < n ? point_list[range.x + lane] : 0u;
-        unsigned id1 = 64u + lane < n ? point_list[range.x + 64u + lane] : 0u;
-        unsigned id2 = 128u + lane < n ? point_list[range.x + 128u + lane] : 0u;      // three 64-id chunks of the list in flight
-        unsigned buf = 0;
-        for (;;) {
-            // the next window: entries [qhead, qhead + m) of the ring
-            while (qcount < F3DG_R5_WIN && cursor < n) {
-                const unsigned idm = id0, pos = cursor + lane;
-                cursor += 64u;
-                id0 = id1;
-                id1 = id2;
-                id2 = cursor + 128u + lane < n ? point_list[range.x + cursor + 128u + lane] : 0u;
-                const bool keep = pos < n && (idm & qbit) != 0u;
-                const unsigned long long kb = __ballot(keep);
-                if (keep) sQ[(qhead + qcount + (unsigned)__popcll(kb & lt)) & (F3DG_R5P_RING - 1)] = make_uint2(pos, idm & F3DG_ID_MASK);
-                qcount += (unsigned)__popcll(kb);
-            }
-            wave_lds_fence5();
-            const unsigned m = qcount < F3DG_R5_WIN ? qcount : F3DG_R5_WIN;
-            float4 e4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (lane < m) {
-                const unsigned id = sQ[(qhead + lane) & (F3DG_R5P_RING - 1)].y;
-                const float4* src = reinterpret_cast<const float4*>(vrec + id);
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
-                                                     (__attribute__((address_space(3))) void*)&sR[buf][c][0], 16, 0, 0);
-                e4 = vcull[id];
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_lds_fence5();
-            if (m != 0u) {
-                const float ec = lane < m ? sR[buf][3][lane].w : 0.0f;
-                int pass_lo = 0, pass_hi = 0;
-                const float u0 = lane < m ? (float)qx0 - e4.x : __builtin_nanf("");
-                const float v0 = (float)qy0 - e4.y;
-                float dxx[8], adx[8], dyy[8], cdy[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    dxx[q] = u0 + (float)q;
-                    adx[q] = e4.z * dxx[q];
-                    dyy[q] = v0 + (float)q;
-                    cdy[q] = ec * dyy[q] * dyy[q];
-                }
-                quad_ballots<0>(pass_lo, pass_hi, fmaf(dxx[0], fmaf(e4.w, dyy[0], adx[0]), cdy[0]), dxx, adx, dyy, cdy, e4.w);
-                sPass[buf][lane] = ((unsigned long long)(unsigned)pass_hi << 32) | (unsigned)pass_lo;
-            }
-            if (lane == 0) { sM[buf] = m; sHead[buf] = qhead; }
-            __syncthreads();                                  // window `buf` is ready; the consumer has finished the window before it
-            if (m == 0u || sStop[buf ^ 1u] == 0xFu)           // (the flag of the window composited before this barrier: the consumer's next write goes to the other one)
-                break;
-            qhead += m;
-            qcount -= m;
-            buf ^= 1u;
-        }
+        // ================================================ wave 4: scan, gather, phase 1 (f3dg_producer.h) ================================
+        f3dg_window_producer(lane, view, tile, quad, qx0, qy0, P, T, hdr, ranges, point_list, rec, cull, sR, sQ, sPass, sMH, sStop, (1u << LPP) - 1u);
         return;
     }
 
     // ================================================== waves 0..3: 16 pixels x 4 lanes each ==================================================
-    const unsigned sub = lane & 3u;                       // which of the pixel's next four entries this lane takes
-    const unsigned q = 16u * wv + (lane >> 2);            // the pixel, 0..63 in the quadrant
+    const unsigned sub = lane & (unsigned)(LPP - 1);      // which of the pixel's next LPP entries this lane takes
+    const unsigned q = (64u / LPP) * wv + lane / LPP;     // the pixel, 0..63 in the quadrant
     const unsigned pix_x = qx0 + (q & 7u), pix_y = qy0 + (q >> 3);
     const bool inside = pix_x < (unsigned)W && pix_y < (unsigned)H;
     const float pixf_x = (float)pix_x + 0.5f, pixf_y = (float)pix_y + 0.5f;
@@ -511,53 +451,73 @@ render5p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
     unsigned med_rank = 0u;                               // with that entry's rank in the walk (0: none)
     unsigned rank_base = 0u;
     {
-        unsigned buf = 0;
+        unsigned buf = 0, rb = 0;                          // window k: pass masks in [k & 1], records in [k % 3]
         for (;;) {
             __syncthreads();                                  // window `buf` is ready
-            const unsigned m = sM[buf];
-            if (m == 0u || sStop[buf ^ 1u] == 0xFu)
+            const unsigned m = sMH[buf].x;
+            if (m == 0u || sStop[buf ^ 1u] == (1u << LPP) - 1u)
                 break;
             unsigned long long pass = done ? 0ull : sPass[buf][q];
             while (pass != 0ull) {
-                // the pixel's next four passing entries: lane `sub` takes the one of that rank
-                const unsigned long long p1 = pass & (pass - 1ull), p2 = p1 & (p1 - 1ull), p3 = p2 & (p2 - 1ull);
-                const unsigned long long mine = sub == 0u ? pass : sub == 1u ? p1 : sub == 2u ? p2 : p3;
-                pass = p3 & (p3 - 1ull);
+                // the pixel's next LPP passing entries: lane `sub` takes the one of that rank
+                unsigned long long mine;
+                {
+                    const unsigned long long p1 = pass & (pass - 1ull);
+                    if constexpr (LPP == 4) {
+                        const unsigned long long p2 = p1 & (p1 - 1ull), p3 = p2 & (p2 - 1ull);
+                        mine = sub == 0u ? pass : sub == 1u ? p1 : sub == 2u ? p2 : p3;
+                        pass = p3 & (p3 - 1ull);
+                    } else {
+                        mine = sub == 0u ? pass : p1;
+                        pass = p1 & (p1 - 1ull);
+                    }
+                }
                 const bool have = mine != 0ull;
                 const int j = have ? __builtin_ctzll(mine) : 0;
-                const float4 q0 = sR[buf][0][j], q1 = sR[buf][1][j], q2 = sR[buf][2][j], q3 = sR[buf][3][j];
+                const float4 q0 = sR[rb][0][j], q1 = sR[rb][1][j], q2 = sR[rb][2][j], q3 = sR[rb][3][j];
                 const F3dgPair pr = f3dg_pair_eval<true, true, true, true>(ray_x, ray_y, q0, q1, q2);
                 asm volatile("" :: "v"(q2.w), "v"(q3.w), "v"(pr.alpha));
                 const float alpha = have ? pr.alpha : 0.0f;
-                // transmittance in front of this lane's entry: T of the pixel x the product over the quad's earlier lanes
+                // transmittance in front of this lane's entry: T of the pixel x the product over the group's earlier lanes
+                // (DPP quad_perm patterns: SHR1 = the lane before within the group, LAST = the group's last lane, swaps for the sums)
+                constexpr int SHR1 = LPP == 4 ? F3DG_QP(0, 0, 1, 2) : F3DG_QP(0, 0, 2, 2);
+                constexpr int LAST = LPP == 4 ? F3DG_QP(3, 3, 3, 3) : F3DG_QP(1, 1, 3, 3);
                 float Pi = 1.0f - alpha;
-                float t = F3DG_QDPP(Pi, F3DG_QP(0, 0, 1, 2));
-                Pi *= sub >= 1u ? t : 1.0f;
-                t = F3DG_QDPP(Pi, F3DG_QP(0, 1, 0, 1));
-                Pi *= sub >= 2u ? t : 1.0f;
-                const float Psh = F3DG_QDPP(Pi, F3DG_QP(0, 0, 1, 2));
+                float t = F3DG_QDPP(Pi, SHR1);
+                float Psh;
+                if constexpr (LPP == 4) {
+                    Pi *= sub >= 1u ? t : 1.0f;
+                    t = F3DG_QDPP(Pi, F3DG_QP(0, 1, 0, 1));
+                    Pi *= sub >= 2u ? t : 1.0f;
+                    Psh = F3DG_QDPP(Pi, SHR1);
+                } else {
+                    Psh = t;                                 // lane 1's exclusive product is lane 0's factor
+                    Pi *= sub >= 1u ? t : 1.0f;
+                }
                 const float Tb = Tf * (sub >= 1u ? Psh : 1.0f), tT = Tf * Pi;
                 const bool killed = !(tT >= 0.0001f);         // the stop (forward.cu:543-548), or an entry behind it
                 const float w = killed ? 0.0f : alpha * Tb;
                 C0 = fmaf(q3.x, w, C0); C1 = fmaf(q3.y, w, C1); C2 = fmaf(q3.z, w, C2); C7 += w;
                 C3 = fmaf(pr.nn0, w, C3); C4 = fmaf(pr.nn1, w, C4); C5 = fmaf(pr.nn2, w, C5);
-                // distortion (forward.cu:552-557): the running sums IN FRONT of this entry = the pixel's + the quad's earlier lanes'
+                // distortion (forward.cu:552-557): the running sums IN FRONT of this entry = the pixel's + the group's earlier lanes'
                 const float a1 = pr.m * w, a2 = pr.m * a1;
                 float s1 = a1, s2 = a2;
-                t = F3DG_QDPP(s1, F3DG_QP(0, 0, 1, 2)); s1 += sub >= 1u ? t : 0.0f;
-                t = F3DG_QDPP(s2, F3DG_QP(0, 0, 1, 2)); s2 += sub >= 1u ? t : 0.0f;
-                t = F3DG_QDPP(s1, F3DG_QP(0, 1, 0, 1)); s1 += sub >= 2u ? t : 0.0f;
-                t = F3DG_QDPP(s2, F3DG_QP(0, 1, 0, 1)); s2 += sub >= 2u ? t : 0.0f;
+                t = F3DG_QDPP(s1, SHR1); s1 += sub >= 1u ? t : 0.0f;
+                t = F3DG_QDPP(s2, SHR1); s2 += sub >= 1u ? t : 0.0f;
+                if constexpr (LPP == 4) {
+                    t = F3DG_QDPP(s1, F3DG_QP(0, 1, 0, 1)); s1 += sub >= 2u ? t : 0.0f;
+                    t = F3DG_QDPP(s2, F3DG_QP(0, 1, 0, 1)); s2 += sub >= 2u ? t : 0.0f;
+                }
                 const float E1 = (s1 - a1) + D1, E2 = (s2 - a2) + D2;
                 Cd = fmaf(fmaf(-2.0f * pr.m, E1, fmaf(pr.m * pr.m, 1.0f - Tb, E2)), w, Cd);
-                D1 += F3DG_QDPP(s1, F3DG_QP(3, 3, 3, 3));
-                D2 += F3DG_QDPP(s2, F3DG_QP(3, 3, 3, 3));
+                D1 += F3DG_QDPP(s1, LAST);
+                D2 += F3DG_QDPP(s2, LAST);
                 if (!killed && alpha != 0.0f && Tb > 0.5f) { med_t = pr.t; med_rank = rank_base + (unsigned)j + 1u; }
-                // the pixel's new T; if one of the four stopped: T in front of the stopping entry = T - the weights blended before it
+                // the pixel's new T; if one of the group stopped: T in front of the stopping entry = T - the weights blended before it
                 float ws = w;
                 ws += F3DG_QDPP(ws, F3DG_QP(1, 0, 3, 2));
-                ws += F3DG_QDPP(ws, F3DG_QP(2, 3, 0, 1));
-                const float tT3 = F3DG_QDPP(tT, F3DG_QP(3, 3, 3, 3));
+                if constexpr (LPP == 4) ws += F3DG_QDPP(ws, F3DG_QP(2, 3, 0, 1));
+                const float tT3 = F3DG_QDPP(tT, LAST);
                 const bool stop = !(tT3 >= 0.0001f);
                 Tf = stop ? Tf - ws : tT3;
                 if (stop) { done = true; pass = 0ull; }
@@ -565,19 +525,22 @@ render5p_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
             rank_base += 64u;
             if (__ballot(!done) == 0ull && lane == 0) atomicOr(&sStop[buf], 1u << wv);      // (read by all waves after the next barrier)
             buf ^= 1u;
+            rb = rb == 2u ? 0u : rb + 1u;
         }
     }
     // the four partial sums of a pixel meet; the median depth is the candidate of the highest rank
-#define F3DG_QSUM(x) do { x += F3DG_QDPP(x, F3DG_QP(1, 0, 3, 2)); x += F3DG_QDPP(x, F3DG_QP(2, 3, 0, 1)); } while (0)
+#define F3DG_QSUM(x) do { x += F3DG_QDPP(x, F3DG_QP(1, 0, 3, 2)); if constexpr (LPP == 4) x += F3DG_QDPP(x, F3DG_QP(2, 3, 0, 1)); } while (0)
     F3DG_QSUM(C0); F3DG_QSUM(C1); F3DG_QSUM(C2); F3DG_QSUM(C3); F3DG_QSUM(C4); F3DG_QSUM(C5); F3DG_QSUM(C7); F3DG_QSUM(Cd);
 #undef F3DG_QSUM
     {
         unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)med_rank, F3DG_QP(1, 0, 3, 2), 0xf, 0xf, false);
         float tt = F3DG_QDPP(med_t, F3DG_QP(1, 0, 3, 2));
         if (r > med_rank) { med_rank = r; med_t = tt; }
-        r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)med_rank, F3DG_QP(2, 3, 0, 1), 0xf, 0xf, false);
-        tt = F3DG_QDPP(med_t, F3DG_QP(2, 3, 0, 1));
-        if (r > med_rank) { med_rank = r; med_t = tt; }
+        if constexpr (LPP == 4) {
+            r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)med_rank, F3DG_QP(2, 3, 0, 1), 0xf, 0xf, false);
+            tt = F3DG_QDPP(med_t, F3DG_QP(2, 3, 0, 1));
+            if (r > med_rank) { med_rank = r; med_t = tt; }
+        }
     }
     if (inside && sub == 0u) {
         const size_t HW = (size_t)H * W;
@@ -629,9 +592,14 @@ int f3dg_launch_render5_small(hipStream_t s, int V, int P, int W, int H, float f
 {
     const int tiles_x = (W + F3DG_TILE - 1) / F3DG_TILE, tiles_y = (H + F3DG_TILE - 1) / F3DG_TILE;
     const int T = tiles_x * tiles_y;
-    F3DG_KLAUNCH(render5p_fwd_kernel, dim3((unsigned)V * (unsigned)T * 4u), dim3(320), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges,
-                 point_list, rec, cull, background, bg_per_view, out_color);
-    snprintf(g_kernel_name5, sizeof g_kernel_name5, "render5p_fwd_kernel<four lanes per pixel>");
+    const int lpp = g_f3dg_render_scan_lanes == 2 ? 2 : 4;
+    if (lpp == 4)
+        F3DG_KLAUNCH(render5p_fwd_kernel<4>, dim3((unsigned)V * (unsigned)T * 4u), dim3(320), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges,
+                     point_list, rec, cull, background, bg_per_view, out_color);
+    else
+        F3DG_KLAUNCH(render5p_fwd_kernel<2>, dim3((unsigned)V * (unsigned)T * 4u), dim3(192), 0, s, V, P, W, H, tiles_x, T, focal_x, focal_y, hdr, ranges,
+                     point_list, rec, cull, background, bg_per_view, out_color);
+    snprintf(g_kernel_name5, sizeof g_kernel_name5, "render5p_fwd_kernel<%d lanes per pixel>", lpp);
     g_f3dg_last_render_kernel = g_kernel_name5;
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
