@@ -19,8 +19,9 @@ Workloads (`--workload`):
       + the 8 orbit views of every merged set + frame packing + the gather. A "step" = B x 8 final views.
 
 Every number of the JSON line is measured in THIS run except the `*_from_profiles` objects, which are read from the committed
-rocprofv3 PMC passes of the same command (profiles/<round>/traffic.json) and say so: hardware counters cannot be read from inside
-the process. C2 at N = 1 runs three timed loops of K steps each: frames left in HBM (`value_in_hbm`), frames packed to 8-bit RGB
+rocprofv3 PMC passes of the same command (profiles/<round>/traffic.json) and say so. Hardware counters cannot be read from inside
+the process: at N = 1 the C2 line's `roofline.traffic` comes from two child runs of the same workload under `rocprofv3 --pmc`
+(FETCH_SIZE, WRITE_SIZE; `roofline.traffic_live`; --no-pmc or F3DG_BENCH_PMC=0 skips them, a failure leaves null and says why). C2 at N = 1 runs three timed loops of K steps each: frames left in HBM (`value_in_hbm`), frames packed to 8-bit RGB
 and copied to pinned host memory behind the next step's rendering (`value`: SURVEY 8d "views/s ... including the final D2H of RGB"),
 and the in-HBM loop again in the reference's float32/float64 arithmetic (`value_exact`, `roofline_exact`). `roofline` is the
 compositing kernel, timed with HIP events the library records on the launch stream, on the list entries the launch is handed
@@ -87,6 +88,8 @@ def parse():
     ap.add_argument("--scan", type=int, choices=[0, 1], default=int(os.environ.get("F3DG_SCAN", "0")),
                     help="1: the calls carry F3DG_FLAG_SCAN -- the split-pixel compositing schedule (render5_fwd_kernel), its own 1e-4-gated mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) that fill roofline.traffic at N = 1 (also: F3DG_BENCH_PMC=0)")
     ap.add_argument("--no-d2h", action="store_true", help="skip the timed loops with frame packing + device-to-host copy: `value` is then the in-HBM rate")
     ap.add_argument("--d2h-issue", choices=["thread", "main"], default=os.environ.get("F3DG_D2H_ISSUE", "main"),
                     help="who issues the pack + device-to-host copy of a finished step on the side stream: the step's own host thread "
@@ -522,8 +525,9 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
             rf["units"] = ("COUNTED by the kernel: 4 B x list entries scanned + 80 B x list entries staged + 36 B x pixels + 8 B x tiles -- the "
                            "72 B x list-entry formula gives more than 1.3 x that here (frac_formula_on_all_list_entries) because saturated "
                            "quadrants never read most of their tile's list")
-    # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes, which cannot run inside this process): `traffic` stays
-    # null in this line; the figure of the newest committed profile of THIS configuration is under traffic_from_profiles, with its source
+    # HBM bytes per launch need PMC counters (separate rocprofv3 --pmc passes, which cannot run inside this process): at N = 1 `traffic` is
+    # filled at the end by two child runs of this workload under rocprofv3 (live_pmc_traffic); the figure of the newest committed
+    # profile of THIS configuration stays beside it under traffic_from_profiles, with its source
     rf.update({"traffic": None,
                "traffic_from_profiles": prof.get("traffic"), "valu_from_profiles": prof.get("valu"),
                "valu_issue_frac_from_profiles": (prof.get("valu") or {}).get("valu_issue_frac"),
@@ -587,7 +591,73 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         result["roofline_exact"]["note"] = "same run, option render_fast = 0: the reference's float32/float64 operation order; frames left in HBM"
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(g, cams, shs, P, RES, args.cpu_sample_views if args.data == "synthetic" else max(2, args.cpu_sample_views // 3))
+    if world == 1 and not args.no_pmc and os.environ.get("F3DG_BENCH_PMC", "1") != "0":
+        live = live_pmc_traffic(args, kernel_name)
+        rf["traffic"] = live.get("bytes_per_launch")
+        rf["traffic_live"] = live
+        if rf["traffic"]:
+            rf["frac_on_counter_traffic"] = rf["traffic"] / (rf["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     return result
+
+
+def live_pmc_traffic(args, kernel_name):
+    """HBM bytes per launch of the compositing kernel from the PMC counters, measured NOW: this same workload run again in two child
+    processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, nothing else traced -- the recipe of
+    MI355X_MICROARCH.md's HBM section), 3 steps each, frames left in HBM. Per pass: the mean over the dispatches of that kernel with the
+    largest grid (the timed launches). traffic = 2 x FETCH_SIZE + WRITE_SIZE, both in KB in the CSV (the gfx950 correction: FETCH_SIZE
+    tallies a 128-byte line as 64 -- calibrated for this kernel's 64-byte gathers in notes/r06.md section 1). Any failure (no rocprofv3,
+    time-out, no matching dispatch) leaves bytes_per_launch None and says why; the bench line is printed either way."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    out = {"bytes_per_launch": None, "kernel": kernel_name, "method": "2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this workload "
+           "in child processes of this run (3 steps each, mean over the largest-grid dispatches of the kernel)"}
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        out["error"] = "rocprofv3 not found"
+        return out
+    sub = (kernel_name or "").split("<")[0].strip()
+    if not sub:
+        out["error"] = "no kernel name"
+        return out
+    cmd_tail = [sys.executable, os.path.abspath(__file__), "--workload", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-d2h",
+                "--no-exact", "--no-pmc", "--gaussians", str(args.gaussians), "--views", str(args.views), "--res", str(args.res),
+                "--sigma0", repr(args.sigma0), "--views-per-call", str(args.views_per_call), "--render-mode", args.render_mode,
+                "--tile-cull", str(args.tile_cull), "--data", args.data, "--channels", args.channels, "--scan", str(args.scan)]
+    env = dict(os.environ, TMPDIR="/tmp", F3DG_BENCH_PMC="0")
+    vals = {}
+    t0 = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="f3dg_pmc_", dir="/tmp")
+        try:
+            p = subprocess.Popen([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "b", "--"] + cmd_tail,
+                                 cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                out["error"] = "%s pass timed out" % counter
+                return out
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    rows += [r for r in csv.DictReader(fh) if sub in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
+            if not rows:
+                out["error"] = "%s pass: no dispatch of %s in the counter file (exit code %s)" % (counter, sub, p.returncode)
+                return out
+            big = max(int(r["Grid_Size"]) for r in rows)
+            v = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == big]
+            vals[counter] = (sum(v) / len(v), len(v))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"][0] * 1024.0, vals["WRITE_SIZE"][0] * 1024.0
+    out.update({"bytes_per_launch": 2.0 * fetch + write, "fetch_size_bytes_x2": 2.0 * fetch, "write_size_bytes": write,
+                "dispatches_averaged": vals["FETCH_SIZE"][1], "seconds": round(time.time() - t0, 1)})
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------- C4

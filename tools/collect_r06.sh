@@ -5,11 +5,12 @@
 TAG=${1:-r06}
 export TMPDIR=/tmp; R=/root/repo; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R; ulimit -c 0
 T="timeout 400"
+export F3DG_BENCH_PMC=0        # only the two full bench lines below measure roofline.traffic live (two rocprofv3 child runs each)
 python -c "import f3dgaus_amd; from f3dgaus_amd import _lib; print(_lib.lib().f3dg_version().decode())" 2>/dev/null > $O/version.txt
-$T python bench.py > $O/bench_default.log 2>&1
+F3DG_BENCH_PMC=1 timeout 900 python bench.py > $O/bench_default.log 2>&1
 $T python bench.py --no-cpu-baseline --d2h-issue thread > $O/bench_default_thread.log 2>&1
 $T python bench.py --no-cpu-baseline --d2h-issue main > $O/bench_default_main2.log 2>&1
-$T python bench.py --data real > $O/bench_real.log 2>&1
+F3DG_BENCH_PMC=1 timeout 900 python bench.py --data real > $O/bench_real.log 2>&1
 $T python bench.py --data real --scan 1 --no-cpu-baseline > $O/bench_real_scan.log 2>&1
 $T python bench.py --data real --channels rgb_depth_alpha --no-cpu-baseline > $O/bench_real_lean.log 2>&1
 $T python bench.py --data real --channels rgb_depth_alpha --scan 1 --no-cpu-baseline > $O/bench_real_lean_scan.log 2>&1

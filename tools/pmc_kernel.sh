@@ -4,7 +4,7 @@
 # left out).   usage: tools/pmc_kernel.sh <out_tag> <kernel substring> <bench.py args...>     (env F3DG_* pass through)
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; KSUB=$2; shift 2
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-d2h --no-exact $*"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-d2h --no-exact --no-pmc $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- $B > $O/bench_under_rocprof.log 2>&1
 rm -f $O/stats/*kernel_trace.csv
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $O/sq1 -o b -- $B > /dev/null 2>&1
