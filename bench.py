@@ -592,7 +592,11 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(g, cams, shs, P, RES, args.cpu_sample_views if args.data == "synthetic" else max(2, args.cpu_sample_views // 3))
     if world == 1 and not args.no_pmc and os.environ.get("F3DG_BENCH_PMC", "1") != "0":
-        live = live_pmc_traffic(args, kernel_name)
+        live = live_pmc_traffic(kernel_name, ["--workload", "c2", "--steps", "3", "--warmup", "1", "--no-d2h", "--no-exact",
+                                              "--gaussians", str(args.gaussians), "--views", str(args.views), "--res", str(args.res),
+                                              "--sigma0", repr(args.sigma0), "--views-per-call", str(args.views_per_call),
+                                              "--render-mode", args.render_mode, "--tile-cull", str(args.tile_cull), "--data", args.data,
+                                              "--channels", args.channels, "--scan", str(args.scan)])
         rf["traffic"] = live.get("bytes_per_launch")
         rf["traffic_live"] = live
         if rf["traffic"]:
@@ -600,7 +604,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     return result
 
 
-def live_pmc_traffic(args, kernel_name):
+def live_pmc_traffic(kernel_name, workload_args):
     """HBM bytes per launch of the compositing kernel from the PMC counters, measured NOW: this same workload run again in two child
     processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, nothing else traced -- the recipe of
     MI355X_MICROARCH.md's HBM section), 3 steps each, frames left in HBM. Per pass: the mean over the dispatches of that kernel with the
@@ -614,7 +618,7 @@ def live_pmc_traffic(args, kernel_name):
     import subprocess
     import tempfile
     out = {"bytes_per_launch": None, "kernel": kernel_name, "method": "2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this workload "
-           "in child processes of this run (3 steps each, mean over the largest-grid dispatches of the kernel)"}
+           "in child processes of this run (a few steps each, mean over the largest-grid dispatches of the kernel)"}
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         out["error"] = "rocprofv3 not found"
@@ -623,10 +627,7 @@ def live_pmc_traffic(args, kernel_name):
     if not sub:
         out["error"] = "no kernel name"
         return out
-    cmd_tail = [sys.executable, os.path.abspath(__file__), "--workload", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-d2h",
-                "--no-exact", "--no-pmc", "--gaussians", str(args.gaussians), "--views", str(args.views), "--res", str(args.res),
-                "--sigma0", repr(args.sigma0), "--views-per-call", str(args.views_per_call), "--render-mode", args.render_mode,
-                "--tile-cull", str(args.tile_cull), "--data", args.data, "--channels", args.channels, "--scan", str(args.scan)]
+    cmd_tail = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-pmc"] + list(workload_args)
     env = dict(os.environ, TMPDIR="/tmp", F3DG_BENCH_PMC="0")
     vals = {}
     t0 = time.time()
@@ -886,12 +887,19 @@ def run_c5(args, rank, world, dist, device, comm_device, f3d, L):
     # `frac` never exceeds what the kernel moved: SURVEY 8d's formula prices every contributing pair at 68 bytes of atomics, which the
     # wave-level reduction of this kernel never issues; where a committed PMC profile of this configuration exists and the formula gives
     # more than 1.3 x its figure, the counter figure is the primary number and the formula's stays under its own key
+    if world == 1 and not args.no_pmc and os.environ.get("F3DG_BENCH_PMC", "1") != "0":
+        live = live_pmc_traffic(bwd_kernel, ["--workload", "c5", "--steps", "2", "--warmup", "1", "--sigma0", repr(args.sigma0)])
+        bwd_rf["traffic"] = live.get("bytes_per_launch")
+        bwd_rf["traffic_live"] = live
+        if bwd_rf["traffic"]:      # this run's own counter passes take precedence over the committed profile's
+            bwd_rf["frac_on_counter_traffic"] = bwd_rf["traffic"] / (bwd_rf["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     fc = bwd_rf.get("frac_on_counter_traffic")
     if fc and bwd_rf["frac"] > 1.3 * fc:
         bwd_rf["frac_formula_80R_60WHV_68C"] = bwd_rf["frac"]
         bwd_rf["frac"] = fc
         bwd_rf["achieved"] = fc * HBM_PEAK_GBS
-        bwd_rf["units"] = "HBM bytes per launch from the PMC passes of the newest committed profile of this configuration (2 x FETCH_SIZE + WRITE_SIZE) / this run's kernel time"
+        bwd_rf["units"] = ("HBM bytes per launch from PMC passes (2 x FETCH_SIZE + WRITE_SIZE: this run's child passes when `traffic` is set, "
+                           "else the newest committed profile of this configuration) / this run's kernel time")
     return {
         "metric": "rendered views/sec at 256x256 (N Gaussians, K cams)", "value": world * V * args.steps / elapsed, "unit": "views/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

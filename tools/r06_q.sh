@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo; export TMPDIR=/tmp; ulimit -c 0
-S=$(date +%s); python bench.py 2> gpurun_out/r06q_err.txt | tail -1 > gpurun_out/r06q_bench.json; echo "wall $(( $(date +%s) - S )) s"; tail -3 gpurun_out/r06q_err.txt
+S=$(date +%s); python bench.py --workload c5 --steps 3 --warmup 1 2> gpurun_out/r06q_err.txt | tail -1 > gpurun_out/r06q_bench.json; echo "wall $(( $(date +%s) - S )) s"; tail -3 gpurun_out/r06q_err.txt
 
 python - <<'PY'
 import json
