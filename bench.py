@@ -94,6 +94,11 @@ def parse():
     ap.add_argument("--d2h-issue", choices=["thread", "main"], default=os.environ.get("F3DG_D2H_ISSUE", "main"),
                     help="who issues the pack + device-to-host copy of a finished step on the side stream: the step's own host thread "
                          "(three asynchronous calls behind an event) or a second host thread")
+    ap.add_argument("--d2h-path", choices=["direct", "copy"], default=os.environ.get("F3DG_D2H_PATH", "copy"),
+                    help="how a finished step's 8-bit frames reach pinned host memory: copy (default) = f3dg_pack_frames into HBM + a "
+                         "device-to-host copy (HIP runs it as a whole-chip shader copy, __amd_rocclr_copyBuffer); direct = "
+                         "f3dg_pack_frames_host writes them there (one kernel of a few workgroups; measured 1 % slower, notes/r06.md section 3)")
+    ap.add_argument("--d2h-workgroups", type=int, default=int(os.environ.get("F3DG_D2H_WG", "0")), help="direct path: workgroups of the pack kernel (0: 64)")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra timed loop in the reference's arithmetic (value_exact / roofline_exact)")
     ap.add_argument("--cpu-sample-views", type=int, default=12)
     return ap.parse_args()
@@ -300,7 +305,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     if world == 1 and not args.no_d2h:
         import queue
         import threading
-        side = torch.cuda.Stream(device=device)
+        side = torch.cuda.Stream(device=device)       # (stream priorities -1 / 0 on either side: no difference, notes/r06.md section 3)
         outs = [out, torch.empty_like(out)]
         packed = [torch.empty((V, RES, RES, 3), dtype=torch.uint8, device=device) for _ in range(2)]
         host = [torch.empty((V, RES, RES, 3), dtype=torch.uint8) for _ in range(2)]
@@ -317,6 +322,13 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
         # that issues the next step's kernels.
         copier_error = []
 
+        def pack_and_copy(k):           # (on the side stream) frames of buffer k -> host[k]
+            if args.d2h_path == "direct" and host[k].is_pinned():
+                f3d.gaussian_renderer.pack_frames(outs[k], out=host[k], max_workgroups=args.d2h_workgroups)
+            else:
+                f3d.gaussian_renderer.pack_frames(outs[k], out=packed[k])
+                host[k].copy_(packed[k], non_blocking=True)
+
         def copier():
             torch.cuda.set_device(device)
             while True:
@@ -326,8 +338,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                 try:
                     with torch.cuda.stream(side):
                         side.wait_event(rendered[k])
-                        f3d.gaussian_renderer.pack_frames(outs[k], out=packed[k])
-                        host[k].copy_(packed[k], non_blocking=True)
+                        pack_and_copy(k)
                         copied[k].record()
                 except Exception as ex:          # the main thread must not wait for ever on issued[k]
                     copier_error.append(ex)
@@ -353,8 +364,7 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                 rendered[k].record()
                 with torch.cuda.stream(side):
                     side.wait_event(rendered[k])
-                    f3d.gaussian_renderer.pack_frames(outs[k], out=packed[k])
-                    host[k].copy_(packed[k], non_blocking=True)
+                    pack_and_copy(k)
                     copied[k].record()
                 return
             wait_issued(issued[k])
@@ -398,6 +408,18 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
             e2.synchronize()
             leg.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
         leg_pack_ms, leg_copy_ms = min(x[0] for x in leg), min(x[1] for x in leg)
+        leg_direct_ms = None
+        if host[0].is_pinned():
+            legd = []
+            for _ in range(3):
+                e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                with torch.cuda.stream(side):
+                    e0.record()
+                    f3d.gaussian_renderer.pack_frames(outs[0], out=host[0], max_workgroups=args.d2h_workgroups)
+                    e1.record()
+                e1.synchronize()
+                legd.append(e0.elapsed_time(e1))
+            leg_direct_ms = min(legd)
 
         host_f32 = torch.empty((V, 3, RES, RES), dtype=torch.float32).pin_memory()
 
@@ -407,14 +429,17 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
 
         e32 = timed(step_f32, gat.barrier, 1, args.steps)
         d2h = {"uint8_rgb": {"value": V * args.steps / elapsed, "unit": "views/s", "ms_per_step": 1e3 * elapsed / args.steps,
-                             "bytes_per_step": V * RES * RES * 3, "pipelined": True, "issued_by": args.d2h_issue,
-                             "leg_alone_ms": {"pack_frames": leg_pack_ms, "copy_to_pinned": leg_copy_ms,
+                             "bytes_per_step": V * RES * RES * 3, "pipelined": True, "issued_by": args.d2h_issue, "path": args.d2h_path,
+                             "leg_alone_ms": {"pack_frames_host (direct path: one kernel writes pinned host memory)": leg_direct_ms,
+                                              "direct_GBps": V * RES * RES * 3 / (leg_direct_ms * 1e-3) / 1e9 if leg_direct_ms else None,
+                                              "pack_frames": leg_pack_ms, "copy_to_pinned": leg_copy_ms,
                                               "copy_GBps": V * RES * RES * 3 / (leg_copy_ms * 1e-3) / 1e9 if leg_copy_ms > 0 else None}},
                "float32_rgb": {"value": V * args.steps / e32, "unit": "views/s", "ms_per_step": 1e3 * e32 / args.steps,
                                "bytes_per_step": V * RES * RES * 12, "pipelined": False},
-               "note": "uint8: f3dg_pack_frames + copy to pinned host memory on a side stream, double-buffered behind the next step's "
-                       "rendering, all waited for inside the timed region (= `value`); float32: the three RGB planes copied after every "
-                       "step on the same stream"}
+               "note": "uint8: the frames of a finished step go to pinned host memory on a side stream, double-buffered behind the next "
+                       "step's rendering, all waited for inside the timed region (= `value`) -- path direct: f3dg_pack_frames_host writes "
+                       "them there (one kernel, a few workgroups); path copy: f3dg_pack_frames + a device-to-host copy, which HIP runs as a "
+                       "whole-chip shader copy; float32: the three RGB planes copied after every step on the same stream"}
 
     # (3) the same build in the reference's own arithmetic (float32 with the float64 island, forward.cu:511-579), frames left in HBM
     exact = None

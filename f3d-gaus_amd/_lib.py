@@ -58,6 +58,7 @@ SIGNATURES = {
     "f3dg_render_epilogue_view": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p]),
     "f3dg_cycle_inputs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "f3dg_pack_frames": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "f3dg_pack_frames_host": (_i, [_p, _i, _i, _i, _i, _p, _p, _i]),
     "f3dg_group_norm_silu": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
     "f3dg_group_norm_silu_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p]),
     "f3dg_group_norm_silu_pb": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _i, _p]),

@@ -209,6 +209,42 @@ pack_frames_kernel(size_t HW, int src_channels, const float* __restrict__ src, u
     }
 }
 
+// The same frames written STRAIGHT into pinned host memory (device-accessible: hipHostMalloc / torch pin_memory): no staging copy in
+// HBM and no copy command. HIP runs a device -> pinned-host hipMemcpyAsync as a shader copy over the whole chip
+// (__amd_rocclr_copyBuffer, 0.43 ms per 23.6 MB on this box: tools/micro/d2h_engine.py) which takes wave slots from the next step's
+// rendering; this kernel is PCIe-bound all the same, so a FEW workgroups (max_workgroups) move it in the same time and leave the
+// rest of the chip alone. A lane produces one 16-byte chunk of the byte stream -- 5 1/3 pixels: byte B of a frame is channel B % 3 of
+// pixel B / 3 -- so that a store instruction of a wave writes 1 KB of contiguous host memory (the fabric forwards partial lines as
+// small PCIe writes); the 16 float reads of a lane are shared with its neighbours through L1 / L2.
+__global__ void __launch_bounds__(F3DG_BLOCK)
+pack_frames_host_kernel(size_t n_bytes, size_t HW, int src_channels, const float* __restrict__ src, unsigned char* __restrict__ dst)
+{
+    auto cv = [](float v) -> unsigned { return (unsigned)(255.0f * fminf(fmaxf(v, 0.0f), 1.0f)); };
+    const size_t frame_bytes = 3 * HW, n_chunks = (n_bytes + 15) / 16;
+    for (size_t c = (size_t)blockIdx.x * F3DG_BLOCK + threadIdx.x; c < n_chunks; c += (size_t)gridDim.x * F3DG_BLOCK) {
+        const size_t b0 = 16 * c;
+        size_t n = b0 / frame_bytes;
+        unsigned rem = (unsigned)(b0 - n * frame_bytes);           // (a frame is < 4 GB)
+        const float* s = src + n * (size_t)src_channels * HW;
+        unsigned p = rem / 3u, ch = rem - 3u * p;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (b0 + j < n_bytes)
+                w[j >> 2] |= cv(s[(size_t)ch * HW + p]) << (8 * (j & 3));
+            if (++ch == 3u) {
+                ch = 0u;
+                if (++p == (unsigned)HW) { p = 0u; s += (size_t)src_channels * HW; }       // the chunk runs into the next frame
+            }
+        }
+        if (b0 + 16 <= n_bytes) {
+            *reinterpret_cast<uint4*>(dst + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int j = 0; b0 + j < n_bytes; j++) dst[b0 + j] = (unsigned char)(w[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int f3dg_splat_head(void* stream, int B, int H, int W, const float* net_out, const float* depth,
@@ -265,6 +301,28 @@ extern "C" int f3dg_pack_frames(void* stream, int n_frames, int H, int W, int sr
     if (((uintptr_t)src & 15u) || ((uintptr_t)dst & 3u)) return F3DG_ERR_BAD_ARG;
     F3DG_KLAUNCH(pack_frames_kernel, dim3((unsigned)((HW / 4 + F3DG_BLOCK) / F3DG_BLOCK), (unsigned)n_frames), dim3(F3DG_BLOCK), 0,
                        (hipStream_t)stream, HW, src_channels, src, dst);
+    F3DG_HIP_CHECK(hipGetLastError());
+    return F3DG_OK;
+}
+
+extern "C" int f3dg_pack_frames_host(void* stream, int n_frames, int H, int W, int src_channels, const float* src,
+                                     unsigned char* dst_host, int max_workgroups)
+{
+    if (n_frames < 0 || H <= 0 || W <= 0 || src_channels < 3 || !src || !dst_host) return F3DG_ERR_BAD_ARG;
+    if (n_frames == 0) return F3DG_OK;
+    if ((uintptr_t)dst_host & 15u) return F3DG_ERR_BAD_ARG;
+    const size_t HW = (size_t)H * W, n_bytes = 3 * HW * (size_t)n_frames;
+    if (3 * HW >= ((size_t)1 << 32)) return F3DG_ERR_BAD_ARG;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dst_host) != hipSuccess || at.type != hipMemoryTypeHost) {      // pinned, device-accessible host memory only
+        (void)hipGetLastError();
+        return F3DG_ERR_BAD_ARG;
+    }
+    const size_t need = ((n_bytes + 15) / 16 + F3DG_BLOCK - 1) / F3DG_BLOCK;
+    size_t grid = max_workgroups > 0 ? (size_t)max_workgroups : 64;
+    if (grid > need) grid = need;
+    F3DG_KLAUNCH(pack_frames_host_kernel, dim3((unsigned)grid), dim3(F3DG_BLOCK), 0, (hipStream_t)stream, n_bytes, HW, src_channels, src,
+                 dst_host);
     F3DG_HIP_CHECK(hipGetLastError());
     return F3DG_OK;
 }

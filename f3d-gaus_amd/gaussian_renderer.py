@@ -88,17 +88,28 @@ def _epilogue_autograd(rendered_image, world_view_transform, W, H, FoVx, FoVy):
     return normal_world, output.permute(2, 0, 1)
 
 
-def pack_frames(raster, out=None):
+def pack_frames(raster, out=None, max_workgroups=0):
     """raster [n,C>=3,H,W] float32 on the HIP device -> uint8 [n,H,W,3] = (255 * clip(raster[:, :3], 0, 1)).astype(uint8),
-    the frame format of visualize.py:416, in one kernel (f3dg_pack_frames). ``out``: a contiguous uint8 [n,H,W,3] tensor to fill."""
+    the frame format of visualize.py:416, in one kernel (f3dg_pack_frames). ``out``: a contiguous uint8 [n,H,W,3] tensor to fill --
+    on the same device, or a PINNED host tensor: the kernel then writes the frames straight into host memory
+    (f3dg_pack_frames_host, at most ``max_workgroups`` workgroups, 0 = 64; no staging buffer and no copy command -- HIP's device ->
+    host copy is a whole-chip shader copy that competes with the next launch). The host sees them once the stream is synchronised."""
     if raster.device.type != "cuda":
         raise RuntimeError("pack_frames needs a tensor on a HIP device (no CPU fallback)")
     r = raster.contiguous().float()
     n, Cc, H, W = r.shape
     if out is None:
         out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=r.device)
-    elif out.dtype != torch.uint8 or out.device != r.device or not out.is_contiguous() or out.numel() != n * H * W * 3:
-        raise RuntimeError(f"out must be a contiguous uint8 tensor of shape ({n}, {H}, {W}, 3) on {r.device}")
+    elif out.dtype != torch.uint8 or not out.is_contiguous() or out.numel() != n * H * W * 3:
+        raise RuntimeError(f"out must be a contiguous uint8 tensor of shape ({n}, {H}, {W}, 3)")
+    elif out.device.type == "cpu":
+        if not out.is_pinned():
+            raise RuntimeError("a host `out` must be pinned (tensor.pin_memory()): the kernel writes into it")
+        rc = _lib.lib().f3dg_pack_frames_host(_stream(), n, H, W, Cc, _lib.ptr(r), _lib.ptr(out), int(max_workgroups))
+        _lib.check(rc, "f3dg_pack_frames_host")
+        return out
+    elif out.device != r.device:
+        raise RuntimeError(f"out must be on {r.device} or in pinned host memory")
     rc = _lib.lib().f3dg_pack_frames(_stream(), n, H, W, Cc, _lib.ptr(r), _lib.ptr(out))
     _lib.check(rc, "f3dg_pack_frames")
     return out

@@ -299,6 +299,13 @@ int f3dg_render_epilogue_view(void* stream, int n_views, int H, int W, const flo
  * (uint8)(255 * clamp(src[:, 0:3], 0, 1)) with src [n_frames,src_channels,H,W] float32 planar (src_channels = 9 for the
  * rasterizer output), i.e. what visualize.py:407,416 computes on the host per frame. */
 int f3dg_pack_frames(void* stream, int n_frames, int H, int W, int src_channels, const float* src, unsigned char* dst);
+/* The same frames written directly into PINNED HOST memory (hipHostMalloc / torch pin_memory; 16-byte aligned; anything else is
+ * F3DG_ERR_BAD_ARG): the frames of visualize.py:407,416 arrive in host memory with one kernel and no copy command. HIP executes a
+ * device -> pinned-host hipMemcpyAsync as a whole-chip shader copy, which competes with whatever renders next; this kernel uses at most
+ * max_workgroups workgroups (0: 64) -- the transfer is PCIe-bound either way. Visible to the host after the stream (or an event
+ * recorded behind the call) is synchronised. */
+int f3dg_pack_frames_host(void* stream, int n_frames, int H, int W, int src_channels, const float* src, unsigned char* dst_host,
+                          int max_workgroups);
 
 /* Hand-off of the cycle aggregation (reference visualize.py:311, 331-333): from the rendered rasters [B * V, 9, H, W] (frame
  * b * V + v) to the next predictor inputs, view-major: xin [V, B, 4, H, W] = cat(clamp(rgb, 0, 1), alpha) and

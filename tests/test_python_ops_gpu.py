@@ -169,6 +169,33 @@ def test_pack_frames_matches_reference_formula(gpu_device):
         assert got.shape == ref.shape and np.array_equal(got, ref), (n, C, H, W)
 
 
+def test_pack_frames_into_pinned_host_memory(gpu_device):
+    """f3dg_pack_frames_host: the same bytes written by the kernel straight into a pinned host tensor -- sizes whose byte stream is
+    not a multiple of 16 and whose 16-byte chunks straddle frames, few and many workgroups; pageable or misaligned memory is refused."""
+    import ctypes as C
+    from f3dgaus_amd import _lib
+    from f3dgaus_amd.gaussian_renderer import pack_frames
+    torch.manual_seed(4)
+    for (n, Cc, H, W) in ((5, 9, 64, 64), (3, 3, 17, 23), (1, 9, 256, 256), (7, 4, 5, 3), (120, 9, 32, 32)):
+        x = (torch.rand(n, Cc, H, W) * 1.6 - 0.3)
+        ref = (255 * np.clip(x[:, :3].permute(0, 2, 3, 1).numpy(), 0, 1)).astype(np.uint8)
+        xd = x.to(gpu_device)
+        for wg in (0, 1, 1000):
+            host = torch.full((n, H, W, 3), 77, dtype=torch.uint8).pin_memory()
+            got = pack_frames(xd, out=host, max_workgroups=wg)
+            torch.cuda.synchronize()
+            assert got is host and np.array_equal(host.numpy(), ref), (n, Cc, H, W, wg)
+    with pytest.raises(RuntimeError):
+        pack_frames(xd, out=torch.empty((120, 32, 32, 3), dtype=torch.uint8))             # pageable
+    L = _lib.lib()
+    pageable = torch.empty(120 * 32 * 32 * 3 + 64, dtype=torch.uint8)
+    rc = L.f3dg_pack_frames_host(None, 120, 32, 32, 9, C.c_void_p(xd.data_ptr()), C.c_void_p(pageable.data_ptr()), 0)
+    assert rc == _lib.ERR_BAD_ARG
+    pinned = torch.empty(120 * 32 * 32 * 3 + 64, dtype=torch.uint8).pin_memory()
+    rc = L.f3dg_pack_frames_host(None, 120, 32, 32, 9, C.c_void_p(xd.data_ptr()), C.c_void_p(pinned.data_ptr() + 4), 0)
+    assert rc == _lib.ERR_BAD_ARG
+
+
 def test_cycle_aggregation_matches_the_reference_loop_fixture(gpu_device):
     """tests/golden/cycle_loop.npz was produced by the reference's OWN loop (visualize.py:224-340 executed from where it lies)
     around the reference's own predictor and renderer wrapper, with the C oracle as the rasterizer and formula-defined weights
