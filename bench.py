@@ -629,6 +629,22 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
     return result
 
 
+def pmc_counter_mean(directory, kernel_substring, counter):
+    """(mean value, dispatches) of `counter` over the dispatches with the LARGEST grid among the kernels whose name contains
+    `kernel_substring`, from the *counter_collection.csv files rocprofv3 --pmc left under `directory` (set-up launches of the same kernel
+    on fewer views have smaller grids and are left out); None when no row matches."""
+    import csv
+    rows = []
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            rows += [r for r in csv.DictReader(fh) if kernel_substring in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
+    if not rows:
+        return None
+    big = max(int(r["Grid_Size"]) for r in rows)
+    v = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == big]
+    return sum(v) / len(v), len(v)
+
+
 def live_pmc_traffic(kernel_name, workload_args):
     """HBM bytes per launch of the compositing kernel from the PMC counters, measured NOW: this same workload run again in two child
     processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, nothing else traced -- the recipe of
@@ -636,8 +652,6 @@ def live_pmc_traffic(kernel_name, workload_args):
     largest grid (the timed launches). traffic = 2 x FETCH_SIZE + WRITE_SIZE, both in KB in the CSV (the gfx950 correction: FETCH_SIZE
     tallies a 128-byte line as 64 -- calibrated for this kernel's 64-byte gathers in notes/r06.md section 1). Any failure (no rocprofv3,
     time-out, no matching dispatch) leaves bytes_per_launch None and says why; the bench line is printed either way."""
-    import csv
-    import glob
     import shutil
     import signal
     import subprocess
@@ -668,16 +682,11 @@ def live_pmc_traffic(kernel_name, workload_args):
                 p.wait()
                 out["error"] = "%s pass timed out" % counter
                 return out
-            rows = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    rows += [r for r in csv.DictReader(fh) if sub in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
-            if not rows:
+            got = pmc_counter_mean(d, sub, counter)
+            if got is None:
                 out["error"] = "%s pass: no dispatch of %s in the counter file (exit code %s)" % (counter, sub, p.returncode)
                 return out
-            big = max(int(r["Grid_Size"]) for r in rows)
-            v = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == big]
-            vals[counter] = (sum(v) / len(v), len(v))
+            vals[counter] = got
         finally:
             shutil.rmtree(d, ignore_errors=True)
     fetch, write = vals["FETCH_SIZE"][0] * 1024.0, vals["WRITE_SIZE"][0] * 1024.0

@@ -158,3 +158,23 @@ def test_flag_constants_match_the_header():
     for name in ("SAVE_AUX", "BG_PER_VIEW", "SKIP_NORMAL", "SKIP_DISTORTION", "EXACT", "FAST", "NO_TILE_CULL", "NO_SMALL_PATH"):
         assert getattr(_lib, "FLAG_" + name) == defs[name], name
     assert len(set(defs.values())) == len(defs)
+
+
+def test_bench_pmc_counter_mean_takes_the_largest_grid_dispatches(tmp_path):
+    """bench.pmc_counter_mean (the parser behind roofline.traffic): mean over the dispatches of the named kernel with the largest
+    grid, other kernels / counters / smaller set-up launches ignored; None when nothing matches."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    d = tmp_path / "pass" / "host"
+    d.mkdir(parents=True)
+    hdr = "Dispatch_Id,Kernel_Name,Grid_Size,Counter_Name,Counter_Value\n"
+    rows = [(1, "void (anonymous namespace)::render3s_fwd_kernel<false, true>(int)", 64 * 100, "FETCH_SIZE", 5.0),      # set-up launch
+            (2, "void (anonymous namespace)::render3s_fwd_kernel<false, true>(int)", 64 * 4000, "FETCH_SIZE", 100.0),
+            (3, "void (anonymous namespace)::render3s_fwd_kernel<false, true>(int)", 64 * 4000, "FETCH_SIZE", 110.0),
+            (4, "void (anonymous namespace)::render3s_fwd_kernel<false, true>(int)", 64 * 4000, "WRITE_SIZE", 7.0),
+            (5, "void (anonymous namespace)::preprocess_kernel<false, false>(int)", 64 * 9000, "FETCH_SIZE", 900.0)]
+    (d / "b_counter_collection.csv").write_text(hdr + "".join('%d,"%s",%d,%s,%r\n' % r for r in rows))
+    assert bench.pmc_counter_mean(str(tmp_path), "render3s_fwd_kernel", "FETCH_SIZE") == (105.0, 2)
+    assert bench.pmc_counter_mean(str(tmp_path), "render3s_fwd_kernel", "WRITE_SIZE") == (7.0, 1)
+    assert bench.pmc_counter_mean(str(tmp_path), "render5_bwd_kernel", "FETCH_SIZE") is None
