@@ -53,6 +53,17 @@ d = lj("bench_default")
 if d and d.get("with_d2h"):
     leg = d["with_d2h"]["uint8_rgb"].get("leg_alone_ms")
     out += ["", "Frame copy leg alone (nothing else on the device): %s" % json.dumps(leg)]
+for name in ("bench_default", "bench_real"):
+    d = lj(name)
+    live = ((d or {}).get("roofline") or {}).get("traffic_live")
+    if live:
+        r = d["roofline"]
+        out += ["", "`%s`: `roofline.traffic` measured inside the run (two rocprofv3 --pmc child passes, %s s): %s GB per launch of %s "
+                "(2 x FETCH_SIZE %.2f GB + WRITE_SIZE %.2f GB; %s dispatches); `frac_on_counter_traffic` %s%s" % (
+                    name, live.get("seconds"), ("%.2f" % (live["bytes_per_launch"] / 1e9)) if live.get("bytes_per_launch") else "null",
+                    live.get("kernel"), (live.get("fetch_size_bytes_x2") or 0) / 1e9, (live.get("write_size_bytes") or 0) / 1e9,
+                    live.get("dispatches_averaged"), ("%.3f" % r["frac_on_counter_traffic"]) if r.get("frac_on_counter_traffic") else "null",
+                    ("; error: " + live["error"]) if live.get("error") else "")]
 for name in ("bench_dropin", "bench_c4_fp32"):
     d = lj(name)
     if d:
