@@ -1397,6 +1397,12 @@ extern "C" int f3dg_backward(void* stream, void* workspace, size_t workspace_byt
     const int acc_stride = dense ? 16 : 10;           // the dense kernel's 128-byte records (ten float64 + seven float32 sums) or [V*P][10]
     F3DG_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)acc_stride * (size_t)n_views * P, s));
     F3DG_HIP_CHECK(hipMemsetAsync(&hdr->bwd_pairs, 0, sizeof(hdr->bwd_pairs), s));
+    if (!dense) {
+        // the per-view outputs need no zero-fill by the caller: the dense path writes every element of them from its records
+        // (preprocess_bwd_kernel); the lock-step kernels add into these two
+        F3DG_HIP_CHECK(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * (size_t)n_views * P, s));
+        F3DG_HIP_CHECK(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * (size_t)n_views * P, s));
+    }
     const int prof = f3dg_prof_bwd_begin(s);
 
 #ifdef F3DG_LAB

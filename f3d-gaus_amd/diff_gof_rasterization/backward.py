@@ -22,9 +22,12 @@ def rasterize_backward_raw(ws, means3D, sh, colors_precomp, scales, rotations, r
     V = ws.n_views
     M = 0 if sh is None or sh.numel() == 0 else sh.size(1)
     z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
-    g = dict(dL_dmeans2D=z(V, P, 3), dL_dconic=z(V, P, 2, 2), dL_dopacity=z(P, 1), dL_dcolors=z(V, P, 3),
+    # f3dg_backward writes every element of the per-view outputs (include/f3dg.h): no 64-float zero-fill per (view, Gaussian) -- 2 GB at
+    # BASELINE C5; dL_dconic is identically zero in the reference (never written, never returned to autograd): one zero, broadcast
+    e = (lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)) if P else z
+    g = dict(dL_dmeans2D=e(V, P, 3), dL_dconic=z(1, 1, 1, 1).expand(V, P, 2, 2), dL_dopacity=z(P, 1), dL_dcolors=e(V, P, 3),
              dL_dmeans3D=z(P, 3), dL_dcov3D=z(P, 6), dL_dsh=z(P, M, 3), dL_dscales=z(P, 3), dL_drotations=z(P, 4),
-             dL_dview2gaussian=z(V, P, 10))
+             dL_dview2gaussian=e(V, P, 10))
     if P == 0:
         return g
     f = lambda t: _dev_f32(t, device)

@@ -173,8 +173,11 @@ long long f3dg_forward(void* stream, void* workspace, size_t workspace_bytes, lo
                        float* out_color, int* radii, unsigned flags, long long* h_needed);
 
 /* Backward of a forward made with F3DG_FLAG_SAVE_AUX on the same workspace (same P, W, H, n_views,
- * max_rendered). Argument meaning follows Rasterizer::backward (rasterizer.h:57-90). All dL_* outputs must be
- * zero-filled by the caller (rasterize_points.cu:160-170); sizes per view v:
+ * max_rendered). Argument meaning follows Rasterizer::backward (rasterizer.h:57-90). The reference's binding zero-fills every
+ * dL_* tensor (rasterize_points.cu:160-170); here the PER-GAUSSIAN sums (dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale, dL_drot) are
+ * added into and must be zero-filled (or hold running sums) by the caller, the PER-VIEW outputs (dL_dmean2D, dL_dcolor,
+ * dL_dview2gaussian: 64 floats per (view, Gaussian), 2 GB at BASELINE C5) are written in full by the call and may be handed over
+ * uninitialised; dL_dconic and dL_dcov3D are never touched (the reference leaves them zero). Sizes per view v:
  *   dL_dpix [n_views,9,H,W] in;  dL_dmean2D [n_views,P,3], dL_dconic [n_views,P,4] (stays 0), dL_dopacity [P],
  *   dL_dcolor [n_views,P,3], dL_dmean3D [P,3], dL_dcov3D [P,6] (stays 0), dL_dsh [P,M,3], dL_dscale [P,3],
  *   dL_drot [P,4], dL_dview2gaussian [n_views,P,10].

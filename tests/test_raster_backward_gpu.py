@@ -231,3 +231,30 @@ def test_dense_backward_agrees_with_the_lock_step_walk(kw, gpu_device):
     # test_backward_vs_oracle with either kernel, not compared here
     for k in ("dL_dview2gaussian", "dL_dopacity", "dL_dcolors", "dL_dmeans2D", "dL_dsh"):
         assert _rel(g1[k], g0[k]) <= 5e-6, (k, _rel(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize("dense", [1, 0])
+def test_per_view_outputs_are_written_in_full(dense, gpu_device):
+    """include/f3dg.h: dL_dmean2D, dL_dcolor and dL_dview2gaussian need no zero-fill by the caller -- the wrapper hands them over
+    uninitialised (2 GB less to fill at BASELINE C5). The allocator's free blocks are poisoned with NaN first; Gaussians behind the
+    camera and off screen (no list entry, no gradient) must come back as exact zeros, with either compositing backward."""
+    from f3dgaus_amd import _lib
+    L = _lib.lib()
+    scene = make_scene(P=6000, res=(96, 80), s0=0.03, view="oblique", n_views=3, seed=5, behind_fraction=0.2, bg=(0.1, 0.5, 0.3))
+    V, H, W = scene["viewmatrix"].shape[0], scene["H"], scene["W"]
+    dpix = np.random.default_rng(3).standard_normal((V, 9, H, W)).astype(np.float32)
+    try:
+        assert L.f3dg_set_option(b"bwd_dense", dense) == 0
+        ref, radii = _hip_fwd_bwd(scene, dpix, gpu_device)
+        poison = [torch.full((V * 6000 * n,), float("nan"), device=gpu_device) for n in (3, 3, 10, 3, 10)]
+        del poison
+        got, _ = _hip_fwd_bwd(scene, dpix, gpu_device)
+    finally:
+        L.f3dg_set_option(b"bwd_dense", 1)
+    hidden = radii.reshape(V, -1) <= 0
+    assert hidden.any()
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dview2gaussian"):
+        assert np.isfinite(got[k]).all(), k
+        assert not got[k][hidden].any(), k
+    for k in got:           # (both kernels add with float atomics in a run-dependent order: equal to the first run up to that)
+        assert _rel(got[k], ref[k]) <= 1e-5 or k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"), k
