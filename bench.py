@@ -496,6 +496,9 @@ def run_c2(args, rank, world, dist, device, comm_device, f3d, L):
                       "slides_with_at_most_8_live_pixels": int(cbuf[8]), "slides_with_at_most_24": int(cbuf[9]),
                       "tail_steps": int(cbuf[10]), "tail_wave_trips": int(cbuf[11]), "tail_entries_tested": int(cbuf[12]),
                       "staged_entries_reaching_a_live_pixel": int(cbuf[13]),
+                      "two_pixels_per_lane_emulation": {"trips_two_32_lane_halves_walked_separately": int(cbuf[14]),
+                                                        "trips_one_32_lane_walk_with_pixels_i_and_i_plus_32_per_lane": int(cbuf[15]),
+                                                        "ratio": (cbuf[15] / cbuf[14]) if cbuf[14] else None},
                       "note": "one untimed step with option render_count = 1 (the same kernel with work counters); staged entries count "
                               "a list entry once per quadrant wave that gathers its record"}
 

@@ -963,6 +963,7 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
 
     unsigned n_tail_steps = 0, n_tail_trips = 0, n_tail_tests = 0, n_useful = 0;
     bool go_tail = false;
+    unsigned n_half_sep = 0, n_half_pair = 0;
     unsigned n_staged = 0, n_trips = 0, n_wave_trips = 0, n_slides = 0, n_t8 = 0, n_t24 = 0, n_s8 = 0, n_s24 = 0;    // COUNT (option render_count): what this wave did, summed into g_f3dg_counts at its end
     unsigned cursor = 0, qhead = 0, qpend = 0;    // wave-uniform: scan position, ring index of the first pending entry, pending entries
     unsigned flip = 0;                            // physical half (slots 32 flip ..) that holds the OLDER half of the window
@@ -1077,6 +1078,18 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
 #endif
         if (COUNT) {                // the loop ran as often as its busiest lane needed (lanes leave it, none re-enters)
             unsigned t = n_trips - trips_before;
+            {
+                // what TWO pixels per lane would buy, emulated at half scale: the wave's two 8 x 4 halves as separate 32-lane walks
+                // (each lasts as long as its busiest pixel) against one 32-lane walk whose lane i takes pixel i and then pixel i + 32
+                unsigned th = t, tp = t + (unsigned)__shfl_xor((int)t, 32, 64);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    th = max(th, (unsigned)__shfl_xor((int)th, o, 64));
+                    tp = max(tp, (unsigned)__shfl_xor((int)tp, o, 64));
+                }
+                n_half_sep += th + (unsigned)__shfl_xor((int)th, 32, 64);
+                n_half_pair += tp;
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o, 64));
             n_wave_trips += t;
@@ -1200,6 +1213,8 @@ render3s_fwd_kernel(int V, int P, int W, int H, int tiles_x, int T, float focal_
         atomicAdd(&c[11], (unsigned long long)n_tail_trips);
         atomicAdd(&c[12], (unsigned long long)n_tail_tests);
         atomicAdd(&c[13], (unsigned long long)n_useful);
+        atomicAdd(&c[14], (unsigned long long)n_half_sep);
+        atomicAdd(&c[15], (unsigned long long)n_half_pair);
         atomicAdd(&c[0], (unsigned long long)n_staged);
         atomicAdd(&c[1], (unsigned long long)(cursor < n ? cursor : n));
         atomicAdd(&c[2], (unsigned long long)n_wave_trips);
