@@ -172,6 +172,7 @@ extern "C" int f3dg_set_option(const char* name, int value)
         g_f3dg_render_pack = value == 4 ? 1 : -1;   // (leaving the shorthand restores the default: ADVICE r05)
         return F3DG_OK;
     }
+    if (strcmp(name, "tile_split") == 0) { g_f3dg_tile_split = value != 0; return F3DG_OK; }
     if (strcmp(name, "render_scan_lanes") == 0) { g_f3dg_render_scan_lanes = value == 2 ? 2 : 4; return F3DG_OK; }
     if (strcmp(name, "render_pretest") == 0) { g_f3dg_render_pretest = value != 0; return F3DG_OK; }
     if (strcmp(name, "render_queue") == 0) { g_f3dg_render_queue = value != 0; return F3DG_OK; }

@@ -178,7 +178,8 @@ struct SegTable {
 // digit of a key in one pass
 struct ShiftDigit {
     int shift;
-    __device__ __forceinline__ u32 operator()(u32 k) const { return (k >> shift) & 255u; }
+    u32 mask = 255u;        // (a pass over fewer than 8 bits: the tile passes split their bits evenly)
+    __device__ __forceinline__ u32 operator()(u32 k) const { return (k >> shift) & mask; }
 };
 // third and LAST pass of a view's depth sort when all its keys lie within 2^24 of kbase (a multiple of 2^16: the low 16 bits of
 // key - kbase are the key's own, which passes 0 and 1 sorted). Keys of Gaussians that touch no tile (~0) land in digit 255; they
@@ -601,26 +602,26 @@ __device__ __forceinline__ bool var_chunk(const SegTable& st, u32 f, u32& k, Seg
 
 template <typename K>
 __global__ void __launch_bounds__(F3DG_BLOCK)
-radix2_hist_var_kernel(const K* __restrict__ keys, SegTable st, int shift, u32* __restrict__ hist)
+radix2_hist_var_kernel(const K* __restrict__ keys, SegTable st, int shift, u32 mask, u32* __restrict__ hist)
 {
     __shared__ u32 h[F3DG_BLOCK / 64][256];
     u32 k = 0;
     SegChunk ck;
     for (u32 f = blockIdx.x >> 3; var_chunk(st, f, k, ck); f += gridDim.x >> 3)
-        hist_chunk<K, ShiftDigit>(keys, ck, ShiftDigit{shift}, hist, h);
+        hist_chunk<K, ShiftDigit>(keys, ck, ShiftDigit{shift, mask}, hist, h);
 }
 
 template <typename K>
 __global__ void __launch_bounds__(F3DG_BLOCK)
 radix2_scatter_var_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in, K* __restrict__ keys_out,
-                          u32* __restrict__ vals_out, SegTable st, int shift, const u32* __restrict__ offsets)
+                          u32* __restrict__ vals_out, SegTable st, int shift, u32 mask, const u32* __restrict__ offsets)
 {
     __shared__ ScatterShared sh;
     __shared__ K skey[F3DG_SORT_CHUNK];
     u32 k = 0;
     SegChunk ck;
     for (u32 f = blockIdx.x >> 3; var_chunk(st, f, k, ck); f += gridDim.x >> 3) {
-        scatter_chunk<K, false, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{shift}, offsets, sh, skey);
+        scatter_chunk<K, false, ShiftDigit>(keys_in, vals_in, keys_out, vals_out, ck, ShiftDigit{shift, mask}, offsets, sh, skey);
         __syncthreads();          // the LDS staging area is reused by the next chunk
     }
 }
@@ -810,6 +811,8 @@ int f3dg_launch_scan_inclusive(hipStream_t s, const unsigned* in, unsigned* out,
 int f3dg_tile_bits(int T) { return bits_for((unsigned long long)T); }
 
 // Number of 8-bit passes over the instances: only the tile bits (instances are generated in (view, depth, id) order).
+int g_f3dg_tile_split = 1;         // lab option tile_split: two tile passes split their bits evenly (1, default) or 8 + rest (0)
+
 int f3dg_sort_passes(int V, int T)
 {
     (void)V;
@@ -887,14 +890,20 @@ static int binning_tail(hipStream_t s, int V, int P, int grid_x, int T, int tile
         const size_t nbmax = (size_t)L.sort_blocks + (size_t)V;                // >= sum over the views of ceil(instances / chunk)
         const u32 per_xcd = (u32)((nbmax + 7) / 8 < 160 ? (nbmax + 7) / 8 : 160);   // 5 workgroups per CU of the scatter's LDS
         const u32 per_xcd_h = (u32)((nbmax + 7) / 8 < 512 ? (nbmax + 7) / 8 : 512);
+        // two passes (257..65,536 tiles: 512^2 images have 1,024): the tile bits are split EVENLY, 5 + 5 instead of 8 + 2 -- a pass costs
+        // the same whatever its digit width, and a chunk's runs of equal digits, which leave LDS as coalesced stores, are 8 x longer
+        // with 32 digits than with 256 (option tile_split 0: the 8-bit digits of rounds 1-5)
+        const int split = (passes == 2 && g_f3dg_tile_split) ? (tile_bits + 1) / 2 : 8;
         for (int p = 0; p < passes; p++) {
+            const int shift = split * p;
+            const u32 mask = (passes == 2 && g_f3dg_tile_split) ? (1u << (p == 0 ? split : tile_bits - split)) - 1u : 255u;
             F3DG_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(u32) * 256 * nbmax, s));
-            F3DG_KLAUNCH((radix2_hist_var_kernel<G>), dim3(8 * per_xcd_h), dim3(F3DG_BLOCK), 0, s, kgrp[src], st, 8 * p, hist);
+            F3DG_KLAUNCH((radix2_hist_var_kernel<G>), dim3(8 * per_xcd_h), dim3(F3DG_BLOCK), 0, s, kgrp[src], st, shift, mask, hist);
             rc = f3dg_launch_scan_inclusive(s, hist, hist, (unsigned long long)256 * nbmax, scan_tmp, L.scan_tmp_elems, 1, nullptr);
             if (rc != F3DG_OK) return rc;
             // (a single pass: the group stream is not needed again, the ranges come from the scanned histogram)
             F3DG_KLAUNCH((radix2_scatter_var_kernel<G>), dim3(8 * per_xcd), dim3(F3DG_BLOCK), 0, s, kgrp[src], vals[src],
-                               passes == 1 ? (G*)nullptr : kgrp[src ^ 1], vals[src ^ 1], st, 8 * p, hist);
+                               passes == 1 ? (G*)nullptr : kgrp[src ^ 1], vals[src ^ 1], st, shift, mask, hist);
             src ^= 1;
         }
         if (passes == 1) {

@@ -272,6 +272,7 @@ int f3dg_launch_render4(hipStream_t s, int V, int P, int W, int H, float focal_x
 // the split-pixel compositing forward (f3dg_render5.hip; F3DG_FLAG_SCAN / option render_scan: fast inference launches of the general path)
 extern int g_f3dg_render_scan;         // -1 (default): calls with F3DG_FLAG_SCAN; 1: every eligible launch; 0: never
 extern int g_f3dg_render_scan_min;     // stragglers holding fewer older-half entries than this finish the slide in fused trips (default 4; 0: always compact)
+extern int g_f3dg_tile_split;          // two tile passes of the binning split their bits evenly (default 1; lab option tile_split)
 extern int g_f3dg_render_scan_lanes;   // lanes per pixel of the one- and two-view scan kernel (render5p): 4 (default) or 2 (lab option render_scan_lanes)
 extern int g_f3dg_render_scan_th;      // fused trips while more than this many pixels take part (default 20)
 int f3dg_launch_render5(hipStream_t s, int V, int P, int W, int H, float focal_x, float focal_y, const F3dgHeader* hdr, const uint2* ranges,
